@@ -1,0 +1,143 @@
+/* libpunet_hip.so - C ABI of the MI355X-native (gfx950 / CDNA4) Probabilistic U-Net self-training hot path.
+ *
+ * Drop-in boundary.  The reference (/root/reference, pure Python) has no FFI of its own: its hot path
+ * is reached through nn.Module methods (prob_utils/my_models/probabilistic_unet.py:285-371) and trainer bodies
+ * (prob_utils/my_trainer/*.py).  Each entry point below replaces the ATen op(s) that the cited reference line
+ * dispatches; the host-side mirror of the reference API that calls them lives in
+ * probabilistic_domain_adaptation_amd/{my_models,my_trainer,my_predictions} (ctypes binding: _lib.py; the stub a
+ * reference maintainer would add is shown in INTEGRATION.md).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (a PyTorch-ROCm tensor's
+ *    data_ptr(), or hipMalloc); the library owns nothing and allocates nothing.
+ *  - activations are NHWC fp32: x[b][y][x][c]; a [B,1,H,W] tensor (logits, labels, masks) has the same bytes in NCHW.
+ *  - conv weights are [ky][kx][cin][cout] fp32 (the canonical parameter layout of this build; the Python side exposes
+ *    them under the reference's state-dict names/shapes [cout,cin,ky,kx] as permuted views of the same memory).
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work is enqueued on it,
+ *    no hidden synchronisation, no host reads -> every call is hipGraph-capturable.
+ *  - return 0 on success, negative on error (PUNET_ERR_ARG = -1 bad argument, PUNET_ERR_HIP = -2 launch failure);
+ *    punet_last_error() returns a thread-local message.  Nothing throws across the ABI.
+ *  - `workspace` pointers are caller-provided scratch; the matching *_workspace_floats() gives the required size.
+ *  - all reductions are two-pass with fixed summation order (bit-reproducible run to run; no float atomics).
+ */
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* punet_last_error(void);
+const char* punet_build_info(void);
+int punet_device_ok(void);
+
+/* ---- K1: nn.Conv2d(3x3 p1 | 1x1) [+ ReLU] with cin >= 8, fp32 MFMA (unet_blocks.py:19-24, probabilistic_unet.py:56-61,
+ *      168-173).  Optional second source = the channel concat of unet_blocks.py:56 ([up, bridge]) without materialising
+ *      it.  bias_img_stride = 0: bias[cout]; = cout: bias[b][cout] (Fcomb's folded z term, probabilistic_unet.py:206-212).
+ *      c0, c1 multiples of 8; cout multiple of 4. */
+int punet_conv_fwd(const float* x0, int c0, const float* x1, int c1, const float* w, const float* bias,
+                   int bias_img_stride, float* y, int cout, int B, int H, int W, int ksize, int relu, void* stream);
+
+/* ---- K2: autograd input gradient of K1 (convolution_backward, input): dx[.., cin_off : cin_off+cin] of the conv whose
+ *      weight is w[k][k][cin_total][cout]; epilogue multiplies by (mask > 0) when mask != NULL (ReLU backward of the
+ *      tensor that dx belongs to) and adds into dx when accumulate != 0 (skip connections). */
+int punet_conv_dgrad(const float* dz, int cout, const float* w, int cin_total, int cin_off, int cin, float* dx,
+                     const float* mask, int accumulate, int B, int H, int W, int ksize, void* stream);
+
+/* ---- K3: autograd weight + bias gradient of K1 (convolution_backward, weight/bias), fp32 MFMA, deterministic split-K.
+ *      x has cs channels and fills rows [ci_off, ci_off+cs) of dw[k][k][cin_total][cout]; dbias may be NULL.
+ *      dw/db (+)= scale * grad when accumulate != 0, else = scale * grad. */
+size_t punet_wgrad_workspace_floats(int cs, int cout, int ksize, int nslices);
+int punet_wgrad_slices(int cs, int cout, int B, int H, int W);
+int punet_conv_wgrad(const float* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off,
+                     float* dbias, float* workspace, int nslices, int B, int H, int W, int ksize, int accumulate,
+                     float scale, void* stream);
+
+/* ---- K1s: first-layer 3x3 conv with cin in 1..4 (image / [image, mask], probabilistic_unet.py:39-42,118) and its
+ *      weight + bias gradient (no input gradient exists). */
+int punet_conv3x3_small_fwd(const float* x, int cin, const float* w, const float* bias, float* y, int cout, int B,
+                            int H, int W, int relu, void* stream);
+size_t punet_small_wgrad_workspace_floats(int cin, int cout);
+int punet_conv3x3_small_wgrad(const float* x, int cin, const float* dz, int cout, float* dw, float* dbias,
+                              float* workspace, int B, int H, int W, int accumulate, float scale, void* stream);
+
+/* ---- K4: nn.AvgPool2d(2, 2, ceil_mode=True) (unet_blocks.py:17, probabilistic_unet.py:54) and backward
+ *      (dx (+)= (xmask > 0) * dy / window). */
+int punet_pool2x2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
+int punet_pool2x2_bwd(const float* dy, const float* xmask, float* dx, int B, int H, int W, int C, int accumulate,
+                      void* stream);
+
+/* ---- K5: F.interpolate(bilinear, scale_factor=2, align_corners=True) (unet_blocks.py:51) and backward (gather form,
+ *      dx = (xmask > 0) * ...). H, W are the INPUT sizes. */
+int punet_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
+int punet_upsample2x_bwd(const float* dy, const float* xmask, float* dx, int B, int H, int W, int C, void* stream);
+
+/* ---- K6: latent head (probabilistic_unet.py:126-137): mean over H, W then 1x1 conv C -> J = 2*latent_dim.
+ *      muls[b][:L] = mu, muls[b][L:] = log_sigma.  mean[b][C] is kept for the backward. */
+size_t punet_chan_sum_workspace_floats(int B, int P, int C);
+int punet_chan_sum(const float* x, float* out, float* workspace, int B, int P, int C, float scale, void* stream);
+int punet_latent_head_fwd(const float* enc, const float* w, const float* bias, float* mean, float* muls,
+                          float* workspace, int B, int P, int C, int J, void* stream);
+int punet_latent_head_bwd(const float* d_muls, const float* mean, const float* w, const float* enc, float* dw, float* db,
+                          float* dmean, float* denc, int B, int P, int C, int J, int accumulate, void* stream);
+/* z[n][b][:] = mu[b] + exp(log_sigma[b]) * eps[n][b]   (Independent(Normal).rsample, probabilistic_unet.py:141,302,349) */
+int punet_reparam(const float* muls, const float* eps, float* z, int N, int B, int L, void* stream);
+/* kl[0] = mean_b KL(q_b || p_b)  (probabilistic_unet.py:332,351-353) */
+int punet_latent_kl(const float* muls_q, const float* muls_p, float* kl, int B, int L, void* stream);
+/* d(coef * B * kl)/d muls + reparameterisation gradient of the upstream dz; coef = gscale * beta / B */
+int punet_latent_kl_bwd(const float* muls_q, const float* muls_p, const float* eps, const float* dz, float coef,
+                        float* d_muls_q, float* d_muls_p, int B, int L, void* stream);
+
+/* ---- Fcomb pieces (probabilistic_unet.py:200-214) used by the single-sample training path */
+int punet_fcomb_zbias(const float* z, const float* w1, const float* b1, float* zb, int NB, int L, int CH, void* stream);
+/* backward of the folded z term: S[b][CH] = per-image column sums of dZ1 (punet_chan_sum) */
+int punet_fcomb_z_bwd(const float* S, const float* z, const float* w1, float* dw1, float* dz, int B, int L, int CH,
+                      int accumulate, void* stream);
+int punet_dot_bias(const float* h, const float* w3, const float* b3, float* logits, long P, int C, void* stream);
+size_t punet_dot_bwd_workspace_floats(int C);
+int punet_dot_bwd(const float* h, const float* dlogit, const float* w3, float* dz, float* dw3, float* db3,
+                  float* workspace, long P, int C, int accumulate, void* stream);
+
+/* ---- K7: persistent latent-sampler + Fcomb + consensus kernel (mean_teacher_trainer.py:72-88, fixmatch_trainer.py:37-54,
+ *      punet_predictions.py:29-33,108-124).  zb[N][B][CH] from punet_fcomb_zbias.  y = mean_n sigmoid(logit_n);
+ *      z = fraction of samples with sigmoid >= upper or <= lower (masking = 0) or its (== 1) indicator (masking = 1);
+ *      logits[N][P] optional.  CH = num_filters[0] in {32, 64}; nmid = no_convs_fcomb - 2 middle layers. */
+int punet_fcomb_sample(const float* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
+                       const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z,
+                       float* logits, int N, int B, int HW, int CH, int nmid, float upper, float lower, int masking,
+                       void* stream);
+
+/* ---- K8: the reduction half of K7 on given logits[N][P] (unit parity of the consensus rule) */
+int punet_consensus(const float* logits, int N, long P, float upper, float lower, int masking, float* y, float* z,
+                    void* stream);
+
+/* ---- K9: reconstruction loss forward + d/dlogit (probabilistic_unet.py:347-369).  consm (nullable, float) multiplies
+ *      BOTH logits and targets as :363-364 does.  dlogit = gscale * dloss/dlogit.
+ *      BCE: loss_sum[0] = sum of BCEWithLogits(reduction none).  Dice: [recalled torch_em definition, parity unpinned]. */
+size_t punet_loss_workspace_floats(void);
+int punet_bce_fwd_bwd(const float* logits, const float* target, const float* consm, float gscale, float* dlogit,
+                      float* loss_sum, float* workspace, long P, void* stream);
+int punet_dice_fwd_bwd(const float* logits, const float* target, const float* consm, float gscale, float* dlogit,
+                       float* loss_out, float* workspace, long P, void* stream);
+
+/* ---- E1: dice_score sums (my_utils/util.py:17-44): sums3 = [sum(gt*seg), sum(gt), sum(seg)] */
+int punet_dice_score_sums(const float* seg, const float* gt, float thr_seg, int use_thr_seg, float thr_gt, int use_thr_gt,
+                          float* sums3, float* workspace, long P, void* stream);
+
+/* ---- K10: l2_regularisation (utils.py:32-40) over a chunk table {offset, length, tensor index} (int64 triples) */
+int punet_l2_reg(const float* w, const int64_t* chunks, int nchunks, int ntensors, float* partial, float* norms,
+                 float* reg_out, void* stream);
+int punet_l2_reg_add_grad(const float* w, float* g, const int64_t* chunks, int nchunks, const float* norms, float coef,
+                          void* stream);
+
+/* ---- K11 + K12: torch.optim.Adam step (LIVECell/livecell_mt.py:83 defaults) fused with the EMA teacher update
+ *      (mean_teacher_trainer.py:52-55; adamt_trainer.py:40-43) on flat buffers.  teacher may be NULL (no EMA);
+ *      do_adam = 0 performs the EMA alone.  The gradient is read as g * gscale (1/world_size after all-reduce). */
+int punet_adam_ema(float* p, const float* g, float* m, float* v, float* teacher, long n, float gscale, float lr,
+                   float beta1, float beta2, float eps, int step, float ema_momentum, int do_adam, void* stream);
+int punet_scale(float* x, long n, float s, void* stream);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,104 @@
+"""ctypes binding of libpunet_hip.so (C ABI declared in include/punet_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpunet_hip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_l = C.c_long
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); every int-returning entry point is wrapped to raise on a non-zero code
+_SIGS = {
+    "punet_last_error": (C.c_char_p, []),
+    "punet_build_info": (C.c_char_p, []),
+    "punet_device_ok": (_i, []),
+    "punet_conv_fwd": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "punet_conv_dgrad": (_i, [_p, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "punet_wgrad_workspace_floats": (_sz, [_i, _i, _i, _i]),
+    "punet_wgrad_slices": (_i, [_i, _i, _i, _i, _i]),
+    "punet_conv_wgrad": (_i, [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "punet_conv3x3_small_fwd": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "punet_small_wgrad_workspace_floats": (_sz, [_i, _i]),
+    "punet_conv3x3_small_wgrad": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "punet_pool2x2_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "punet_pool2x2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "punet_upsample2x_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "punet_upsample2x_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "punet_chan_sum_workspace_floats": (_sz, [_i, _i, _i]),
+    "punet_chan_sum": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
+    "punet_latent_head_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "punet_latent_head_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "punet_reparam": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "punet_latent_kl": (_i, [_p, _p, _p, _i, _i, _p]),
+    "punet_latent_kl_bwd": (_i, [_p, _p, _p, _p, _f, _p, _p, _i, _i, _p]),
+    "punet_fcomb_zbias": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "punet_fcomb_z_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "punet_dot_bias": (_i, [_p, _p, _p, _p, _l, _i, _p]),
+    "punet_dot_bwd_workspace_floats": (_sz, [_i]),
+    "punet_dot_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _p]),
+    "punet_fcomb_sample": (_i, [_p, _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
+    "punet_consensus": (_i, [_p, _i, _l, _f, _f, _i, _p, _p, _p]),
+    "punet_loss_workspace_floats": (_sz, []),
+    "punet_bce_fwd_bwd": (_i, [_p, _p, _p, _f, _p, _p, _p, _l, _p]),
+    "punet_dice_fwd_bwd": (_i, [_p, _p, _p, _f, _p, _p, _p, _l, _p]),
+    "punet_dice_score_sums": (_i, [_p, _p, _f, _i, _f, _i, _p, _p, _l, _p]),
+    "punet_l2_reg": (_i, [_p, _p, _i, _i, _p, _p, _p, _p]),
+    "punet_l2_reg_add_grad": (_i, [_p, _p, _p, _i, _p, _f, _p]),
+    "punet_adam_ema": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _f, _i, _p]),
+    "punet_scale": (_i, [_p, _l, _f, _p]),
+}
+
+_NO_WRAP = {"punet_last_error", "punet_build_info", "punet_device_ok", "punet_wgrad_workspace_floats",
+            "punet_wgrad_slices", "punet_small_wgrad_workspace_floats", "punet_chan_sum_workspace_floats",
+            "punet_dot_bwd_workspace_floats", "punet_loss_workspace_floats"}
+
+_lib = None
+_fn = {}
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def load():
+    """dlopen the library and bind every symbol.  Raises RuntimeError when it is missing (no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        try:
+            f = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"libpunet_hip.so does not export {name}") from e
+        f.restype = res
+        f.argtypes = args
+        _fn[name] = f
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    load()
+    return _fn["punet_last_error"]().decode()
+
+
+def call(name, *args):
+    """Call an entry point; int-returning ones raise RuntimeError(punet_last_error()) on failure."""
+    if _lib is None:
+        load()
+    r = _fn[name](*args)
+    if name not in _NO_WRAP and r != 0:
+        raise RuntimeError(f"{name} failed ({r}): {last_error()}")
+    return r

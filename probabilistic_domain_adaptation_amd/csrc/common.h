@@ -1,0 +1,41 @@
+// Shared helpers for libpunet_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PUNET_OK 0
+#define PUNET_ERR_ARG (-1)
+#define PUNET_ERR_HIP (-2)
+
+void punet_set_error(const char* fmt, ...);
+
+#define PUNET_CHECK_ARG(cond, ...)          \
+    do {                                    \
+        if (!(cond)) {                      \
+            punet_set_error(__VA_ARGS__);   \
+            return PUNET_ERR_ARG;           \
+        }                                   \
+    } while (0)
+
+#define PUNET_LAUNCH_CHECK(name)                                                  \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) {                                                   \
+            punet_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return PUNET_ERR_HIP;                                                 \
+        }                                                                         \
+    } while (0)
+
+// out[(row / cs) * cin_total + ci_off + row % cs][col] (+)= scale * sum_s partial[s * slab_stride + row * cols + col]
+// (slabs summed in slice order: deterministic).  Defined in pointwise.hip.
+int punet_launch_reduce_slabs(const float* partial, int nslices, size_t slab_stride, int rows, int cols, int cs,
+                              int cin_total, int ci_off, float* out, int accumulate, float scale, hipStream_t stream);
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// C/D fragment map of v_mfma_f32_32x32x2_f32 (dtype independent on gfx950):
+//   col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+__device__ __forceinline__ int mfma32_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }

@@ -1,0 +1,164 @@
+// K1s: first-layer 3x3 convolutions with 1..4 input channels (image, or [image, mask] of the posterior
+// encoder: probabilistic_unet.py:39-42,118) and their weight/bias gradients.
+//
+// These layers are HBM-bound (a few FLOP per output byte), so they stay on the VALU: every thread owns
+// four consecutive output channels of a pixel (Cout/4 threads per pixel -> one coalesced 16 B x Cout/4
+// store per pixel), keeps its 9*CIN weight float4s in registers and walks a strip of pixels.
+// No input gradient exists for them (the image needs none).
+#include "common.h"
+#include "punet_hip.h"
+
+namespace {
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int cout, int B, int H, int W, int relu, int pix_per_block) {
+    const int groups = cout / 4;
+    const int ppb = 256 / groups;
+    const int g = threadIdx.x % groups, pl = threadIdx.x / groups;
+    if (pl >= ppb) return;
+    float4 wr[9 * CIN];
+#pragma unroll
+    for (int i = 0; i < 9 * CIN; ++i) wr[i] = *reinterpret_cast<const float4*>(w + (size_t)i * cout + g * 4);
+    const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t P = (size_t)B * H * W;
+    const size_t base = (size_t)blockIdx.x * pix_per_block;
+    for (int it = 0; it < pix_per_block; it += ppb) {
+        const size_t p = base + it + pl;
+        if (p >= P) break;
+        const int px = (int)(p % W);
+        const int py = (int)((p / W) % H);
+        const size_t b = p / ((size_t)W * H);
+        float4 o = bv;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int gy = py + t / 3 - 1, gx = px + t % 3 - 1;
+            if (gy < 0 || gy >= H || gx < 0 || gx >= W) continue;
+            const float* xp = x + ((b * H + gy) * W + gx) * CIN;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const float xv = xp[c];
+                const float4 ww = wr[t * CIN + c];
+                o.x = fmaf(xv, ww.x, o.x); o.y = fmaf(xv, ww.y, o.y);
+                o.z = fmaf(xv, ww.z, o.z); o.w = fmaf(xv, ww.w, o.w);
+            }
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *reinterpret_cast<float4*>(y + p * cout + g * 4) = o;
+    }
+}
+
+// partial[block][9*CIN + 1][cout]: rows 0..9*CIN-1 = dW[tap][ci][:], last row = dbias
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_small_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                                 float* __restrict__ partial, int cout, int B, int H, int W) {
+    constexpr int ROWS = 9 * CIN + 1;
+    extern __shared__ __attribute__((aligned(16))) float4 sred[];  // [4 waves][ROWS][groups]
+    const int groups = cout / 4;
+    const int ppb = 256 / groups;
+    const int g = threadIdx.x % groups, pl = threadIdx.x / groups;
+    float4 acc[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t P = (size_t)B * H * W;
+    if (pl < ppb) {
+        for (size_t p = (size_t)blockIdx.x * ppb + pl; p < P; p += (size_t)gridDim.x * ppb) {
+            const int px = (int)(p % W);
+            const int py = (int)((p / W) % H);
+            const size_t b = p / ((size_t)W * H);
+            const float4 d = *reinterpret_cast<const float4*>(dz + p * cout + g * 4);
+            acc[ROWS - 1].x += d.x; acc[ROWS - 1].y += d.y; acc[ROWS - 1].z += d.z; acc[ROWS - 1].w += d.w;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int gy = py + t / 3 - 1, gx = px + t % 3 - 1;
+                if (gy < 0 || gy >= H || gx < 0 || gx >= W) continue;
+                const float* xp = x + ((b * H + gy) * W + gx) * CIN;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) {
+                    const float xv = xp[c];
+                    float4& a = acc[t * CIN + c];
+                    a.x = fmaf(xv, d.x, a.x); a.y = fmaf(xv, d.y, a.y);
+                    a.z = fmaf(xv, d.z, a.z); a.w = fmaf(xv, d.w, a.w);
+                }
+            }
+        }
+    }
+    // reduce over the pixel lanes of a wave (lanes with equal g), then over the 4 waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        for (int off = groups; off < 64; off <<= 1) {
+            acc[i].x += __shfl_xor(acc[i].x, off); acc[i].y += __shfl_xor(acc[i].y, off);
+            acc[i].z += __shfl_xor(acc[i].z, off); acc[i].w += __shfl_xor(acc[i].w, off);
+        }
+        if (lane < groups) sred[(wave * ROWS + i) * groups + lane] = acc[i];
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < ROWS * groups; u += 256) {
+        float4 s = sred[u];
+        for (int wv = 1; wv < 4; ++wv) {
+            const float4 v = sred[wv * ROWS * groups + u];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const int row = u / groups, gg = u % groups;
+        *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * ROWS + row) * cout + gg * 4) = s;
+    }
+}
+
+constexpr int SMALL_WGRAD_BLOCKS = 1024;
+
+}  // namespace
+
+extern "C" int punet_conv3x3_small_fwd(const float* x, int cin, const float* w, const float* bias, float* y, int cout,
+                                       int B, int H, int W, int relu, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PUNET_CHECK_ARG(x && w && y, "punet_conv3x3_small_fwd: null pointer");
+    PUNET_CHECK_ARG(cin >= 1 && cin <= 4, "punet_conv3x3_small_fwd: cin must be 1..4 (got %d)", cin);
+    PUNET_CHECK_ARG(cout >= 4 && cout % 4 == 0 && 256 % (cout / 4) == 0 && cout <= 1024,
+                    "punet_conv3x3_small_fwd: cout/4 must divide 256 (got cout=%d)", cout);
+    const size_t P = (size_t)B * H * W;
+    const int ppb = 256 / (cout / 4);
+    const int pix_per_block = ppb * 16;
+    const int grid = (int)((P + pix_per_block - 1) / pix_per_block);
+    switch (cin) {
+        case 1: conv3x3_small_fwd_kernel<1><<<grid, 256, 0, stream>>>(x, w, bias, y, cout, B, H, W, relu, pix_per_block); break;
+        case 2: conv3x3_small_fwd_kernel<2><<<grid, 256, 0, stream>>>(x, w, bias, y, cout, B, H, W, relu, pix_per_block); break;
+        case 3: conv3x3_small_fwd_kernel<3><<<grid, 256, 0, stream>>>(x, w, bias, y, cout, B, H, W, relu, pix_per_block); break;
+        default: conv3x3_small_fwd_kernel<4><<<grid, 256, 0, stream>>>(x, w, bias, y, cout, B, H, W, relu, pix_per_block); break;
+    }
+    PUNET_LAUNCH_CHECK("conv3x3_small_fwd");
+    return PUNET_OK;
+}
+
+extern "C" size_t punet_small_wgrad_workspace_floats(int cin, int cout) {
+    return (size_t)SMALL_WGRAD_BLOCKS * (9 * cin + 1) * cout;
+}
+
+extern "C" int punet_conv3x3_small_wgrad(const float* x, int cin, const float* dz, int cout, float* dw, float* dbias,
+                                         float* workspace, int B, int H, int W, int accumulate, float scale,
+                                         void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PUNET_CHECK_ARG(x && dz && dw && dbias && workspace, "punet_conv3x3_small_wgrad: null pointer");
+    PUNET_CHECK_ARG(cin >= 1 && cin <= 4, "punet_conv3x3_small_wgrad: cin must be 1..4 (got %d)", cin);
+    PUNET_CHECK_ARG(cout >= 4 && cout % 4 == 0 && 64 % (cout / 4) == 0,
+                    "punet_conv3x3_small_wgrad: cout/4 must divide 64 (got cout=%d)", cout);
+    const size_t P = (size_t)B * H * W;
+    const int groups = cout / 4, ppb = 256 / groups;
+    int grid = (int)((P + ppb - 1) / ppb);
+    if (grid > SMALL_WGRAD_BLOCKS) grid = SMALL_WGRAD_BLOCKS;
+    const int rows = 9 * cin + 1;
+    const size_t shmem = (size_t)4 * rows * groups * sizeof(float4);
+    switch (cin) {
+        case 1: conv3x3_small_wgrad_kernel<1><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W); break;
+        case 2: conv3x3_small_wgrad_kernel<2><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W); break;
+        case 3: conv3x3_small_wgrad_kernel<3><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W); break;
+        default: conv3x3_small_wgrad_kernel<4><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W); break;
+    }
+    PUNET_LAUNCH_CHECK("conv3x3_small_wgrad");
+    const size_t slab = (size_t)rows * cout;
+    int rc = punet_launch_reduce_slabs(workspace, grid, slab, 9 * cin, cout, cin, cin, 0, dw, accumulate, scale, stream);
+    if (rc != PUNET_OK) return rc;
+    return punet_launch_reduce_slabs(workspace + (size_t)9 * cin * cout, grid, slab, 1, cout, 1, 1, 0, dbias, accumulate,
+                                     scale, stream);
+}

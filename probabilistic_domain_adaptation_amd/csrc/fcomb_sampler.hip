@@ -1,0 +1,178 @@
+// K7: persistent latent-sampler + Fcomb kernel with the consensus / mean epilogue.
+//
+// Replaces the N-sample Monte-Carlo loop of the reference:
+//   [sigmoid(model.sample()) for _ in range(n_samples)]  + thresholds + stack/sum
+//   (prob_utils/my_trainer/mean_teacher_trainer.py:72-88, fixmatch_trainer.py:37-54,
+//    my_predictions/punet_predictions.py:29-33,108-124) where every sample() runs
+//   Fcomb.forward (probabilistic_unet.py:200-214): tile z, cat [features, z], 1x1 convs.
+// The reference materialises a [B, C+L, H, W] concat plus two [B, C, H, W] temporaries per sample;
+// here nothing per-sample ever reaches HBM.
+//
+// Algebra (exact up to fp32 summation order): the first 1x1 conv splits into a feature term
+//   T1 = W1[:C]^T . F  (computed ONCE per pixel) and a z term folded into a per-(sample, image) bias
+//   zb = b1 + W1[C:]^T . z  (punet_fcomb_zbias).  Per sample only relu(T1 + zb), the middle 1x1
+//   conv(s), the last C->1 dot, the sigmoid and the consensus test remain.
+// Mapping: one wave = 32 consecutive pixels.  All products are computed "channels x pixels"
+//   (A = weights [cout][k], B = activations [k][pixel]) so that the 32x32 accumulator tile of one layer,
+//   which holds pixel = lane & 31 and 16 channels in its registers, IS the B operand of the next
+//   layer's v_mfma_f32_32x32x2_f32 - activations never leave the register file between layers.
+// Persistent: the grid is a fixed number of workgroups that stride over the pixel tiles; the weights
+//   (<= 64 KB) are staged in LDS once per workgroup.
+#include "common.h"
+#include "punet_hip.h"
+
+namespace {
+
+struct SamplerArgs {
+    const float* feat;   // [P][CH]
+    const float* w1;     // [CH + L][CH]   (rows 0..CH-1 used here)
+    const float* zb;     // [N][B][CH]
+    const float* wmid;   // [NMID][CH][CH]
+    const float* bmid;   // [NMID][CH]
+    const float* w3;     // [CH]
+    const float* b3;     // [1]
+    float* y;            // [P] mean of sigmoids (nullable)
+    float* z;            // [P] consensus (nullable)
+    float* logits;       // [N][P] (nullable)
+    long wmid_stride, bmid_stride;  // elements between consecutive middle layers
+    int N, B, HW, nmid, masking, ntiles;
+    float upper, lower;
+};
+
+template <int NBLK>
+__global__ __launch_bounds__(256) void fcomb_sampler_kernel(SamplerArgs a) {
+    constexpr int CH = 32 * NBLK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sW1 = smem;                          // [CH][CH]
+    float* sWm = sW1 + CH * CH;                 // [nmid][CH][CH]
+    float* sBm = sWm + a.nmid * CH * CH;        // [nmid][CH]
+    float* sW3 = sBm + a.nmid * CH;             // [CH]
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < CH * CH / 4; i += 256)
+        reinterpret_cast<float4*>(sW1)[i] = reinterpret_cast<const float4*>(a.w1)[i];
+    for (int l = 0; l < a.nmid; ++l) {
+        for (int i = tid; i < CH * CH; i += 256) sWm[l * CH * CH + i] = a.wmid[l * a.wmid_stride + i];
+        for (int i = tid; i < CH; i += 256) sBm[l * CH + i] = a.bmid[l * a.bmid_stride + i];
+    }
+    for (int i = tid; i < CH; i += 256) sW3[i] = a.w3[i];
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const float b3 = a.b3[0];
+    const size_t P = (size_t)a.B * a.HW;
+
+    for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += gridDim.x * 4) {
+        const size_t pix = (size_t)tile * 32 + l31;
+        const int b = (int)(((size_t)tile * 32) / a.HW);
+
+        // ---- feature term, once per pixel: T1[co][pix] = sum_k W1[k][co] * F[pix][k]
+        // k slot of half h in step (g, e) is channel 8g + 4h + e (A and B use the same bijection)
+        float4 fr[CH / 8];
+#pragma unroll
+        for (int g = 0; g < CH / 8; ++g)
+            fr[g] = *reinterpret_cast<const float4*>(a.feat + pix * CH + 8 * g + 4 * half);
+        f32x16 t1[NBLK];
+#pragma unroll
+        for (int cb = 0; cb < NBLK; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t1[cb][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < CH / 8; ++g) {
+            const float fv[4] = {fr[g].x, fr[g].y, fr[g].z, fr[g].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 8 * g + e;  // + 4 * half at run time
+#pragma unroll
+                for (int cb = 0; cb < NBLK; ++cb) {
+                    const float av = sW1[(k + 4 * half) * CH + cb * 32 + l31];
+                    t1[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, fv[e], t1[cb], 0, 0, 0);
+                }
+            }
+        }
+
+        float ysum = 0.f, cnt = 0.f;
+        for (int n = 0; n < a.N; ++n) {
+            const float* zbp = a.zb + ((size_t)n * a.B + b) * CH;
+            f32x16 ha[NBLK], hb[NBLK];
+#pragma unroll
+            for (int cb = 0; cb < NBLK; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ha[cb][r] = fmaxf(t1[cb][r] + zbp[cb * 32 + mfma32_row(r, half)], 0.f);
+
+            for (int l = 0; l < a.nmid; ++l) {
+                const float* wl = sWm + l * CH * CH;
+                const float* bl = sBm + l * CH;
+#pragma unroll
+                for (int ob = 0; ob < NBLK; ++ob) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hb[ob][r] = 0.f;
+#pragma unroll
+                    for (int cb = 0; cb < NBLK; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float av = wl[(cb * 32 + mfma32_row(r, half)) * CH + ob * 32 + l31];
+                            hb[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, ha[cb][r], hb[ob], 0, 0, 0);
+                        }
+                }
+#pragma unroll
+                for (int ob = 0; ob < NBLK; ++ob)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ha[ob][r] = fmaxf(hb[ob][r] + bl[ob * 32 + mfma32_row(r, half)], 0.f);
+            }
+
+            float part = 0.f;
+#pragma unroll
+            for (int cb = 0; cb < NBLK; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part = fmaf(ha[cb][r], sW3[cb * 32 + mfma32_row(r, half)], part);
+            const float logit = part + __shfl_xor(part, 32) + b3;
+            if (a.logits && half == 0) a.logits[(size_t)n * P + pix] = logit;
+            const float s = 1.f / (1.f + expf(-logit));
+            ysum += s;
+            cnt += (s >= a.upper || s <= a.lower) ? 1.f : 0.f;
+        }
+        if (half == 0) {
+            if (a.y) a.y[pix] = ysum / (float)a.N;
+            if (a.z) {
+                const float c = cnt / (float)a.N;
+                a.z[pix] = a.masking ? (c == 1.f ? 1.f : 0.f) : c;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int punet_fcomb_sample(const float* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
+                                  const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z, float* logits, int N, int B, int HW,
+                                  int CH, int nmid, float upper, float lower, int masking, void* stream) {
+    PUNET_CHECK_ARG(feat && w1 && zb && w3 && b3, "punet_fcomb_sample: null pointer");
+    PUNET_CHECK_ARG(CH == 32 || CH == 64, "punet_fcomb_sample: num_filters[0] must be 32 or 64 (got %d)", CH);
+    PUNET_CHECK_ARG(nmid >= 0 && nmid <= 4 && (nmid == 0 || (wmid && bmid)), "punet_fcomb_sample: bad nmid %d", nmid);
+    PUNET_CHECK_ARG(N > 0 && B > 0 && HW > 0 && HW % 32 == 0, "punet_fcomb_sample: H*W must be a multiple of 32 (got %d)", HW);
+    SamplerArgs a{};
+    a.feat = feat; a.w1 = w1; a.zb = zb; a.wmid = wmid; a.bmid = bmid; a.wmid_stride = wmid_stride; a.bmid_stride = bmid_stride; a.w3 = w3; a.b3 = b3;
+    a.y = y; a.z = z; a.logits = logits;
+    a.N = N; a.B = B; a.HW = HW; a.nmid = nmid; a.masking = masking;
+    a.ntiles = (int)(((size_t)B * HW) / 32);
+    a.upper = upper; a.lower = lower;
+    const size_t shmem = ((size_t)CH * CH * (1 + nmid) + (size_t)nmid * CH + CH) * sizeof(float);
+    int grid = (a.ntiles + 3) / 4;
+    if (grid > 512) grid = 512;
+    if (shmem > 48 * 1024) {  // raise the dynamic-LDS cap (160 KiB per CU on gfx950)
+        const void* fn = CH == 64 ? (const void*)fcomb_sampler_kernel<2> : (const void*)fcomb_sampler_kernel<1>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {
+            punet_set_error("punet_fcomb_sample: cannot reserve %zu bytes of LDS", shmem);
+            return PUNET_ERR_HIP;
+        }
+    }
+    if (CH == 64)
+        fcomb_sampler_kernel<2><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
+    else
+        fcomb_sampler_kernel<1><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
+    PUNET_LAUNCH_CHECK("fcomb_sampler");
+    return PUNET_OK;
+}

@@ -1,0 +1,552 @@
+"""Host-side engine: walks the Probabilistic U-Net graph and enqueues the HIP kernels of libpunet_hip.so.
+
+This is the host logic above the C ABI (include/punet_hip.h).  It mirrors the module structure of the reference
+(prob_utils/my_models/{unet,unet_blocks,probabilistic_unet}.py) but owns no arithmetic: every FLOP runs in a
+hand-written gfx950 kernel.  PyTorch-ROCm is used for device memory (torch.empty), streams and nothing else.
+
+Data layout in HBM
+  * parameters: ONE flat fp32 buffer; every conv weight stored [ky][kx][cin][cout] (K-major slabs the kernels read
+    with unit stride along cout), biases [cout].  Tensor order = the reference's state_dict() order.
+    The same layout is used for gradients, Adam moments and the EMA teacher, so optimizer / EMA / RCCL all-reduce
+    are single flat-buffer operations.
+  * activations: NHWC fp32, one tensor per conv output (kept for the backward when a tape is recorded).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+
+# --------------------------------------------------------------------------------------------
+# parameter layout
+# --------------------------------------------------------------------------------------------
+def encoder_conv_indices(n_blocks: int, convs_per_block: int = 3) -> List[List[int]]:
+    """nn.Sequential indices of the convs inside the reference's Encoder (probabilistic_unet.py:44-63)."""
+    idx, out = 0, []
+    for i in range(n_blocks):
+        if i != 0:
+            idx += 1
+        blk = []
+        for _ in range(convs_per_block):
+            blk.append(idx)
+            idx += 2
+        out.append(blk)
+    return out
+
+
+class ConvP:
+    """One conv layer's slot in the flat parameter buffer."""
+    __slots__ = ("name", "cin", "cout", "k", "w_off", "b_off")
+
+    def __init__(self, name, cin, cout, k):
+        self.name, self.cin, self.cout, self.k = name, cin, cout, k
+        self.w_off = self.b_off = -1
+
+    @property
+    def w_numel(self):
+        return self.k * self.k * self.cin * self.cout
+
+
+class ParamLayout:
+    """Flat layout of all parameters; names and logical shapes follow the reference state-dict (M0)."""
+
+    def __init__(self, input_channels=1, num_classes=1, num_filters=(64, 128, 256, 512), latent_dim=6,
+                 no_convs_fcomb=3):
+        nf = list(num_filters)
+        if num_classes != 1:
+            raise ValueError("the HIP path implements num_classes == 1 (every reference script uses 1)")
+        if nf[0] not in (32, 64) or any(f % 32 for f in nf):
+            raise ValueError("num_filters must be multiples of 32 with num_filters[0] in {32, 64}")
+        if not 1 <= input_channels <= 3:
+            raise ValueError("input_channels must be 1..3")
+        if no_convs_fcomb < 2:
+            raise ValueError("no_convs_fcomb must be >= 2")
+        self.input_channels, self.num_classes, self.nf = input_channels, num_classes, nf
+        self.latent_dim, self.no_convs_fcomb = latent_dim, no_convs_fcomb
+        self.convs: "OrderedDict[str, ConvP]" = OrderedDict()
+
+        def add(name, cin, cout, k):
+            self.convs[name] = ConvP(name, cin, cout, k)
+
+        n = len(nf)
+        self.unet_down: List[List[str]] = []
+        for i, co in enumerate(nf):
+            ci = input_channels if i == 0 else nf[i - 1]
+            off = 0 if i == 0 else 1
+            names = [f"unet.contracting_path.{i}.layers.{off + k}" for k in (0, 2, 4)]
+            add(names[0], ci, co, 3)
+            add(names[1], co, co, 3)
+            add(names[2], co, co, 3)
+            self.unet_down.append(names)
+        self.unet_up: List[List[str]] = []
+        out = nf[-1]
+        for j, i in enumerate(range(n - 2, -1, -1)):
+            ci = out + nf[i]
+            out = nf[i]
+            names = [f"unet.upsampling_path.{j}.conv_block.layers.{k}" for k in (0, 2, 4)]
+            add(names[0], ci, out, 3)
+            add(names[1], out, out, 3)
+            add(names[2], out, out, 3)
+            self.unet_up.append(names)
+        self.enc: Dict[str, List[List[str]]] = {}
+        for net, extra in (("prior", 0), ("posterior", num_classes)):
+            blocks = []
+            for i, blk in enumerate(encoder_conv_indices(n)):
+                ci = (input_channels + extra) if i == 0 else nf[i - 1]
+                names = [f"{net}.encoder.layers.{li}" for li in blk]
+                for k, nm in enumerate(names):
+                    add(nm, ci if k == 0 else nf[i], nf[i], 3)
+                blocks.append(names)
+            self.enc[net] = blocks
+            add(f"{net}.conv_layer", nf[-1], 2 * latent_dim, 1)
+        add("fcomb.layers.0", nf[0] + latent_dim, nf[0], 1)
+        self.fcomb_mid = []
+        for k in range(no_convs_fcomb - 2):
+            nm = f"fcomb.layers.{2 * (k + 1)}"
+            add(nm, nf[0], nf[0], 1)
+            self.fcomb_mid.append(nm)
+        add("fcomb.last_layer", nf[0], num_classes, 1)
+
+        off = 0
+        self.entries: List[Tuple[str, int, int, Tuple[int, ...]]] = []  # (state-dict name, offset, numel, logical shape)
+        for c in self.convs.values():
+            c.w_off = off
+            self.entries.append((c.name + ".weight", off, c.w_numel, (c.cout, c.cin, c.k, c.k)))
+            off += c.w_numel
+            c.b_off = off
+            self.entries.append((c.name + ".bias", off, c.cout, (c.cout,)))
+            off += c.cout
+            off = (off + 3) // 4 * 4  # keep every tensor 16-byte aligned (float4 loads)
+        self.numel = off
+        self.n_params = sum(e[2] for e in self.entries)
+
+    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        """Logical (reference-shaped) view of one tensor inside a flat buffer (no copy)."""
+        for nm, off, n, shape in self.entries:
+            if nm == name:
+                return self._view(flat, off, n, shape)
+        raise KeyError(name)
+
+    @staticmethod
+    def _view(flat, off, n, shape):
+        t = flat[off:off + n]
+        if len(shape) == 4:
+            co, ci, k, _ = shape
+            return t.view(k, k, ci, co).permute(3, 2, 0, 1)  # storage [ky][kx][cin][cout] seen as [cout,cin,ky,kx]
+        return t
+
+    def views(self, flat: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
+        return OrderedDict((nm, self._view(flat, off, n, shape)) for nm, off, n, shape in self.entries)
+
+    def l2_chunk_table(self, chunk: int = 16384) -> Tuple[torch.Tensor, int]:
+        """{offset, length, tensor index} triples for posterior, prior and fcomb.layers (mean_teacher_trainer.py:115-116)."""
+        rows, t = [], 0
+        for nm, off, n, _ in self.entries:
+            if nm.startswith("posterior.") or nm.startswith("prior.") or nm.startswith("fcomb.layers."):
+                for s in range(0, n, chunk):
+                    rows.append((off + s, min(chunk, n - s), t))
+                t += 1
+        return torch.tensor(rows, dtype=torch.int64), t
+
+
+# --------------------------------------------------------------------------------------------
+# activations + tape
+# --------------------------------------------------------------------------------------------
+class Act:
+    """An NHWC activation tensor with its geometry; relu_out marks tensors whose gradient must be gated by (t > 0)."""
+    __slots__ = ("t", "B", "H", "W", "C", "relu_out", "needs_grad")
+
+    def __init__(self, t, B, H, W, C, relu_out=False, needs_grad=True):
+        self.t, self.B, self.H, self.W, self.C = t, B, H, W, C
+        self.relu_out, self.needs_grad = relu_out, needs_grad
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Workspace:
+    """Grow-only scratch buffers keyed by purpose (split-K slabs, reduction partials)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs: Dict[str, torch.Tensor] = {}
+
+    def get(self, key: str, nfloats: int) -> torch.Tensor:
+        b = self.bufs.get(key)
+        if b is None or b.numel() < nfloats:
+            b = torch.empty(max(int(nfloats), 1), dtype=torch.float32, device=self.device)
+            self.bufs[key] = b
+        return b
+
+
+class PUNetEngine:
+    """Enqueues the kernels for one model configuration on one GPU.  Stateless w.r.t. weights: every call takes the
+    flat parameter tensor to use (student or teacher)."""
+
+    def __init__(self, layout: ParamLayout, device):
+        self.L = layout
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("PUNetEngine needs a ROCm device: the product path has no CPU fallback")
+        _lib.load()
+        self.ws = Workspace(self.device)
+        tab, self.l2_ntensors = layout.l2_chunk_table()
+        self.l2_chunks = tab.to(self.device)
+        self.l2_nchunks = tab.shape[0]
+
+    # ---------------------------------------------------------------- helpers
+    def _empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def _wptr(self, flat, conv: ConvP):
+        return flat.data_ptr() + 4 * conv.w_off
+
+    def _bptr(self, flat, conv: ConvP):
+        return flat.data_ptr() + 4 * conv.b_off
+
+    def to_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+        """[B,C,H,W] (any strides) -> contiguous NHWC fp32 on the device (a no-op view when C == 1)."""
+        x = x.to(device=self.device, dtype=torch.float32)
+        return x.permute(0, 2, 3, 1).contiguous()
+
+    # ---------------------------------------------------------------- forward ops
+    def conv(self, flat, name: str, x0: Act, x1: Optional[Act] = None, relu=True, tape=None) -> Act:
+        c = self.L.convs[name]
+        B, H, W = x0.B, x0.H, x0.W
+        y = Act(self._empty(B, H, W, c.cout), B, H, W, c.cout, relu_out=relu)
+        cin = x0.C + (x1.C if x1 is not None else 0)
+        assert cin == c.cin, (name, cin, c.cin)
+        if cin <= 4:
+            assert x1 is None and c.k == 3
+            _lib.call("punet_conv3x3_small_fwd", x0.ptr, cin, self._wptr(flat, c), self._bptr(flat, c), y.ptr, c.cout,
+                      B, H, W, int(relu), _stream())
+        else:
+            _lib.call("punet_conv_fwd", x0.ptr, x0.C, x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0,
+                      self._wptr(flat, c), self._bptr(flat, c), 0, y.ptr, c.cout, B, H, W, c.k, int(relu), _stream())
+        if tape is not None:
+            tape.append(("conv", c, x0, x1, y))
+        return y
+
+    def pool(self, x: Act, tape=None) -> Act:
+        OH, OW = (x.H + 1) // 2, (x.W + 1) // 2
+        y = Act(self._empty(x.B, OH, OW, x.C), x.B, OH, OW, x.C)
+        _lib.call("punet_pool2x2_fwd", x.ptr, y.ptr, x.B, x.H, x.W, x.C, _stream())
+        if tape is not None:
+            tape.append(("pool", x, y))
+        return y
+
+    def upsample(self, x: Act, tape=None) -> Act:
+        y = Act(self._empty(x.B, 2 * x.H, 2 * x.W, x.C), x.B, 2 * x.H, 2 * x.W, x.C)
+        _lib.call("punet_upsample2x_fwd", x.ptr, y.ptr, x.B, x.H, x.W, x.C, _stream())
+        if tape is not None:
+            tape.append(("up", x, y))
+        return y
+
+    def encoder_stack(self, flat, blocks: Sequence[Sequence[str]], x: Act, tape=None, taps=None, tag="") -> Tuple[Act, List[Act]]:
+        """The 4-block contracting stack shared by Unet (unet.py:50-55) and Encoder (probabilistic_unet.py:67-69)."""
+        outs = []
+        for i, names in enumerate(blocks):
+            if i != 0:
+                x = self.pool(x, tape)
+            for nm in names:
+                x = self.conv(flat, nm, x, None, True, tape)
+            outs.append(x)
+            if taps is not None:
+                taps[f"{tag}{i}"] = x
+        return x, outs
+
+    def unet(self, flat, x: Act, tape=None, taps=None) -> Act:
+        """Unet.forward with apply_last_layer=False (unet.py:50-69; UpConvBlock.forward unet_blocks.py:49-59)."""
+        if x.H % (1 << (len(self.L.nf) - 1)) or x.W % (1 << (len(self.L.nf) - 1)):
+            raise ValueError(f"H and W must be divisible by {1 << (len(self.L.nf) - 1)} (got {x.H}x{x.W})")
+        x, outs = self.encoder_stack(flat, self.L.unet_down, x, tape, taps, "unet.down")
+        for j, names in enumerate(self.L.unet_up):
+            up = self.upsample(x, tape)
+            bridge = outs[-j - 2]
+            assert up.W == bridge.W and up.H == bridge.H  # unet_blocks.py:55
+            x = self.conv(flat, names[0], up, bridge, True, tape)  # concat order [up, bridge] (unet_blocks.py:56)
+            x = self.conv(flat, names[1], x, None, True, tape)
+            x = self.conv(flat, names[2], x, None, True, tape)
+            if taps is not None:
+                taps[f"unet.up{j}"] = x
+        return x
+
+    def latent(self, flat, net: str, x: Act, tape=None, taps=None):
+        """AxisAlignedConvGaussian.forward (probabilistic_unet.py:113-142) -> (muls [B, 2L], mean [B, C], enc Act)."""
+        enc, _ = self.encoder_stack(flat, self.L.enc[net], x, tape, taps, f"{net}.enc")
+        c = self.L.convs[f"{net}.conv_layer"]
+        P = enc.H * enc.W
+        mean = self._empty(enc.B, enc.C)
+        muls = self._empty(enc.B, c.cout)
+        ws = self.ws.get("chan", _lib.call("punet_chan_sum_workspace_floats", enc.B, P, enc.C))
+        _lib.call("punet_latent_head_fwd", enc.ptr, self._wptr(flat, c), self._bptr(flat, c), mean.data_ptr(), muls.data_ptr(),
+                  ws.data_ptr(), enc.B, P, enc.C, c.cout, _stream())
+        return muls, mean, enc
+
+    # ---------------------------------------------------------------- inference / teacher path
+    def forward_features(self, flat, x_nhwc: torch.Tensor, taps=None):
+        """ProbabilisticUnet.forward(patch, None, training=False) (probabilistic_unet.py:292-293)."""
+        B, H, W, C = x_nhwc.shape
+        xin = Act(x_nhwc, B, H, W, C, needs_grad=False)
+        muls_p, _, _ = self.latent(flat, "prior", xin, None, taps)
+        feat = self.unet(flat, xin, None, taps)
+        return {"features": feat, "prior_muls": muls_p}
+
+    def _fcomb_ptrs(self, flat):
+        L = self.L
+        c1, c3 = L.convs["fcomb.layers.0"], L.convs["fcomb.last_layer"]
+        nmid = len(L.fcomb_mid)
+        if nmid:
+            m0 = L.convs[L.fcomb_mid[0]]
+            wmid, bmid = self._wptr(flat, m0), self._bptr(flat, m0)
+            stride = (L.convs[L.fcomb_mid[1]].w_off - m0.w_off) if nmid > 1 else 0
+        else:
+            wmid = bmid = None
+            stride = 0
+        return c1, c3, nmid, wmid, bmid, stride
+
+    def sample(self, flat, feat: Act, z: torch.Tensor, upper=0.9, lower=0.1, masking=False, want_logits=False,
+               want_consensus=True):
+        """N Monte-Carlo samples through Fcomb + consensus (K7).  z: [N, B, L] latent draws.
+        Returns (y_mean [B,1,H,W], consensus [B,1,H,W] float, logits [N,B,1,H,W] or None)."""
+        N, B, Ld = z.shape
+        CH = self.L.nf[0]
+        c1, c3, nmid, wmid, bmid, stride = self._fcomb_ptrs(flat)
+        zb = self._empty(N, B, CH)
+        _lib.call("punet_fcomb_zbias", z.data_ptr(), self._wptr(flat, c1), self._bptr(flat, c1), zb.data_ptr(), N * B, Ld, CH,
+                  _stream())
+        HW = feat.H * feat.W
+        y = self._empty(B, 1, feat.H, feat.W) if want_consensus else None
+        cz = self._empty(B, 1, feat.H, feat.W) if want_consensus else None
+        logits = self._empty(N, B, 1, feat.H, feat.W) if want_logits else None
+        _lib.call("punet_fcomb_sample", feat.ptr, self._wptr(flat, c1), zb.data_ptr(), wmid, stride, bmid, stride,
+                  self._wptr(flat, c3), self._bptr(flat, c3), y.data_ptr() if y is not None else None,
+                  cz.data_ptr() if cz is not None else None, logits.data_ptr() if logits is not None else None, N, B, HW,
+                  CH, nmid, float(upper), float(lower), int(masking), _stream())
+        return y, cz, logits
+
+    def reparam(self, muls: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
+        """z = mu + exp(log_sigma) * eps for eps [N, B, L] (Normal.rsample; probabilistic_unet.py:302,349)."""
+        N, B, Ld = eps.shape
+        z = self._empty(N, B, Ld)
+        _lib.call("punet_reparam", muls.data_ptr(), eps.data_ptr(), z.data_ptr(), N, B, Ld, _stream())
+        return z
+
+    def consensus(self, logits: torch.Tensor, upper=0.9, lower=0.1, masking=False):
+        """K8 on given logits [N, ...] (unit parity of mean_teacher_trainer.py:74-86)."""
+        N = logits.shape[0]
+        P = logits[0].numel()
+        y = self._empty(*logits.shape[1:])
+        z = self._empty(*logits.shape[1:])
+        _lib.call("punet_consensus", logits.data_ptr(), N, P, float(upper), float(lower), int(masking), y.data_ptr(),
+                  z.data_ptr(), _stream())
+        return y, z
+
+    # ---------------------------------------------------------------- training path
+    def elbo_forward(self, flat, x_nhwc, y_tgt, consm, eps, loss_kind="bce", beta=1.0, gscale=1.0, record=True, taps=None):
+        """forward(patch, segm, training=True) + elbo(segm, consm) (probabilistic_unet.py:285-293,341-371).
+        y_tgt, consm: [B,1,H,W] float (consm may be None); eps: [B, L].  When record is True the tape and the
+        d loss / d logit (scaled by gscale) are kept for elbo_backward."""
+        L = self.L
+        B, H, W, C = x_nhwc.shape
+        Ld, CH = L.latent_dim, L.nf[0]
+        st = {"B": B, "H": H, "W": W, "gscale": gscale, "beta": beta}
+        xin = Act(x_nhwc, B, H, W, C, needs_grad=False)
+        xq = Act(torch.cat([x_nhwc, y_tgt.reshape(B, H, W, 1)], dim=3), B, H, W, C + 1, needs_grad=False)  # [patch, segm]
+        tq = [] if record else None
+        tp = [] if record else None
+        tu = [] if record else None
+        muls_q, mean_q, enc_q = self.latent(flat, "posterior", xq, tq, taps)
+        muls_p, mean_p, enc_p = self.latent(flat, "prior", xin, tp, taps)
+        feat = self.unet(flat, xin, tu, taps)
+        eps3 = eps.reshape(1, B, Ld).contiguous()
+        z = self.reparam(muls_q, eps3)  # [1, B, L]
+        kl = self._empty(1)
+        _lib.call("punet_latent_kl", muls_q.data_ptr(), muls_p.data_ptr(), kl.data_ptr(), B, Ld, _stream())
+        # Fcomb, single sample, activations materialised for the backward
+        c1, c3 = L.convs["fcomb.layers.0"], L.convs["fcomb.last_layer"]
+        zb = self._empty(B, CH)
+        _lib.call("punet_fcomb_zbias", z.data_ptr(), self._wptr(flat, c1), self._bptr(flat, c1), zb.data_ptr(), B, Ld, CH,
+                  _stream())
+        h = Act(self._empty(B, H, W, CH), B, H, W, CH, relu_out=True)
+        _lib.call("punet_conv_fwd", feat.ptr, CH, None, 0, self._wptr(flat, c1), zb.data_ptr(), CH, h.ptr, CH, B, H, W, 1, 1,
+                  _stream())
+        hs = [h]
+        for nm in L.fcomb_mid:
+            h = self.conv(flat, nm, h, None, True, None)
+            hs.append(h)
+        P = B * H * W
+        logits = self._empty(B, 1, H, W)
+        _lib.call("punet_dot_bias", h.ptr, self._wptr(flat, c3), self._bptr(flat, c3), logits.data_ptr(), P, CH, _stream())
+        dlogit = self._empty(B, 1, H, W) if record else None
+        rec = self._empty(1)
+        wsl = self.ws.get("loss", _lib.call("punet_loss_workspace_floats"))
+        cm = consm.data_ptr() if consm is not None else None
+        if loss_kind == "bce":
+            _lib.call("punet_bce_fwd_bwd", logits.data_ptr(), y_tgt.data_ptr(), cm, float(gscale),
+                      dlogit.data_ptr() if record else None, rec.data_ptr(), wsl.data_ptr(), P, _stream())
+        elif loss_kind == "dice":
+            if dlogit is None:
+                dlogit = self._empty(B, 1, H, W)
+            _lib.call("punet_dice_fwd_bwd", logits.data_ptr(), y_tgt.data_ptr(), cm, float(gscale), dlogit.data_ptr(),
+                      rec.data_ptr(), wsl.data_ptr(), P, _stream())
+        else:
+            raise ValueError(loss_kind)
+        st.update(muls_q=muls_q, muls_p=muls_p, mean_q=mean_q, mean_p=mean_p, enc_q=enc_q, enc_p=enc_p, feat=feat, z=z,
+                  eps=eps3, kl=kl, rec=rec, logits=logits, dlogit=dlogit, hs=hs, tapes=(tq, tp, tu), loss_kind=loss_kind)
+        return st
+
+    def _wgrad(self, gflat, c: ConvP, x: Act, ci_off: int, dz: torch.Tensor, with_bias: bool, accumulate: bool):
+        B, H, W = x.B, x.H, x.W
+        dw = gflat.data_ptr() + 4 * c.w_off
+        db = gflat.data_ptr() + 4 * c.b_off
+        if c.cin <= 4:
+            ws = self.ws.get("wgrad", _lib.call("punet_small_wgrad_workspace_floats", c.cin, c.cout))
+            _lib.call("punet_conv3x3_small_wgrad", x.ptr, c.cin, dz.data_ptr(), c.cout, dw, db, ws.data_ptr(), B, H, W,
+                      int(accumulate), 1.0, _stream())
+            return
+        ns = _lib.call("punet_wgrad_slices", x.C, c.cout, B, H, W)
+        ws = self.ws.get("wgrad", _lib.call("punet_wgrad_workspace_floats", x.C, c.cout, c.k, ns))
+        _lib.call("punet_conv_wgrad", x.ptr, x.C, dz.data_ptr(), c.cout, dw, c.cin, ci_off, db if with_bias else None,
+                  ws.data_ptr(), ns, B, H, W, c.k, int(accumulate), 1.0, _stream())
+
+    def _grad_into(self, gm: dict, a: Act):
+        """(buffer, accumulate flag) for the gradient of activation a."""
+        g = gm.get(id(a))
+        if g is None:
+            g = torch.empty_like(a.t)
+            gm[id(a)] = g
+            return g, 0
+        return g, 1
+
+    def _backward_tape(self, flat, gflat, tape, gm: dict, accumulate: bool):
+        for op in reversed(tape):
+            if op[0] == "conv":
+                _, c, x0, x1, y = op
+                dz = gm.pop(id(y))
+                self._wgrad(gflat, c, x0, 0, dz, True, accumulate)
+                if x1 is not None:
+                    self._wgrad(gflat, c, x1, x0.C, dz, False, accumulate)
+                off = 0
+                for src in (x0, x1):
+                    if src is None:
+                        continue
+                    if src.needs_grad:
+                        g, acc = self._grad_into(gm, src)
+                        _lib.call("punet_conv_dgrad", dz.data_ptr(), c.cout, self._wptr(flat, c), c.cin, off, src.C,
+                                  g.data_ptr(), src.ptr if src.relu_out else None, acc, src.B, src.H, src.W, c.k, _stream())
+                    off += src.C
+            elif op[0] == "pool":
+                _, x, y = op
+                dy = gm.pop(id(y))
+                g, acc = self._grad_into(gm, x)
+                _lib.call("punet_pool2x2_bwd", dy.data_ptr(), x.ptr if x.relu_out else None, g.data_ptr(), x.B, x.H, x.W, x.C,
+                          acc, _stream())
+            else:
+                _, x, y = op
+                dy = gm.pop(id(y))
+                assert id(x) not in gm
+                g, _ = self._grad_into(gm, x)
+                _lib.call("punet_upsample2x_bwd", dy.data_ptr(), x.ptr if x.relu_out else None, g.data_ptr(), x.B, x.H, x.W,
+                          x.C, _stream())
+
+    def elbo_backward(self, flat, gflat, st, accumulate=False):
+        """Gradient of gscale * (reconstruction_loss + beta * kl) w.r.t. every parameter into gflat
+        (= d(-elbo)/d theta, probabilistic_unet.py:371), written or accumulated."""
+        L = self.L
+        B, H, W = st["B"], st["H"], st["W"]
+        Ld, CH = L.latent_dim, L.nf[0]
+        acc = int(accumulate)
+        P = B * H * W
+        c1, c3 = L.convs["fcomb.layers.0"], L.convs["fcomb.last_layer"]
+        hs: List[Act] = st["hs"]
+        feat: Act = st["feat"]
+        # last layer C -> 1
+        dz_h = torch.empty_like(hs[-1].t)
+        ws = self.ws.get("dot", _lib.call("punet_dot_bwd_workspace_floats", CH))
+        _lib.call("punet_dot_bwd", hs[-1].ptr, st["dlogit"].data_ptr(), self._wptr(flat, c3), dz_h.data_ptr(),
+                  gflat.data_ptr() + 4 * c3.w_off, gflat.data_ptr() + 4 * c3.b_off, ws.data_ptr(), P, CH, acc, _stream())
+        # middle 1x1 layers, last to first
+        for k in range(len(L.fcomb_mid) - 1, -1, -1):
+            c = L.convs[L.fcomb_mid[k]]
+            xin = hs[k]
+            self._wgrad(gflat, c, xin, 0, dz_h, True, accumulate)
+            dprev = torch.empty_like(xin.t)
+            _lib.call("punet_conv_dgrad", dz_h.data_ptr(), c.cout, self._wptr(flat, c), c.cin, 0, xin.C, dprev.data_ptr(),
+                      xin.ptr, 0, B, H, W, 1, _stream())
+            dz_h = dprev
+        # first layer: feature rows by wgrad (+ bias), z rows and dz from the per-image column sums
+        self._wgrad(gflat, c1, feat, 0, dz_h, True, accumulate)
+        S = self._empty(B, CH)
+        wsc = self.ws.get("chan", _lib.call("punet_chan_sum_workspace_floats", B, H * W, CH))
+        _lib.call("punet_chan_sum", dz_h.data_ptr(), S.data_ptr(), wsc.data_ptr(), B, H * W, CH, 1.0, _stream())
+        dz = self._empty(B, Ld)
+        _lib.call("punet_fcomb_z_bwd", S.data_ptr(), st["z"].data_ptr(), self._wptr(flat, c1), gflat.data_ptr() + 4 * c1.w_off,
+                  dz.data_ptr(), B, Ld, CH, acc, _stream())
+        gm_u = {}
+        dfeat, _ = self._grad_into(gm_u, feat)
+        _lib.call("punet_conv_dgrad", dz_h.data_ptr(), CH, self._wptr(flat, c1), c1.cin, 0, CH, dfeat.data_ptr(), feat.ptr, 0,
+                  B, H, W, 1, _stream())
+        del dz_h
+        tq, tp, tu = st["tapes"]
+        self._backward_tape(flat, gflat, tu, gm_u, accumulate)
+        # latent heads: KL + reparameterisation
+        dq = self._empty(B, 2 * Ld)
+        dp = self._empty(B, 2 * Ld)
+        coef = float(st["gscale"]) * float(st["beta"]) / B
+        _lib.call("punet_latent_kl_bwd", st["muls_q"].data_ptr(), st["muls_p"].data_ptr(), st["eps"].data_ptr(), dz.data_ptr(),
+                  coef, dq.data_ptr(), dp.data_ptr(), B, Ld, _stream())
+        for net, d, mean, enc, tape in (("posterior", dq, st["mean_q"], st["enc_q"], tq),
+                                       ("prior", dp, st["mean_p"], st["enc_p"], tp)):
+            c = L.convs[f"{net}.conv_layer"]
+            gm = {}
+            denc, _ = self._grad_into(gm, enc)
+            dmean = self._empty(B, enc.C)
+            _lib.call("punet_latent_head_bwd", d.data_ptr(), mean.data_ptr(), self._wptr(flat, c), enc.ptr,
+                      gflat.data_ptr() + 4 * c.w_off, gflat.data_ptr() + 4 * c.b_off, dmean.data_ptr(), denc.data_ptr(), B,
+                      enc.H * enc.W, enc.C, c.cout, acc, _stream())
+            self._backward_tape(flat, gflat, tape, gm, accumulate)
+
+    # ---------------------------------------------------------------- regulariser / optimiser
+    def l2_reg(self, flat) -> Tuple[torch.Tensor, torch.Tensor]:
+        """sum of un-squared 2-norms over posterior, prior, fcomb.layers (utils.py:32-40) -> (reg [1], norms [T])."""
+        partial = self.ws.get("l2p", self.l2_nchunks)
+        norms = self._empty(self.l2_ntensors)
+        reg = self._empty(1)
+        _lib.call("punet_l2_reg", flat.data_ptr(), self.l2_chunks.data_ptr(), self.l2_nchunks, self.l2_ntensors,
+                  partial.data_ptr(), norms.data_ptr(), reg.data_ptr(), _stream())
+        return reg, norms
+
+    def l2_reg_add_grad(self, flat, gflat, norms, coef: float):
+        _lib.call("punet_l2_reg_add_grad", flat.data_ptr(), gflat.data_ptr(), self.l2_chunks.data_ptr(), self.l2_nchunks,
+                  norms.data_ptr(), float(coef), _stream())
+
+    def adam_ema(self, flat, gflat, m, v, teacher, step: int, lr: float, betas=(0.9, 0.999), eps=1e-8, gscale=1.0,
+                 ema_momentum=0.999, do_adam=True):
+        _lib.call("punet_adam_ema", flat.data_ptr(), gflat.data_ptr() if gflat is not None else None,
+                  m.data_ptr() if m is not None else None, v.data_ptr() if v is not None else None,
+                  teacher.data_ptr() if teacher is not None else None, flat.numel(), float(gscale), float(lr),
+                  float(betas[0]), float(betas[1]), float(eps), int(step), float(ema_momentum), int(do_adam), _stream())
+
+    def dice_score(self, seg: torch.Tensor, gt: torch.Tensor, threshold_seg=None, threshold_gt=None) -> float:
+        """dice_score (my_utils/util.py:17-44) on device tensors; returns a host float (one sync)."""
+        sums = self._empty(3)
+        ws = self.ws.get("loss", _lib.call("punet_loss_workspace_floats"))
+        seg = seg.contiguous()
+        gt = gt.contiguous()
+        assert seg.numel() == gt.numel()
+        _lib.call("punet_dice_score_sums", seg.data_ptr(), gt.data_ptr(), float(threshold_seg or 0.0),
+                  int(threshold_seg is not None), float(threshold_gt or 0.0), int(threshold_gt is not None),
+                  sums.data_ptr(), ws.data_ptr(), seg.numel(), _stream())
+        a, b, c = [float(v) for v in sums.tolist()]
+        return (2.0 * a) / (b + c + 1e-7)

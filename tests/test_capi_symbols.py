@@ -1,0 +1,52 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/punet_hip.h declares
+(no compute calls without a GPU)."""
+import os
+import re
+
+import pytest
+
+
+def _header_symbols():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "include", "punet_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(punet_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_build_and_exports():
+    import __graft_entry__ as g
+    g.build()
+    from probabilistic_domain_adaptation_amd import _lib
+    lib = _lib.load()
+    hdr = _header_symbols()
+    assert len(hdr) >= 30
+    for s in hdr:
+        assert hasattr(lib, s), f"{s} declared in include/punet_hip.h but not exported"
+    assert set(hdr) == set(_lib.declared_symbols()), set(hdr) ^ set(_lib.declared_symbols())
+    assert b"gfx950" in _lib.call("punet_build_info")
+
+
+def test_bad_arguments_are_reported_not_thrown():
+    from probabilistic_domain_adaptation_amd import _lib
+    _lib.load()
+    with pytest.raises(RuntimeError, match="ksize"):
+        _lib.call("punet_conv_fwd", 1, 8, None, 0, 1, None, 0, 1, 8, 1, 8, 8, 5, 1, None)
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        _lib.call("punet_conv_fwd", 1, 6, None, 0, 1, None, 0, 1, 8, 1, 8, 8, 3, 1, None)
+
+
+def test_product_path_refuses_cpu():
+    import torch
+    from probabilistic_domain_adaptation_amd.engine import ParamLayout, PUNetEngine
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        PUNetEngine(ParamLayout(1, 1, [32, 32, 32, 32]), torch.device("cpu"))
+
+
+def test_layout_matches_reference_state_dict():
+    from oracle import punet_oracle as O
+    from probabilistic_domain_adaptation_amd.engine import ParamLayout
+    for nf, c in (([64, 128, 256, 512], 1), ([32, 64, 96, 128], 3)):
+        lay = ParamLayout(c, 1, nf, 6, 3)
+        spec = O.param_spec(c, 1, nf, 6, 3)
+        assert [(n, s) for n, _, _, s in lay.entries] == [(n, tuple(s)) for n, s in spec.items()]
+    assert ParamLayout(1, 1, [64, 128, 256, 512]).n_params == 27349593

@@ -1,0 +1,175 @@
+"""GPU parity tests proper: the HIP hot path (through the C ABI) against (a) the committed golden fixtures, which hold
+outputs of the REFERENCE itself, and (b) the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): segmentation logits within 1e-3 absolute; consensus masks bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import punet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["uniform32_literal", "fixed_small", "fixed_rgb", "full_nf"]
+LOGIT_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _eps(n, b, l, seed):
+    return torch.randn(n, b, l, generator=torch.Generator().manual_seed(seed))
+
+
+def _setup(golden_dir, name, dev):
+    from probabilistic_domain_adaptation_amd.engine import ParamLayout, PUNetEngine
+    fx = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = fx["meta"]
+    B, C, H, W, s0, s1, s2, fixed = [int(v) for v in meta[:8]]
+    nf = [int(v) for v in meta[8:]]
+    cfg = O.PUNetConfig(C, 1, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    Pnp = O.synth_params(cfg.spec(), s1)
+    lay = ParamLayout(C, 1, nf, 6, 3)
+    eng = PUNetEngine(lay, dev)
+    flat = torch.zeros(lay.numel, device=dev)
+    views = lay.views(flat)
+    assert list(views.keys()) == list(Pnp.keys())
+    for k, v in Pnp.items():
+        views[k].copy_(torch.from_numpy(v))
+    batch = O.synth_batch(B, C, H, W, s0)
+    return fx, cfg, Pnp, lay, eng, flat, batch, (B, C, H, W, s0, s1, s2)
+
+
+def _nchw(act):
+    return act.t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_inference_path(golden_dir, dev, name):
+    fx, cfg, Pnp, lay, eng, flat, (x, x1, x2, y), (B, C, H, W, s0, s1, s2) = _setup(golden_dir, name, dev)
+    taps = {}
+    st = eng.forward_features(flat, eng.to_nhwc(x1), taps)
+    torch.cuda.synchronize()
+    # every block output against the oracle
+    Po = O.to_torch(Pnp)
+    otaps = {}
+    with torch.no_grad():
+        ost = O.punet_forward(Po, cfg, x1, None, False, otaps)
+    worst = {}
+    for k, v in otaps.items():
+        got = _nchw(taps[k])
+        worst[k] = (got - v).abs().max().item() / (v.abs().max().item() + 1e-9)
+    assert max(worst.values()) < 1e-4, worst
+    muls = st["prior_muls"].cpu()
+    np.testing.assert_allclose(muls[:, :6].numpy(), fx["prior_mu"], atol=1e-4)
+    np.testing.assert_allclose(muls[:, 6:].exp().numpy(), fx["prior_sigma"], rtol=1e-4)
+    np.testing.assert_allclose(_nchw(st["features"])[:, :, :8, :8].numpy(), fx["features_crop"], atol=1e-4, rtol=1e-4)
+    # N samples: logits vs the reference's, consensus vs the reference's
+    nmax = fx["logits"].shape[0]
+    eps = _eps(nmax, B, 6, s2).to(dev)
+    z = eng.reparam(st["prior_muls"], eps)
+    _, _, logits = eng.sample(flat, st["features"], z, want_logits=True)
+    torch.cuda.synchronize()
+    err = np.abs(logits.cpu().numpy() - fx["logits"]).max()
+    assert err < LOGIT_TOL, f"logits max abs err {err}"
+    for key in fx.files:
+        if not key.startswith("y_n"):
+            continue
+        n = int(key[3:])
+        for masking, tag in ((False, "weight"), (True, "mask")):
+            ym, cz, _ = eng.sample(flat, st["features"], z[:n].contiguous(), 0.9, 0.1, masking)
+            torch.cuda.synchronize()
+            assert np.abs(ym.cpu().numpy() - fx[key]).max() < 1e-4
+            ref = fx[f"z_n{n}_{tag}"].astype(np.float32)
+            mism = int((cz.cpu().numpy() != ref).sum())
+            assert mism == 0, f"{mism} consensus pixels differ from the reference ({tag}, N={n})"
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("mode", ["none", "weight", "mask"])
+def test_training_path(golden_dir, dev, name, mode):
+    fx, cfg, Pnp, lay, eng, flat, (x, x1, x2, y), (B, C, H, W, s0, s1, s2) = _setup(golden_dir, name, dev)
+    nlast = max(int(k[3:]) for k in fx.files if k.startswith("y_n"))
+    y_soft = torch.from_numpy(fx[f"y_n{nlast}"])
+    consm = None if mode == "none" else torch.from_numpy(fx[f"z_n{nlast}_{mode}"]).float()
+    eps_s = _eps(1, B, 6, s2 + 100)[0]
+    st = eng.elbo_forward(flat, eng.to_nhwc(x2), y_soft.to(dev), consm.to(dev) if consm is not None else None, eps_s.to(dev),
+                          "bce", 1.0, 1.0, True)
+    g = torch.full((lay.numel,), float("nan"), device=dev)
+    eng.elbo_backward(flat, g, st, accumulate=False)
+    reg, norms = eng.l2_reg(flat)
+    eng.l2_reg_add_grad(flat, g, norms, 1e-5)
+    torch.cuda.synchronize()
+    sc = fx[f"train_{mode}_scalars"]  # loss, rec_sum, rec_mean, kl, reg
+    rec, kl = st["rec"].item(), st["kl"].item()
+    loss = rec + 1.0 * kl + 1e-5 * reg.item()
+    np.testing.assert_allclose([loss, rec, kl, reg.item()], [sc[0], sc[1], sc[3], sc[4]], rtol=2e-4)
+    np.testing.assert_allclose(st["muls_q"][:, :6].cpu().numpy(), fx[f"train_{mode}_post_mu"], atol=1e-4)
+    assert np.abs(st["logits"].cpu().numpy() - fx[f"train_{mode}_recon"]).max() < LOGIT_TOL
+    # gradients: against the oracle's autograd (full tensors) and the reference digests
+    P = O.to_torch(Pnp, requires_grad=True)
+    lo, _ = O.training_loss(P, cfg, x2, y_soft, consm, eps_s)
+    go = O.grads_of(lo, P)
+    gv = lay.views(g)
+    bad = {}
+    for k, ref in go.items():
+        got = gv[k].cpu()
+        assert torch.isfinite(got).all(), k
+        e = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-8)
+        if e > 2e-3:
+            bad[k] = e
+    assert not bad, bad
+    dig = fx[f"train_{mode}_grad_digest"]
+    for row, (k, _) in zip(dig, go.items()):
+        a = gv[k].contiguous().cpu().numpy().ravel()
+        nrm = np.sqrt((a.astype(np.float64) ** 2).sum())
+        assert abs(nrm - row[0]) <= 2e-3 * row[0] + 1e-7, (k, nrm, row[0])
+
+
+def test_gradient_accumulation_and_scale(golden_dir, dev):
+    """Two passes with gscale = 0.5 accumulate to one pass with gscale = 1 (joint trainers' (sup + tgt) / 2)."""
+    fx, cfg, Pnp, lay, eng, flat, (x, x1, x2, y), (B, C, H, W, s0, s1, s2) = _setup(golden_dir, "uniform32_literal", dev)
+    eps_s = _eps(1, B, 6, 77)[0].to(dev)
+    X, Y = eng.to_nhwc(x2), y.to(dev)
+    st = eng.elbo_forward(flat, X, Y, None, eps_s, "bce", 1.0, 1.0, True)
+    g1 = torch.empty(lay.numel, device=dev)
+    eng.elbo_backward(flat, g1, st, False)
+    g2 = torch.empty(lay.numel, device=dev)
+    st = eng.elbo_forward(flat, X, Y, None, eps_s, "bce", 1.0, 0.5, True)
+    eng.elbo_backward(flat, g2, st, False)
+    st = eng.elbo_forward(flat, X, Y, None, eps_s, "bce", 1.0, 0.5, True)
+    eng.elbo_backward(flat, g2, st, True)
+    torch.cuda.synchronize()
+    assert (g1 - g2).abs().max().item() <= 1e-5 * g1.abs().max().item()
+    # run-to-run bit reproducibility (no float atomics)
+    g3 = torch.empty(lay.numel, device=dev)
+    st = eng.elbo_forward(flat, X, Y, None, eps_s, "bce", 1.0, 1.0, True)
+    eng.elbo_backward(flat, g3, st, False)
+    torch.cuda.synchronize()
+    assert torch.equal(g1, g3)
+
+
+def test_dice_criterion_matches_recalled_definition(golden_dir, dev):
+    """rl_swap=True path [parity unpinned: recalled torch_em definition] against the oracle's restatement."""
+    fx, cfg, Pnp, lay, eng, flat, (x, x1, x2, y), (B, C, H, W, s0, s1, s2) = _setup(golden_dir, "uniform32_literal", dev)
+    cfg.rl_swap = True
+    eps_s = _eps(1, B, 6, 78)[0]
+    consm = (torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(3)) > 0.3).float()
+    st = eng.elbo_forward(flat, eng.to_nhwc(x2), y.to(dev), consm.to(dev), eps_s.to(dev), "dice", 1.0, 1.0, True)
+    g = torch.empty(lay.numel, device=dev)
+    eng.elbo_backward(flat, g, st, False)
+    torch.cuda.synchronize()
+    P = O.to_torch(Pnp, requires_grad=True)
+    lo, aux = O.training_loss(P, cfg, x2, y, consm, eps_s, reg_weight=0.0)
+    go = O.grads_of(lo, P)
+    assert abs(st["rec"].item() - aux["reconstruction_loss"].item()) < 1e-5
+    gv = lay.views(g)
+    for k, ref in go.items():
+        e = (gv[k].cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-8)
+        assert e < 2e-3, (k, e)
