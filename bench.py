@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: training patches/s of the PUNet Mean-Teacher step on 512x512 LIVECell-shaped synthetic
+patches (BASELINE.json metric), N GPUs of one node, one process per GPU, RCCL all-reduce of the flat gradient.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mean_teacher|punet_source|inference]
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one Mean-Teacher iteration on a batch of 4 patches per GPU (mean_teacher_trainer.py:101-131):
+teacher forward + N=8 Monte-Carlo samples + consensus masking, student forward, ELBO (BCE + KL) + L2 regulariser,
+full backward, gradient all-reduce, Adam, EMA teacher update.  Inputs are resident in HBM before the timed region.
+fp32 everywhere (parity mode: exact-fp32 MFMA, logits within 1e-3 of the reference); nothing is skipped or cached.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel = the 3x3 MFMA
+convolution, algorithmic FLOPs / HIP-event duration measured live in the timed region, against the 157.3 TFLOP/s fp32
+matrix peak) and `cpu_baseline` (the CPU oracle = a port of the reference's path, timed on the host cores, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NF = [64, 128, 256, 512]
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+# algorithmic GFLOP per patch at 512x512x1
+GFLOP = {"mean_teacher": {8: 3233.4, 16: 3269.6}, "punet_source": 2539.4, "inference": {8: 694.0, 16: 730.2}}
+
+
+def synth(B, H, W, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    k = torch.ones(1, 1, 5, 5) / 25.0
+    blur = lambda t: torch.nn.functional.conv2d(torch.nn.functional.pad(t, (2, 2, 2, 2), mode="reflect"), k)
+    x = blur(torch.randn(B, 1, H, W, generator=g))
+    x = (x - x.mean(dim=(1, 2, 3), keepdim=True)) / (x.std(dim=(1, 2, 3), keepdim=True) + 1e-7)
+    x1 = x + 0.1 * torch.randn(x.shape, generator=g)
+    x2 = 1.5 * blur(x) + 0.25 * torch.randn(x.shape, generator=g)
+    y = (blur(torch.randn(B, 1, H, W, generator=g)) * 5.0 > 0.3).float()
+    return [t.contiguous().to(dev) for t in (x, x1, x2, y)]
+
+
+def cpu_baseline(workload, n_samples, H, W, budget_s=12.0):
+    """The CPU oracle (own restatement of the reference path, pinned by golden fixtures) on the host cores."""
+    from oracle import punet_oracle as O
+    torch.set_num_threads(os.cpu_count())
+    cfg = O.PUNetConfig(1, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    Pnp = O.synth_params(cfg.spec(), 1)
+
+    def one(h, w):
+        Ps, Pt = O.to_torch(Pnp, True), O.to_torch(Pnp)
+        opt = O.AdamState(Ps, lr=1e-5)
+        x, x1, x2, y = O.synth_batch(1, 1, h, w, 0)
+        g = torch.Generator().manual_seed(2)
+        et, es = torch.randn(n_samples, 1, 6, generator=g), torch.randn(1, 6, generator=g)
+        t0 = time.time()
+        if workload == "mean_teacher":
+            O.mean_teacher_step(Ps, Pt, cfg, opt, x1, x2, et, es, True)
+        elif workload == "punet_source":
+            O.punet_step(Ps, cfg, opt, x2, y, es)
+        else:
+            O.mc_prediction(Ps, cfg, x1, et)
+        return time.time() - t0
+
+    one(64, 64)  # warm-up (page-in, thread pools)
+    times = []
+    while sum(times) < budget_s and len(times) < 3:
+        times.append(one(H, W))
+    per = sum(times) / len(times)
+    return {"value": round(1.0 / per, 5), "unit": "patches/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{len(times)} x (batch 1, {H}x{W}, N={n_samples}) {workload} step of the CPU oracle "
+                      f"(torch {torch.__version__} CPU fp32, {torch.get_num_threads()} threads), {per:.2f} s each"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="mean_teacher", choices=["mean_teacher", "punet_source", "inference"])
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--samples", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" == RCCL on ROCm
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+
+    B, H, W, N = a.batch, a.size, a.size, a.samples
+    model = ProbabilisticUnet(1, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=1)
+    teacher = None
+    if a.workload == "mean_teacher":
+        import copy
+        teacher = copy.deepcopy(model)
+    opt = FusedAdam(model, lr=1e-5)
+    x, x1, x2, y = synth(B, H, W, 100 + rank, dev)  # every rank its own shard of the synthetic stream
+    gen = torch.Generator(device=dev).manual_seed(7 + rank)
+    model.generator = gen
+    if teacher is not None:
+        teacher.generator = gen
+
+    def step():
+        if a.workload == "mean_teacher":
+            FU.fused_self_training_step(model, teacher, opt, x1, x2, N, True, None, None, 0.999, 1e-5)
+        elif a.workload == "punet_source":
+            FU.fused_supervised_step(model, opt, x2, y, None, None, 1e-5)
+        else:
+            FU.pseudo_labels(model, x1, N, True)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    eng = model.engine
+    engines = [eng] + ([teacher.engine] if teacher is not None else [])
+    prof = None if a.no_kernel_timing else []
+    for e in engines:
+        e.prof = prof
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    for e in engines:
+        e.prof = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        patches = world * B * a.steps
+        gf = GFLOP[a.workload]
+        gf = gf[N] if isinstance(gf, dict) else gf
+        if (H, W) != (512, 512):
+            gf = gf * (H * W) / (512 * 512)
+        out = {
+            "metric": "training patches/sec (512x512, N=8 MC samples)" if a.workload != "inference" else "inference patches/sec",
+            "value": round(patches / dt, 4), "unit": "patches/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"PUNet {a.workload} step: nf={NF}, latent 6, fcomb 3, BCE+KL, consensus masking, "
+                                   f"{H}x{W}x1 patches, batch {B}/GPU, N={N} MC samples, Adam lr 1e-5, EMA 0.999",
+                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "algorithmic_gflop_per_patch": gf,
+                       "model_tflops_per_gpu": round(gf * patches / dt / world / 1e3, 2)},
+        }
+        if prof:
+            agg = {}
+            for kind, fl, e0, e1 in prof:
+                d = agg.setdefault(kind, [0.0, 0.0, 0])
+                d[0] += fl
+                d[1] += e0.elapsed_time(e1) * 1e-3
+                d[2] += 1
+            kernels = {k: {"launches": v[2], "avg_ms": round(1e3 * v[1] / v[2], 4), "tflops": round(v[0] / v[1] / 1e12, 2),
+                           "share_of_step": round(v[1] / dt, 3)} for k, v in agg.items()}
+            k3 = agg.get("conv3x3_fwd")
+            if k3:
+                ach = k3[0] / k3[1] / 1e12
+                out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                   "kernel": "conv_mfma_kernel<3,false> (3x3 NHWC direct conv forward, fp32 MFMA)",
+                                   "flops_per_launch_avg": k3[0] / k3[2], "avg_launch_ms": round(1e3 * k3[1] / k3[2], 4),
+                                   "peak_note": "fp32-input MFMA dense peak (parity mode); bf16 MFMA is not used"}
+            out["kernels"] = kernels
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a.workload, N, H, W)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

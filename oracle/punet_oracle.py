@@ -155,9 +155,18 @@ def to_torch(params_np, requires_grad: bool = False) -> Params:
 # --------------------------------------------------------------------------------------
 # model forward
 # --------------------------------------------------------------------------------------
+# Optional ReLU gates (tests only): when RELU_GATES maps a conv name to a 0/1 tensor, that layer's ReLU is applied as
+# pre_activation * gate instead of max(pre_activation, 0).  GPU gradient-parity tests pass the gates of the GPU's own
+# forward, so that a pre-activation within fp32 rounding of 0 (which may legitimately resolve to either side) does not
+# turn into an O(1) difference of individual gradients.  Default None = the reference's plain ReLU.
+RELU_GATES = None
+
+
 def _conv_relu(P: Params, name: str, x: torch.Tensor, relu: bool = True) -> torch.Tensor:
     w = P[name + ".weight"]
     y = F.conv2d(x, w, P[name + ".bias"], stride=1, padding=w.shape[-1] // 2)
+    if relu and RELU_GATES is not None and name in RELU_GATES:
+        return y * RELU_GATES[name].to(y.dtype)
     return F.relu(y) if relu else y
 
 

@@ -106,7 +106,10 @@ __global__ void pool2x2_bwd_kernel(const float4* __restrict__ dy, const float4* 
 // source index as ATen computes it: scale = (in - 1) / (out - 1) in fp32, src = scale * dst.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void up_src(int o, float scale, int in_size, int& i0, int& ip, float& l1) {
-    const float src = scale * (float)o;
+#pragma clang fp contract(off)
+    // __fmul_rn: keep the product ROUNDED like ATen's CPU kernel does; a contracted fma(scale, o, -i0) is more
+    // exact but moves the interpolation weight by ulp(src) ~ 2e-6, which the cancellation src - i0 exposes
+    const float src = __fmul_rn(scale, (float)o);
     i0 = (int)src;
     if (i0 > in_size - 1) i0 = in_size - 1;
     ip = (i0 < in_size - 1) ? 1 : 0;

@@ -200,6 +200,18 @@ class PUNetEngine:
             raise RuntimeError("PUNetEngine needs a ROCm device: the product path has no CPU fallback")
         _lib.load()
         self.ws = Workspace(self.device)
+        self.prof = None  # when a list: (kind, algorithmic FLOPs, start event, end event) per 3x3 MFMA launch
+
+    def _timed(self, kind, flops, name, *args):
+        """Launch through the C ABI; with self.prof set, bracket the launch with HIP events on the launch stream."""
+        if self.prof is None:
+            return _lib.call(name, *args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = _lib.call(name, *args)
+        e1.record()
+        self.prof.append((kind, flops, e0, e1))
+        return r
         tab, self.l2_ntensors = layout.l2_chunk_table()
         self.l2_chunks = tab.to(self.device)
         self.l2_nchunks = tab.shape[0]
@@ -220,7 +232,7 @@ class PUNetEngine:
         return x.permute(0, 2, 3, 1).contiguous()
 
     # ---------------------------------------------------------------- forward ops
-    def conv(self, flat, name: str, x0: Act, x1: Optional[Act] = None, relu=True, tape=None) -> Act:
+    def conv(self, flat, name: str, x0: Act, x1: Optional[Act] = None, relu=True, tape=None, taps=None) -> Act:
         c = self.L.convs[name]
         B, H, W = x0.B, x0.H, x0.W
         y = Act(self._empty(B, H, W, c.cout), B, H, W, c.cout, relu_out=relu)
@@ -231,10 +243,13 @@ class PUNetEngine:
             _lib.call("punet_conv3x3_small_fwd", x0.ptr, cin, self._wptr(flat, c), self._bptr(flat, c), y.ptr, c.cout,
                       B, H, W, int(relu), _stream())
         else:
-            _lib.call("punet_conv_fwd", x0.ptr, x0.C, x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0,
-                      self._wptr(flat, c), self._bptr(flat, c), 0, y.ptr, c.cout, B, H, W, c.k, int(relu), _stream())
+            self._timed(f"conv{c.k}x{c.k}_fwd", 2.0 * B * H * W * cin * c.cout * c.k * c.k, "punet_conv_fwd", x0.ptr, x0.C,
+                        x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0, self._wptr(flat, c),
+                        self._bptr(flat, c), 0, y.ptr, c.cout, B, H, W, c.k, int(relu), _stream())
         if tape is not None:
             tape.append(("conv", c, x0, x1, y))
+        if taps is not None:
+            taps["conv:" + name] = y
         return y
 
     def pool(self, x: Act, tape=None) -> Act:
@@ -259,7 +274,7 @@ class PUNetEngine:
             if i != 0:
                 x = self.pool(x, tape)
             for nm in names:
-                x = self.conv(flat, nm, x, None, True, tape)
+                x = self.conv(flat, nm, x, None, True, tape, taps)
             outs.append(x)
             if taps is not None:
                 taps[f"{tag}{i}"] = x
@@ -274,9 +289,9 @@ class PUNetEngine:
             up = self.upsample(x, tape)
             bridge = outs[-j - 2]
             assert up.W == bridge.W and up.H == bridge.H  # unet_blocks.py:55
-            x = self.conv(flat, names[0], up, bridge, True, tape)  # concat order [up, bridge] (unet_blocks.py:56)
-            x = self.conv(flat, names[1], x, None, True, tape)
-            x = self.conv(flat, names[2], x, None, True, tape)
+            x = self.conv(flat, names[0], up, bridge, True, tape, taps)  # concat order [up, bridge] (unet_blocks.py:56)
+            x = self.conv(flat, names[1], x, None, True, tape, taps)
+            x = self.conv(flat, names[2], x, None, True, tape, taps)
             if taps is not None:
                 taps[f"unet.up{j}"] = x
         return x
@@ -382,8 +397,10 @@ class PUNetEngine:
         _lib.call("punet_conv_fwd", feat.ptr, CH, None, 0, self._wptr(flat, c1), zb.data_ptr(), CH, h.ptr, CH, B, H, W, 1, 1,
                   _stream())
         hs = [h]
+        if taps is not None:
+            taps["conv:fcomb.layers.0"] = h
         for nm in L.fcomb_mid:
-            h = self.conv(flat, nm, h, None, True, None)
+            h = self.conv(flat, nm, h, None, True, None, taps)
             hs.append(h)
         P = B * H * W
         logits = self._empty(B, 1, H, W)
@@ -417,8 +434,9 @@ class PUNetEngine:
             return
         ns = _lib.call("punet_wgrad_slices", x.C, c.cout, B, H, W)
         ws = self.ws.get("wgrad", _lib.call("punet_wgrad_workspace_floats", x.C, c.cout, c.k, ns))
-        _lib.call("punet_conv_wgrad", x.ptr, x.C, dz.data_ptr(), c.cout, dw, c.cin, ci_off, db if with_bias else None,
-                  ws.data_ptr(), ns, B, H, W, c.k, int(accumulate), 1.0, _stream())
+        self._timed(f"conv{c.k}x{c.k}_wgrad", 2.0 * B * H * W * x.C * c.cout * c.k * c.k, "punet_conv_wgrad", x.ptr, x.C,
+                    dz.data_ptr(), c.cout, dw, c.cin, ci_off, db if with_bias else None, ws.data_ptr(), ns, B, H, W, c.k,
+                    int(accumulate), 1.0, _stream())
 
     def _grad_into(self, gm: dict, a: Act):
         """(buffer, accumulate flag) for the gradient of activation a."""
@@ -443,8 +461,10 @@ class PUNetEngine:
                         continue
                     if src.needs_grad:
                         g, acc = self._grad_into(gm, src)
-                        _lib.call("punet_conv_dgrad", dz.data_ptr(), c.cout, self._wptr(flat, c), c.cin, off, src.C,
-                                  g.data_ptr(), src.ptr if src.relu_out else None, acc, src.B, src.H, src.W, c.k, _stream())
+                        self._timed(f"conv{c.k}x{c.k}_dgrad", 2.0 * src.B * src.H * src.W * src.C * c.cout * c.k * c.k,
+                                    "punet_conv_dgrad", dz.data_ptr(), c.cout, self._wptr(flat, c), c.cin, off, src.C,
+                                    g.data_ptr(), src.ptr if src.relu_out else None, acc, src.B, src.H, src.W, c.k,
+                                    _stream())
                     off += src.C
             elif op[0] == "pool":
                 _, x, y = op

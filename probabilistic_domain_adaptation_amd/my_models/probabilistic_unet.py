@@ -1,0 +1,289 @@
+"""`ProbabilisticUnet` with the reference's API surface, computed by the gfx950 kernels.
+
+Mirror of prob_utils/my_models/probabilistic_unet.py:217-371 (constructor kwargs, stateful
+forward() -> sample() / reconstruct() / kl_divergence() / elbo(), attributes the trainers read) and of its
+state-dict contract (same key names, same logical shapes, intended nf[i-1] -> nf[i] wiring).
+
+Differences that are deliberate and documented:
+  * all parameters live in ONE flat device buffer in kernel layout; the nn.Parameters registered under the
+    reference's names are permuted views of it (state_dict()/load_state_dict()/optimizers work unchanged);
+  * latent draws use an injectable standard-normal `eps` (the reference draws from torch's global generator,
+    probabilistic_unet.py:302,307,349) so that results are reproducible against the CPU oracle;
+  * elbo() runs the HIP forward AND backward eagerly and returns a scalar attached to autograd through a thin
+    Function, so `backprop(loss)` of a torch_em-style trainer still fills `.grad` of every parameter;
+  * there is no CPU fallback: constructing the model without a ROCm device raises.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ..engine import ParamLayout, PUNetEngine
+
+
+class _Node(nn.Module):
+    """Container that reproduces the reference's module tree so parameter names match its state-dict."""
+
+
+def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
+    parts = dotted.split(".")
+    node = root
+    for p in parts[:-1]:
+        nxt = node._modules.get(p)
+        if nxt is None:
+            nxt = _Node()
+            node.add_module(p, nxt)
+        node = nxt
+    node.register_parameter(parts[-1], param)
+
+
+class _LatentSpace:
+    """What the trainers may read from `prior_latent_space` / `posterior_latent_space`
+    (Independent(Normal(mu, sigma), 1) in the reference, probabilistic_unet.py:141)."""
+
+    def __init__(self, muls: torch.Tensor, latent_dim: int):
+        self.muls = muls
+        self.loc = muls[:, :latent_dim]
+        self.scale = muls[:, latent_dim:].exp()
+        self.base_dist = self
+
+    def distribution(self):
+        return torch.distributions.Independent(torch.distributions.Normal(self.loc, self.scale), 1)
+
+
+class _ElboFn(torch.autograd.Function):
+    """elbo value whose backward hands out the gradients the HIP backward already computed."""
+
+    @staticmethod
+    def forward(ctx, value, gflat, layout, *params):
+        ctx.gflat, ctx.layout = gflat, layout
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        # gflat holds d(rec + beta*kl)/d theta = d(-elbo)/d theta
+        g = ctx.gflat * (-grad_out)
+        return (None, None, None) + tuple(ctx.layout.views(g).values())
+
+
+class ProbabilisticUnet(nn.Module):
+    """A probabilistic UNet (https://arxiv.org/abs/1806.05034); same signature as the reference's
+    (probabilistic_unet.py:227-237)."""
+
+    def __init__(self, input_channels=1, num_classes=1, num_filters=[32, 64, 128, 192], latent_dim=6, no_convs_fcomb=4,
+                 beta=10.0, consensus_masking=False, rl_swap=False, device=None, seed: Optional[int] = None):
+        super().__init__()
+        self.input_channels = input_channels
+        self.num_classes = num_classes
+        self.num_filters = list(num_filters)
+        self.latent_dim = latent_dim
+        self.no_convs_per_block = 3
+        self.no_convs_fcomb = no_convs_fcomb
+        self.initializers = {'w': 'he_normal', 'b': 'normal'}
+        self.beta = beta
+        self.z_prior_sample = 0
+        self.consensus_masking = consensus_masking
+        self.rl_swap = rl_swap
+
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device()) \
+            if torch.cuda.is_available() else None
+        if dev is None or dev.type != "cuda":
+            raise RuntimeError("ProbabilisticUnet (MI355X build) needs a ROCm GPU: there is no CPU fallback")
+        self.layout = ParamLayout(input_channels, num_classes, self.num_filters, latent_dim, no_convs_fcomb)
+        self.engine = PUNetEngine(self.layout, dev)
+        self._flat = torch.zeros(self.layout.numel, dtype=torch.float32, device=dev)
+        self._views = self.layout.views(self._flat)
+        for name, v in self._views.items():
+            _attach(self, name, nn.Parameter(v, requires_grad=True))
+        self.reset_parameters(seed)
+        self._state = None
+        self.generator = None  # optional torch.Generator (device) for the latent draws
+
+    # ------------------------------------------------------------------ parameters
+    @property
+    def flat_params(self) -> torch.Tensor:
+        return self._flat
+
+    @property
+    def device(self):
+        return self._flat.device
+
+    def reset_parameters(self, seed: Optional[int] = None):
+        """Same init families as the reference: He-normal weights + truncated-normal(1e-3) biases for the 3x3 stacks
+        (utils.py:16-21), orthogonal weights for Fcomb and the latent heads (utils.py:24-28,
+        probabilistic_unet.py:110-111)."""
+        g = torch.Generator().manual_seed(seed if seed is not None else torch.seed() % (2 ** 31))
+        with torch.no_grad():
+            for name, v in self._views.items():
+                shape = tuple(v.shape)
+                if name.endswith(".weight"):
+                    w = torch.empty(shape)
+                    if name.startswith("fcomb.") or name.endswith("conv_layer.weight"):
+                        nn.init.orthogonal_(w, generator=g)
+                    else:
+                        nn.init.kaiming_normal_(w, mode="fan_in", nonlinearity="relu", generator=g)
+                    v.copy_(w)
+                else:
+                    b = torch.empty(shape)
+                    nn.init.trunc_normal_(b, std=0.001, a=-0.002, b=0.002, generator=g)
+                    v.copy_(b)
+
+    def __deepcopy__(self, memo):
+        """deepcopy(model) -> teacher (mean_teacher_trainer.py:40): a new flat buffer with the same values."""
+        m = ProbabilisticUnet(self.input_channels, self.num_classes, self.num_filters, self.latent_dim, self.no_convs_fcomb,
+                              self.beta, self.consensus_masking, self.rl_swap, device=self.device, seed=0)
+        with torch.no_grad():
+            m._flat.copy_(self._flat)
+        for p, q in zip(m.parameters(), self.parameters()):
+            p.requires_grad_(q.requires_grad)
+        m.train(self.training)
+        return m
+
+    def _apply(self, fn, recurse=True):
+        # .to(device)/.cuda() would break the flat-buffer views; the model is built on its GPU and stays there
+        probe = fn(torch.empty(0, device=self.device))
+        if probe.device != self.device or probe.dtype != torch.float32:
+            raise RuntimeError("the MI355X ProbabilisticUnet lives in one flat fp32 device buffer; build it on its device")
+        return self
+
+    # ------------------------------------------------------------------ reference API
+    def _eps(self, n: int, batch: int, eps: Optional[torch.Tensor]) -> torch.Tensor:
+        if eps is None:
+            eps = torch.randn(n, batch, self.latent_dim, device=self.device, generator=self.generator)
+        eps = eps.to(device=self.device, dtype=torch.float32).reshape(n, batch, self.latent_dim).contiguous()
+        return eps
+
+    def forward(self, patch, segm, training=True):
+        """probabilistic_unet.py:285-293.  Returns None; stores prior_latent_space / unet_features (and remembers
+        patch, segm so that elbo() can run the fused training forward+backward)."""
+        eng = self.engine
+        x = eng.to_nhwc(patch)
+        if training and segm is None:
+            raise ValueError("forward(patch, None, training=True) is invalid: the posterior needs the segmentation")
+        self._state = {"x": x, "segm": segm, "training": training}
+        if torch.is_grad_enabled() and training:
+            # the expensive pass happens in elbo(), which knows the target; keep only what sample() may need lazily
+            self._state["lazy"] = True
+            return None
+        self._run_inference_forward()
+        return None
+
+    def _run_inference_forward(self):
+        st = self._state
+        out = self.engine.forward_features(self._flat, st["x"])
+        st.update(out)
+        st["lazy"] = False
+        self.unet_features = out["features"].t.permute(0, 3, 1, 2)
+        self.prior_latent_space = _LatentSpace(out["prior_muls"], self.latent_dim)
+        if st["training"]:
+            # posterior for no-grad validation (mean_teacher_trainer.py:160): computed inside elbo()
+            pass
+
+    def _ensure_features(self):
+        if self._state is None:
+            raise RuntimeError("call forward() first")
+        if self._state.get("lazy", False) or "features" not in self._state:
+            self._run_inference_forward()
+
+    def sample(self, testing=False, eps: Optional[torch.Tensor] = None):
+        """probabilistic_unet.py:295-309: logits of one prior sample ([B,1,H,W])."""
+        self._ensure_features()
+        st = self._state
+        B = st["x"].shape[0]
+        z = self.engine.reparam(st["prior_muls"], self._eps(1, B, eps))
+        self.z_prior_sample = z[0]
+        _, _, logits = self.engine.sample(self._flat, st["features"], z, want_logits=True, want_consensus=False)
+        return logits[0]
+
+    def sample_consensus(self, n_samples: int, upper=0.9, lower=0.1, masking=False, eps: Optional[torch.Tensor] = None):
+        """Fused form of `[sigmoid(sample()) for _ in range(n)]` + thresholds + stack/sum
+        (mean_teacher_trainer.py:74-86): returns (mean of sigmoids, consensus) as [B,1,H,W] float tensors."""
+        self._ensure_features()
+        st = self._state
+        B = st["x"].shape[0]
+        z = self.engine.reparam(st["prior_muls"], self._eps(n_samples, B, eps))
+        y, c, _ = self.engine.sample(self._flat, st["features"], z, upper, lower, masking)
+        return y, c
+
+    def reconstruct(self, use_posterior_mean=False, calculate_posterior=False, z_posterior=None):
+        """probabilistic_unet.py:311-322 (forward only)."""
+        self._ensure_features()
+        st = self._state
+        if use_posterior_mean:
+            z_posterior = self.posterior_latent_space.loc
+        elif calculate_posterior:
+            B = st["x"].shape[0]
+            z_posterior = self.engine.reparam(self.posterior_latent_space.muls, self._eps(1, B, None))[0]
+        z = z_posterior.reshape(1, -1, self.latent_dim).contiguous()
+        _, _, logits = self.engine.sample(self._flat, st["features"], z, want_logits=True, want_consensus=False)
+        return logits[0]
+
+    def kl_divergence(self, analytic=True, calculate_posterior=False, z_posterior=None):
+        """probabilistic_unet.py:324-339 -> [B]."""
+        q = self.posterior_latent_space.distribution()
+        p = self.prior_latent_space.distribution()
+        if analytic:
+            return torch.distributions.kl.kl_divergence(q, p)
+        if calculate_posterior:
+            z_posterior = q.rsample()
+        return q.log_prob(z_posterior) - p.log_prob(z_posterior)
+
+    def elbo(self, segm, consm=None, analytic_kl=True, reconstruct_posterior_mean=False, view=False,
+             eps: Optional[torch.Tensor] = None):
+        """probabilistic_unet.py:341-371: -(reconstruction_loss + beta * kl).
+
+        Runs posterior/prior encoders, U-Net, Fcomb, criterion and KL on the GPU; with grad mode on it also runs the
+        whole backward and returns a scalar wired into autograd (see _ElboFn)."""
+        if not analytic_kl or reconstruct_posterior_mean:
+            raise NotImplementedError("the HIP path implements analytic_kl=True, reconstruct_posterior_mean=False "
+                                      "(the only combination the reference trainers use)")
+        st = self._state
+        if st is None or not st["training"]:
+            raise RuntimeError("elbo() needs forward(patch, segm, training=True) first")
+        eng = self.engine
+        B = st["x"].shape[0]
+        H, W = st["x"].shape[1], st["x"].shape[2]
+        tgt = st["segm"] if st["segm"] is not None else segm
+        # the posterior saw forward()'s segm (probabilistic_unet.py:291); the criterion uses elbo()'s (== in every trainer)
+        tgt = tgt.to(device=self.device, dtype=torch.float32).reshape(B, 1, H, W).contiguous()
+        seg = segm.to(device=self.device, dtype=torch.float32).reshape(B, 1, H, W).contiguous()
+        if seg.data_ptr() != tgt.data_ptr() and not torch.equal(seg, tgt):
+            raise NotImplementedError("elbo(segm) with a segm different from forward()'s is not supported")
+        cm = None
+        if self.consensus_masking is True and consm is not None:
+            cm = consm.to(device=self.device, dtype=torch.float32).reshape(B, 1, H, W).contiguous()
+        e = self._eps(1, B, eps)[0]
+        record = torch.is_grad_enabled()
+        es = eng.elbo_forward(self._flat, st["x"], tgt, cm, e, "dice" if self.rl_swap else "bce", self.beta, 1.0, record)
+        self.posterior_latent_space = _LatentSpace(es["muls_q"], self.latent_dim)
+        self.prior_latent_space = _LatentSpace(es["muls_p"], self.latent_dim)
+        self.unet_features = es["feat"].t.permute(0, 3, 1, 2)
+        st.update(features=es["feat"], prior_muls=es["muls_p"], lazy=False)
+        self.kl = es["kl"][0]
+        self.reconstruction = es["logits"]
+        self.reconstruction_loss = es["rec"][0]
+        self.mean_reconstruction_loss = self.reconstruction_loss / float(B * H * W) if not self.rl_swap \
+            else self.reconstruction_loss
+        value = -(self.reconstruction_loss + self.beta * self.kl)
+        if not record:
+            return value
+        gflat = torch.empty_like(self._flat)
+        eng.elbo_backward(self._flat, gflat, es, accumulate=False)
+        return _ElboFn.apply(value, gflat, self.layout, *self.parameters())
+
+    # ------------------------------------------------------------------ state-dict compatibility
+    def load_reference_state_dict(self, state_dict, strict=True):
+        """Accepts a checkpoint's ["model_state"] / ["teacher_state"] (livecell_punet.py:101, livecell_mt.py:145)."""
+        return self.load_state_dict(state_dict, strict=strict)
+
+
+def l2_regularisation(m):
+    """utils.py:32-40 (kept for drop-in trainers; the fused trainers use the K10 kernels instead)."""
+    l2_reg = None
+    for W in m.parameters():
+        l2_reg = W.norm(2) if l2_reg is None else l2_reg + W.norm(2)
+    return l2_reg

@@ -1,0 +1,119 @@
+"""MC-sample inference on the HIP hot path (prob_utils/my_predictions/punet_predictions.py:15-136).
+
+Compute lives in `mc_prediction` / `predict_image` / `pseudo_predict_image` (numpy image in, numpy out); the path-based
+wrappers `punet_prediction` / `punet_pseudo_prediction` keep the reference signatures and need `imageio` for TIFF I/O
+(file I/O is out of the hot-path scope).
+
+Tiling follows what the reference delegates to the un-vendored `torch_em.util.prediction.predict_with_halo`
+(punet_predictions.py:41-49: block 384x384, halo 64x64 -> 512x512 outer tile) as RECALLED in SURVEY.md §8c: blocks
+read with their halo, reflect padding where the halo leaves the image, per-tile standardisation, halo cropped from the
+output.  That third-party routine is not in /root/reference -> tiling parity is unpinned; per-tile arithmetic is the
+pinned `_custom_punet_prediction` body (punet_predictions.py:29-33).
+"""
+from __future__ import annotations
+
+import os
+from glob import glob
+
+import numpy as np
+import torch
+
+
+def standardize(raw: np.ndarray, eps: float = 1e-7) -> np.ndarray:
+    """[recalled] torch_em.transform.raw.standardize: (x - mean) / (std + eps) over the whole array."""
+    raw = raw.astype("float32")
+    return (raw - raw.mean()) / (raw.std() + eps)
+
+
+@torch.no_grad()
+def mc_prediction(model, raw: torch.Tensor, prior_samples: int = 8, eps=None) -> torch.Tensor:
+    """_custom_punet_prediction (punet_predictions.py:29-33): forward(raw, None, False), then the mean of
+    `prior_samples` sigmoid(sample(testing=True)) - one fused K7 launch instead of N Fcomb passes."""
+    model.forward(raw, None, training=False)
+    y, _ = model.sample_consensus(prior_samples, eps=eps)
+    return y
+
+
+def _tiles(shape, block_shape, halo):
+    for y0 in range(0, shape[0], block_shape[0]):
+        for x0 in range(0, shape[1], block_shape[1]):
+            y1, x1 = min(y0 + block_shape[0], shape[0]), min(x0 + block_shape[1], shape[1])
+            yield (y0, y1, x0, x1)
+
+
+@torch.no_grad()
+def predict_image(model, image: np.ndarray, prior_samples: int = 8, block_shape=(384, 384), halo=(64, 64),
+                  tile_batch: int = 4, multiple_of: int = 8) -> np.ndarray:
+    """Tiled MC prediction of one 2-D image -> float32 mean-probability map (punet_predictions.py:35-50).
+    Tiles of equal outer shape are batched (`tile_batch` per launch); every tile gets its own latent draws."""
+    assert image.ndim == 2, "2-D single-channel images (every reference script uses input_channels=1)"
+    H, W = image.shape
+    out = np.zeros((H, W), dtype="float32")
+    pad = ((halo[0], halo[0] + block_shape[0]), (halo[1], halo[1] + block_shape[1]))
+    padded = np.pad(image.astype("float32"), pad, mode="reflect" if min(H, W) > max(halo) else "symmetric")
+    groups = {}
+    for (y0, y1, x0, x1) in _tiles((H, W), block_shape, halo):
+        bh, bw = y1 - y0, x1 - x0
+        oh = -(-(bh + 2 * halo[0]) // multiple_of) * multiple_of
+        ow = -(-(bw + 2 * halo[1]) // multiple_of) * multiple_of
+        tile = standardize(padded[y0:y0 + oh, x0:x0 + ow])  # padded origin is (-halo, -halo)
+        groups.setdefault((oh, ow), []).append(((y0, y1, x0, x1), tile))
+    dev = model.device
+    for (oh, ow), items in groups.items():
+        for i in range(0, len(items), tile_batch):
+            chunk = items[i:i + tile_batch]
+            raw = torch.from_numpy(np.stack([t for _, t in chunk])[:, None]).to(dev)
+            pred = mc_prediction(model, raw, prior_samples).cpu().numpy()[:, 0]
+            for k, ((y0, y1, x0, x1), _) in enumerate(chunk):
+                out[y0:y1, x0:x1] = pred[k, halo[0]:halo[0] + (y1 - y0), halo[1]:halo[1] + (x1 - x0)]
+    return out
+
+
+@torch.no_grad()
+def pseudo_predict_image(model, image: np.ndarray, prior_samples: int = 8, upper_threshold=0.9, lower_threshold=0.1):
+    """Whole-image forward, mean of N sigmoids and the binary consensus mask (punet_predictions.py:96-124):
+    returns (mean float32 [H, W], consensus uint8 [H, W])."""
+    patch = torch.from_numpy(standardize(image))[None, None].to(model.device)
+    model.forward(patch, None, training=False)
+    y, z = model.sample_consensus(prior_samples, upper_threshold, lower_threshold, masking=True)
+    return y[0, 0].cpu().numpy(), z[0, 0].cpu().numpy().astype("uint8")
+
+
+def _imageio():
+    try:
+        import imageio.v3 as imageio
+        return imageio
+    except ImportError as e:  # pragma: no cover
+        raise ImportError("punet_prediction's TIFF I/O needs `imageio` (not installed here); use predict_image() / "
+                          "pseudo_predict_image() on arrays instead") from e
+
+
+def punet_prediction(input_image_path: str, output_pred_path: str, model, prior_samples: int = 8, device: str = "cuda",
+                     mysig=None):
+    """Reference signature (punet_predictions.py:15-63)."""
+    imageio = _imageio()
+    model.eval()
+    os.makedirs(output_pred_path, exist_ok=True)
+    for img_path in glob(input_image_path):
+        pred = predict_image(model, imageio.imread(img_path), prior_samples)
+        out = os.path.join(output_pred_path, f"{os.path.basename(img_path)[:-4]}.tif")
+        imageio.imwrite(out, pred, compression="zlib")
+        print(f"Saved image at '{out}")
+
+
+def punet_pseudo_prediction(input_image_path, output_pred_path, model, prior_samples=8, device="cuda", cellname_=None,
+                            split_name: str = None):
+    """Reference signature (punet_predictions.py:66-136)."""
+    imageio = _imageio()
+    os.makedirs(output_pred_path, exist_ok=True)
+    model.eval()
+    for i in glob(input_image_path + f"{cellname_}*.tif"):
+        name = i.split("/")[-1]
+        mypred, consensus = pseudo_predict_image(model, imageio.imread(i), prior_samples)
+        dir1 = output_pred_path + f"annotations/{split_name}/{cellname_}/"
+        dir2 = output_pred_path + f"consensus/{split_name}/{cellname_}/"
+        os.makedirs(dir1, exist_ok=True)
+        os.makedirs(dir2, exist_ok=True)
+        imageio.imwrite(dir1 + name, mypred)
+        imageio.imwrite(dir2 + name, consensus)
+        print(f"{name}'s predictions saved")

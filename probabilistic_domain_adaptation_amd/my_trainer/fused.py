@@ -1,0 +1,174 @@
+"""Fused (autograd-free) training steps and the flat-buffer optimizer.
+
+`FusedAdam` is torch.optim.Adam's arithmetic (defaults, LIVECell/livecell_mt.py:83) on the model's flat parameter buffer,
+fused with the EMA teacher update (mean_teacher_trainer.py:52-55) in one kernel (K11 + K12).  The step functions are the
+per-iteration bodies of the reference trainers with every tensor op replaced by a kernel launch and no host sync.
+
+Data parallelism: one process per GPU; the flat gradient buffer is summed with ONE RCCL all-reduce (torch.distributed
+backend "nccl" == RCCL on ROCm) and the 1/world_size scale is folded into the Adam kernel.  Per-rank loss semantics =
+reference semantics at the per-GPU batch (reconstruction is a SUM over the local batch, KL a local batch mean);
+gradients are averaged over ranks (DDP convention) - see DESIGN.md §6.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from ..my_models import ProbabilisticUnet
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """Adam on a ProbabilisticUnet's flat buffer.  Usable (a) by the fused steps (gradients already in `grad_flat`) and
+    (b) as a drop-in `optimizer.step()` after `loss.backward()` (gradients gathered from `.grad`)."""
+
+    def __init__(self, model: ProbabilisticUnet, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps))
+        self.model = model
+        flat = model.flat_params
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.grad_flat = torch.zeros_like(flat)
+        self.step_count = 0
+
+    @property
+    def lr(self) -> float:
+        return self.param_groups[0]["lr"]
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.model.parameters():
+            p.grad = None
+
+    def gather_grads(self):
+        """Copy autograd's per-parameter .grad into the flat gradient buffer (drop-in mode only)."""
+        views = self.model.layout.views(self.grad_flat)
+        with torch.no_grad():
+            for p, v in zip(self.model.parameters(), views.values()):
+                if p.grad is None:
+                    v.zero_()
+                else:
+                    v.copy_(p.grad)
+
+    def fused_step(self, teacher: Optional[ProbabilisticUnet] = None, ema_momentum: float = 0.999, grad_scale: float = 1.0):
+        """One Adam step from grad_flat (+ EMA into `teacher` when given) - a single kernel launch."""
+        g = self.param_groups[0]
+        self.step_count += 1
+        self.model.engine.adam_ema(self.model.flat_params, self.grad_flat, self.exp_avg, self.exp_avg_sq,
+                                   teacher.flat_params if teacher is not None else None, self.step_count, g["lr"],
+                                   g["betas"], g["eps"], grad_scale, ema_momentum, True)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self.gather_grads()
+        self.fused_step()
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(),
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.step_count = sd["step"]
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
+
+
+def ema_update(model: ProbabilisticUnet, teacher: ProbabilisticUnet, momentum: float):
+    """teacher = teacher * m + student * (1 - m) on the flat buffers (mean_teacher_trainer.py:52-55)."""
+    model.engine.adam_ema(model.flat_params, None, None, None, teacher.flat_params, 0, 0.0, ema_momentum=momentum,
+                          do_adam=False)
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def allreduce_grads(gflat: torch.Tensor) -> float:
+    """Sum the flat gradient over ranks (one RCCL ring all-reduce over xGMI); returns the scale to apply (1/world)."""
+    w = _world()
+    if w > 1:
+        dist.all_reduce(gflat, op=dist.ReduceOp.SUM)
+    return 1.0 / w
+
+
+def pseudo_labels(net: ProbabilisticUnet, x1, n_samples: int, masking: bool, eps=None, upper=0.9, lower=0.1):
+    """sample_from_teacher / sample_from_weak_model (mean_teacher_trainer.py:72-88, fixmatch_trainer.py:37-54), fused:
+    forward(x1, None, False) then K7.  Returns float [B,1,H,W] tensors (y soft mean, z consensus)."""
+    with torch.no_grad():
+        net.forward(x1, None, training=False)
+        return net.sample_consensus(n_samples, upper, lower, masking, eps)
+
+
+def elbo_grad_pass(model: ProbabilisticUnet, gflat, x, y, z, eps, gscale: float, accumulate: bool):
+    """forward(x, y, True); elbo(y, z); backward of gscale * (-elbo) into gflat.  Returns device scalars."""
+    eng = model.engine
+    B = x.shape[0]
+    xn = eng.to_nhwc(x)
+    H, W = xn.shape[1], xn.shape[2]
+    yt = y.to(device=model.device, dtype=torch.float32).reshape(B, 1, H, W).contiguous()
+    cm = None
+    if model.consensus_masking is True and z is not None:
+        cm = z.to(device=model.device, dtype=torch.float32).reshape(B, 1, H, W).contiguous()
+    e = model._eps(1, B, eps)[0]
+    st = eng.elbo_forward(model.flat_params, xn, yt, cm, e, "dice" if model.rl_swap else "bce", model.beta, gscale, True)
+    eng.elbo_backward(model.flat_params, gflat, st, accumulate)
+    return st["rec"][0], st["kl"][0], st
+
+
+def fused_supervised_step(model, opt: FusedAdam, x, y, z=None, eps=None, reg_weight=1e-5):
+    """PUNetTrainer / PseudoTrainerPUNet iteration (punet_trainer.py:24-36, punet_target_trainer.py:105-118)."""
+    eng = model.engine
+    rec, kl, _ = elbo_grad_pass(model, opt.grad_flat, x, y, z, eps, 1.0, False)
+    reg, norms = eng.l2_reg(model.flat_params)
+    eng.l2_reg_add_grad(model.flat_params, opt.grad_flat, norms, reg_weight)
+    scale = allreduce_grads(opt.grad_flat)
+    opt.fused_step(None, grad_scale=scale)
+    return rec + model.beta * kl + reg_weight * reg[0]
+
+
+def fused_self_training_step(model, teacher, opt: FusedAdam, x1, x2, n_samples: int, masking: bool, eps_pl=None, eps_s=None,
+                             momentum: Optional[float] = 0.999, reg_weight=1e-5, source_distribution=None):
+    """Mean-Teacher iteration (teacher = EMA copy, mean_teacher_trainer.py:101-131) or FixMatch iteration
+    (teacher is the model itself and momentum is None, fixmatch_trainer.py:67-95)."""
+    eng = model.engine
+    y, z = pseudo_labels(teacher, x1, n_samples, masking, eps_pl)
+    ratio = None
+    if source_distribution is not None:
+        y, ratio = distribution_alignment(y, source_distribution)
+    rec, kl, _ = elbo_grad_pass(model, opt.grad_flat, x2, y, z, eps_s, 1.0, False)
+    reg, norms = eng.l2_reg(model.flat_params)
+    eng.l2_reg_add_grad(model.flat_params, opt.grad_flat, norms, reg_weight)
+    scale = allreduce_grads(opt.grad_flat)
+    do_ema = momentum is not None and teacher is not model and bool(opt.lr)  # `if lr:` gate, mean_teacher_trainer.py:126
+    opt.fused_step(teacher if do_ema else None, ema_momentum=momentum if do_ema else 0.0, grad_scale=scale)
+    return rec + model.beta * kl + reg_weight * reg[0], y, z, ratio
+
+
+def fused_joint_step(model, teacher, opt: FusedAdam, xs, ys, xt1, xt2, n_samples: int, masking: bool, eps_sup=None,
+                     eps_pl=None, eps_s=None, momentum: Optional[float] = None, use_consensus=True, reg_weight=1e-5):
+    """AdaMT (adamt_trainer.py:89-128) / AdaMatch (adamatch_trainer.py:62-107) iteration:
+    loss = (supervised + target) / 2 with ONE optimizer step; two gradient passes at scale 0.5 accumulate."""
+    eng = model.engine
+    rec_s, kl_s, _ = elbo_grad_pass(model, opt.grad_flat, xs, ys, None, eps_sup, 0.5, False)
+    y, z = pseudo_labels(teacher, xt1, n_samples, masking, eps_pl)
+    rec_t, kl_t, _ = elbo_grad_pass(model, opt.grad_flat, xt2, y, z if use_consensus else None, eps_s, 0.5, True)
+    reg, norms = eng.l2_reg(model.flat_params)
+    eng.l2_reg_add_grad(model.flat_params, opt.grad_flat, norms, reg_weight)  # (reg + reg) / 2
+    scale = allreduce_grads(opt.grad_flat)
+    ema = momentum is not None and teacher is not model
+    opt.fused_step(teacher if ema else None, ema_momentum=momentum if ema else 0.0, grad_scale=scale)
+    loss = 0.5 * (rec_s + model.beta * kl_s + rec_t + model.beta * kl_t) + reg_weight * reg[0]
+    return loss, y, z
+
+
+def distribution_alignment(y: torch.Tensor, source_distribution: torch.Tensor):
+    """fixmatch_trainer.py:77-84 with device-side counting (no torch.unique host sync):
+    target class frequencies of (y >= 0.5), ratio = source / target, rescale and clip."""
+    src = torch.as_tensor(source_distribution, dtype=torch.float32, device=y.device)
+    pos = (y >= 0.5).sum().to(torch.float32)
+    n = float(y.numel())
+    target = torch.stack([n - pos, pos]) / n
+    ratio = src / target
+    return torch.where(y < 0.5, y * ratio[0], y * ratio[1]).clip(0, 1), ratio

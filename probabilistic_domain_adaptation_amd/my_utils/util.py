@@ -1,0 +1,27 @@
+"""dice_score with the reference's signature (prob_utils/my_utils/util.py:17-44), reduced on the GPU (E1 kernel)."""
+import numpy as np
+import torch
+
+
+def dice_score(segmentation, groundtruth, threshold_seg=None, threshold_gt=None):
+    """2 * sum(gt * seg) / (sum(gt) + sum(seg) + 1e-7).  Accepts torch tensors (any device) or numpy arrays; the sums
+    run on the current ROCm device (no CPU fallback)."""
+    from ..engine import ParamLayout, PUNetEngine
+    if not torch.cuda.is_available():
+        raise RuntimeError("dice_score (MI355X build) needs a ROCm GPU: there is no CPU fallback")
+    seg = torch.as_tensor(np.asarray(segmentation) if not torch.is_tensor(segmentation) else segmentation)
+    gt = torch.as_tensor(np.asarray(groundtruth) if not torch.is_tensor(groundtruth) else groundtruth)
+    assert seg.shape == gt.shape, f"{seg.shape}, {gt.shape}"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    eng = _engine(dev)
+    return eng.dice_score(seg.to(dev, torch.float32), gt.to(dev, torch.float32), threshold_seg, threshold_gt)
+
+
+_ENG = {}
+
+
+def _engine(dev):
+    from ..engine import ParamLayout, PUNetEngine
+    if dev not in _ENG:
+        _ENG[dev] = PUNetEngine(ParamLayout(1, 1, [32, 32, 32, 32]), dev)
+    return _ENG[dev]

@@ -184,7 +184,8 @@ def test_pool(dev, B, H, W, C):
     assert rel_err(nchw(Y), y.detach()) < 1e-6
     prev = torch.randn(B, C, H, W, generator=g)
     DX = nhwc(prev)
-    L.call("punet_pool2x2_bwd", nhwc(dy).data_ptr(), X.data_ptr(), DX.data_ptr(), B, H, W, C, 1, S())
+    DY = nhwc(dy)
+    L.call("punet_pool2x2_bwd", DY.data_ptr(), X.data_ptr(), DX.data_ptr(), B, H, W, C, 1, S())
     torch.cuda.synchronize()
     assert rel_err(nchw(DX), prev + x.grad * (x.detach() > 0)) < 1e-6
 
@@ -203,7 +204,8 @@ def test_upsample(dev, B, H, W, C):
     torch.cuda.synchronize()
     assert (nchw(Y) - y.detach()).abs().max().item() < 2e-6
     DX = torch.empty(B, H, W, C, device=dev)
-    L.call("punet_upsample2x_bwd", nhwc(dy).data_ptr(), X.data_ptr(), DX.data_ptr(), B, H, W, C, S())
+    DY = nhwc(dy)
+    L.call("punet_upsample2x_bwd", DY.data_ptr(), X.data_ptr(), DX.data_ptr(), B, H, W, C, S())
     torch.cuda.synchronize()
     assert (nchw(DX) - x.grad * (x.detach() > 0)).abs().max().item() < 1e-5
 
@@ -245,7 +247,8 @@ def test_latent_head_and_kl(dev):
     assert abs(klo.item() - kl.item()) < 1e-5 * abs(kl.item()) + 1e-6
     dq = torch.empty(B, 2 * Ld, device=dev)
     dp = torch.empty(B, 2 * Ld, device=dev)
-    L.call("punet_latent_kl_bwd", mu.data_ptr(), MP.data_ptr(), EPS.data_ptr(), dz.cuda().data_ptr(), gscale * beta / B,
+    DZ = dz.cuda()
+    L.call("punet_latent_kl_bwd", mu.data_ptr(), MP.data_ptr(), EPS.data_ptr(), DZ.data_ptr(), gscale * beta / B,
            dq.data_ptr(), dp.data_ptr(), B, Ld, S())
     dw = torch.empty(1, 1, C, 2 * Ld, device=dev)
     db = torch.empty(2 * Ld, device=dev)
@@ -309,7 +312,8 @@ def test_fcomb_sampler(dev, CH, nmid, N, B, H, W):
     # K8 on the reference logits is bit-exact w.r.t. the same sigmoid rule
     y8 = torch.empty(B, 1, H, W, device=dev)
     c8 = torch.empty(B, 1, H, W, device=dev)
-    L.call("punet_consensus", logits.cuda().data_ptr(), N, B * H * W, 0.9, 0.1, 0, y8.data_ptr(), c8.data_ptr(), S())
+    LG = logits.cuda()
+    L.call("punet_consensus", LG.data_ptr(), N, B * H * W, 0.9, 0.1, 0, y8.data_ptr(), c8.data_ptr(), S())
     torch.cuda.synchronize()
     mism = (c8.cpu() != conf)
     near = (((s - 0.9).abs() < 1e-6) | ((s - 0.1).abs() < 1e-6)).any(0)
@@ -337,7 +341,8 @@ def test_dot_and_loss(dev):
     dl = torch.empty(B, 1, H, W, device=dev)
     ls = torch.empty(1, device=dev)
     ws = torch.empty(L.call("punet_loss_workspace_floats"), device=dev)
-    L.call("punet_bce_fwd_bwd", lg.data_ptr(), tgt.cuda().data_ptr(), cm.cuda().data_ptr(), gscale, dl.data_ptr(), ls.data_ptr(),
+    TG, CM = tgt.cuda(), cm.cuda()  # keep the device copies alive across the asynchronous launches
+    L.call("punet_bce_fwd_bwd", lg.data_ptr(), TG.data_ptr(), CM.data_ptr(), gscale, dl.data_ptr(), ls.data_ptr(),
            ws.data_ptr(), P, S())
     dz = torch.empty(B, H, W, CH, device=dev)
     dw3 = torch.empty(CH, device=dev)
@@ -352,7 +357,7 @@ def test_dot_and_loss(dev):
     assert rel_err(dw3.cpu(), w3.grad.reshape(-1)) < 1e-5
     assert rel_err(db3.cpu(), b3.grad) < 1e-5
     # no mask
-    L.call("punet_bce_fwd_bwd", lg.data_ptr(), tgt.cuda().data_ptr(), None, 1.0, None, ls.data_ptr(), ws.data_ptr(), P, S())
+    L.call("punet_bce_fwd_bwd", lg.data_ptr(), TG.data_ptr(), None, 1.0, None, ls.data_ptr(), ws.data_ptr(), P, S())
     torch.cuda.synchronize()
     ref = F.binary_cross_entropy_with_logits(logit.detach(), tgt, reduction="sum").item()
     assert abs(ls.item() - ref) < 1e-5 * ref

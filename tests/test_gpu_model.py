@@ -99,8 +99,9 @@ def test_training_path(golden_dir, dev, name, mode):
     y_soft = torch.from_numpy(fx[f"y_n{nlast}"])
     consm = None if mode == "none" else torch.from_numpy(fx[f"z_n{nlast}_{mode}"]).float()
     eps_s = _eps(1, B, 6, s2 + 100)[0]
+    taps = {}
     st = eng.elbo_forward(flat, eng.to_nhwc(x2), y_soft.to(dev), consm.to(dev) if consm is not None else None, eps_s.to(dev),
-                          "bce", 1.0, 1.0, True)
+                          "bce", 1.0, 1.0, True, taps)
     g = torch.full((lay.numel,), float("nan"), device=dev)
     eng.elbo_backward(flat, g, st, accumulate=False)
     reg, norms = eng.l2_reg(flat)
@@ -112,24 +113,34 @@ def test_training_path(golden_dir, dev, name, mode):
     np.testing.assert_allclose([loss, rec, kl, reg.item()], [sc[0], sc[1], sc[3], sc[4]], rtol=2e-4)
     np.testing.assert_allclose(st["muls_q"][:, :6].cpu().numpy(), fx[f"train_{mode}_post_mu"], atol=1e-4)
     assert np.abs(st["logits"].cpu().numpy() - fx[f"train_{mode}_recon"]).max() < LOGIT_TOL
-    # gradients: against the oracle's autograd (full tensors) and the reference digests
+    # gradients, tier 1 (tight, 5e-4 of each tensor's max): against the oracle's autograd on the full tensors, with the
+    # oracle's ReLUs gated by the GPU's own forward activations.  A pre-activation within fp32 rounding of 0 may
+    # resolve to either side of the ReLU on the two machines; that is not an error of the backward kernels, but it
+    # moves single gradient entries by O(1e-3) of the tensor max (observed: one such flip in uniform32_literal).
+    gates = {k[5:]: (v.t > 0).permute(0, 3, 1, 2).cpu() for k, v in taps.items() if k.startswith("conv:")}
+    assert len(gates) == len(lay.convs) - 3  # every conv but the two latent heads and the last fcomb layer
     P = O.to_torch(Pnp, requires_grad=True)
-    lo, _ = O.training_loss(P, cfg, x2, y_soft, consm, eps_s)
-    go = O.grads_of(lo, P)
+    O.RELU_GATES = gates
+    try:
+        lo, _ = O.training_loss(P, cfg, x2, y_soft, consm, eps_s)
+        go = O.grads_of(lo, P)
+    finally:
+        O.RELU_GATES = None
     gv = lay.views(g)
     bad = {}
     for k, ref in go.items():
         got = gv[k].cpu()
         assert torch.isfinite(got).all(), k
         e = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-8)
-        if e > 2e-3:
+        if e > 5e-4:
             bad[k] = e
     assert not bad, bad
+    # tier 2 (loose, covers a possible ReLU flip): norms against the digests of the REFERENCE's own gradients
     dig = fx[f"train_{mode}_grad_digest"]
     for row, (k, _) in zip(dig, go.items()):
         a = gv[k].contiguous().cpu().numpy().ravel()
         nrm = np.sqrt((a.astype(np.float64) ** 2).sum())
-        assert abs(nrm - row[0]) <= 2e-3 * row[0] + 1e-7, (k, nrm, row[0])
+        assert abs(nrm - row[0]) <= 5e-3 * row[0] + 1e-7, (k, nrm, row[0])
 
 
 def test_gradient_accumulation_and_scale(golden_dir, dev):
@@ -138,9 +149,9 @@ def test_gradient_accumulation_and_scale(golden_dir, dev):
     eps_s = _eps(1, B, 6, 77)[0].to(dev)
     X, Y = eng.to_nhwc(x2), y.to(dev)
     st = eng.elbo_forward(flat, X, Y, None, eps_s, "bce", 1.0, 1.0, True)
-    g1 = torch.empty(lay.numel, device=dev)
+    g1 = torch.zeros(lay.numel, device=dev)
     eng.elbo_backward(flat, g1, st, False)
-    g2 = torch.empty(lay.numel, device=dev)
+    g2 = torch.zeros(lay.numel, device=dev)
     st = eng.elbo_forward(flat, X, Y, None, eps_s, "bce", 1.0, 0.5, True)
     eng.elbo_backward(flat, g2, st, False)
     st = eng.elbo_forward(flat, X, Y, None, eps_s, "bce", 1.0, 0.5, True)
@@ -148,7 +159,7 @@ def test_gradient_accumulation_and_scale(golden_dir, dev):
     torch.cuda.synchronize()
     assert (g1 - g2).abs().max().item() <= 1e-5 * g1.abs().max().item()
     # run-to-run bit reproducibility (no float atomics)
-    g3 = torch.empty(lay.numel, device=dev)
+    g3 = torch.zeros(lay.numel, device=dev)
     st = eng.elbo_forward(flat, X, Y, None, eps_s, "bce", 1.0, 1.0, True)
     eng.elbo_backward(flat, g3, st, False)
     torch.cuda.synchronize()
