@@ -76,6 +76,7 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback for the product path.")
+    import torch  # noqa: F401  - first: loads PyTorch-ROCm's bundled HIP runtime, which libpunet_hip.so links against
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         try:

@@ -201,6 +201,9 @@ class PUNetEngine:
         _lib.load()
         self.ws = Workspace(self.device)
         self.prof = None  # when a list: (kind, algorithmic FLOPs, start event, end event) per 3x3 MFMA launch
+        tab, self.l2_ntensors = layout.l2_chunk_table()
+        self.l2_chunks = tab.to(self.device)
+        self.l2_nchunks = tab.shape[0]
 
     def _timed(self, kind, flops, name, *args):
         """Launch through the C ABI; with self.prof set, bracket the launch with HIP events on the launch stream."""
@@ -212,9 +215,6 @@ class PUNetEngine:
         e1.record()
         self.prof.append((kind, flops, e0, e1))
         return r
-        tab, self.l2_ntensors = layout.l2_chunk_table()
-        self.l2_chunks = tab.to(self.device)
-        self.l2_nchunks = tab.shape[0]
 
     # ---------------------------------------------------------------- helpers
     def _empty(self, *shape):
