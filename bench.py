@@ -44,10 +44,22 @@ def synth(B, H, W, seed, dev):
     return [t.contiguous().to(dev) for t in (x, x1, x2, y)]
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask, cgroup quota, and the GPU box's per-GPU share (16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return int(os.environ.get("PUNET_CPU_THREADS", min(n, 16)))
+
+
 def cpu_baseline(workload, n_samples, H, W, budget_s=12.0):
     """The CPU oracle (own restatement of the reference path, pinned by golden fixtures) on the host cores."""
     from oracle import punet_oracle as O
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(host_cores())
     cfg = O.PUNetConfig(1, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
     Pnp = O.synth_params(cfg.spec(), 1)
 
@@ -68,10 +80,10 @@ def cpu_baseline(workload, n_samples, H, W, budget_s=12.0):
 
     one(64, 64)  # warm-up (page-in, thread pools)
     times = []
-    while sum(times) < budget_s and len(times) < 3:
+    while sum(times) < budget_s and len(times) < 2:
         times.append(one(H, W))
     per = sum(times) / len(times)
-    return {"value": round(1.0 / per, 5), "unit": "patches/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": round(1.0 / per, 5), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{len(times)} x (batch 1, {H}x{W}, N={n_samples}) {workload} step of the CPU oracle "
                       f"(torch {torch.__version__} CPU fp32, {torch.get_num_threads()} threads), {per:.2f} s each"}
 
