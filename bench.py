@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--samples", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI; the default) or gloo (rehearsal on one GPU)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,11 +107,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    local = local % max(torch.cuda.device_count(), 1)  # gloo rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" == RCCL on ROCm
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" == RCCL on ROCm
+        else:
+            dist.init_process_group(a.backend)
 
     import __graft_entry__ as ge
     if rank == 0:

@@ -1,0 +1,88 @@
+"""GPU: data-parallel correctness with 2 ranks sharing the one GPU of the box (gloo carries the all-reduce; on the
+8-GPU node the same code path uses RCCL).  After one fused step the replicas are bit-identical and equal to a
+single-process emulation that averages the two shards' gradients."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+NF = [32, 64, 64, 96]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup_model(dev):
+    from oracle import punet_oracle as O
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
+    cfg = O.PUNetConfig(1, 1, NF, 6, 3, 1.0, True, False)
+    Pnp = O.synth_params(cfg.spec(), 4)
+    m = ProbabilisticUnet(1, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in Pnp.items()})
+    return m, FusedAdam(m, lr=1e-3)
+
+
+def _shard(rank):
+    from oracle import punet_oracle as O
+    x, x1, x2, y = O.synth_batch(2, 1, 32, 32, 30 + rank)
+    eps = torch.randn(1, 2, 6, generator=torch.Generator().manual_seed(40 + rank))
+    return x2, y, eps
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    m, opt = _setup_model(dev)
+    x2, y, eps = _shard(rank)
+    loss = FU.fused_supervised_step(m, opt, x2.to(dev), y.to(dev), None, eps)
+    torch.cuda.synchronize()
+    q.put((rank, m.flat_params.cpu().numpy(), float(loss)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_process_emulation():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1]), "replicas diverged"
+    # single-process emulation: mean of the two shards' gradients, then the same Adam kernel
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    dev = torch.device("cuda:0")
+    m, opt = _setup_model(dev)
+    eng = m.engine
+    gsum = torch.zeros_like(opt.grad_flat)
+    for r in range(2):
+        x2, y, eps = _shard(r)
+        g = torch.zeros_like(opt.grad_flat)
+        FU.elbo_grad_pass(m, g, x2.to(dev), y.to(dev), None, eps, 1.0, False)
+        reg, norms = eng.l2_reg(m.flat_params)
+        eng.l2_reg_add_grad(m.flat_params, g, norms, 1e-5)
+        gsum += g
+    opt.grad_flat.copy_(gsum)
+    opt.fused_step(None, grad_scale=0.5)
+    torch.cuda.synchronize()
+    assert np.array_equal(m.flat_params.cpu().numpy(), res[0][1])
