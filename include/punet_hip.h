@@ -45,6 +45,13 @@ int punet_conv_fwd(const float* x0, int c0, const float* x1, int c1, const float
 int punet_conv_dgrad(const float* dz, int cout, const float* w, int cin_total, int cin_off, int cin, float* dx,
                      const float* mask, int accumulate, int B, int H, int W, int ksize, void* stream);
 
+/* ---- K2 fast form: the dgrad's weight slab is first brought into forward-kernel orientation,
+ *      wt[k*k-1-t][cout][cin_total] = w[t][cin_total][cout] (once per step for all layers), after which the input gradient
+ *      is exactly the K1 kernel.  cin_total, cin_off, cin multiples of 4. */
+int punet_flip_transpose_weights(const float* w, float* wt, int cin, int cout, int ksize, void* stream);
+int punet_conv_dgrad_t(const float* dz, int cout, const float* wt, int cin_total, int cin_off, int cin, float* dx,
+                       const float* mask, int accumulate, int B, int H, int W, int ksize, void* stream);
+
 /* ---- K3: autograd weight + bias gradient of K1 (convolution_backward, weight/bias), fp32 MFMA, deterministic split-K.
  *      x has cs channels and fills rows [ci_off, ci_off+cs) of dw[k][k][cin_total][cout]; dbias may be NULL.
  *      dw/db (+)= scale * grad when accumulate != 0, else = scale * grad. */

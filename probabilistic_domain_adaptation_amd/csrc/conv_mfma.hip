@@ -238,6 +238,54 @@ extern "C" int punet_conv_fwd(const float* x0, int c0, const float* x1, int c1, 
     return ksize == 3 ? launch_conv<3, false>(a, (hipStream_t)stream) : launch_conv<1, false>(a, (hipStream_t)stream);
 }
 
+namespace {
+// wt[kk-1-t][co][ci] = w[t][ci][co]: the dgrad's weight slab in forward-kernel orientation (32x32 LDS-tiled transpose,
+// coalesced on both sides).  grid = (cout/32, cin/32, k*k), block = 32 x 8.
+__global__ __launch_bounds__(256) void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int cin,
+                                                             int cout, int kk) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z, co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = w + (size_t)t * cin * cout;
+    float* dst = wt + (size_t)(kk - 1 - t) * cin * cout;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        if (ci0 + r < cin && co0 + tx < cout) tile[r][tx] = src[(size_t)(ci0 + r) * cout + co0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        if (co0 + r < cout && ci0 + tx < cin) dst[(size_t)(co0 + r) * cin + ci0 + tx] = tile[tx][r];
+}
+}  // namespace
+
+extern "C" int punet_flip_transpose_weights(const float* w, float* wt, int cin, int cout, int ksize, void* stream) {
+    PUNET_CHECK_ARG(w && wt && cin > 0 && cout > 0 && (ksize == 1 || ksize == 3), "punet_flip_transpose_weights: bad args");
+    dim3 grid(ceil_div(cout, 32), ceil_div(cin, 32), ksize * ksize);
+    flip_transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(w, wt, cin, cout, ksize * ksize);
+    PUNET_LAUNCH_CHECK("flip_transpose");
+    return PUNET_OK;
+}
+
+// dgrad with a weight slab prepared by punet_flip_transpose_weights (wt[k][k][cout][cin_total]): runs the forward kernel.
+extern "C" int punet_conv_dgrad_t(const float* dz, int cout, const float* wt, int cin_total, int cin_off, int cin,
+                                  float* dx, const float* mask, int accumulate, int B, int H, int W, int ksize,
+                                  void* stream) {
+    PUNET_CHECK_ARG(ksize == 1 || ksize == 3, "punet_conv_dgrad_t: ksize must be 1 or 3 (got %d)", ksize);
+    PUNET_CHECK_ARG(dz && wt && dx, "punet_conv_dgrad_t: null pointer");
+    PUNET_CHECK_ARG(cout > 0 && cout % CK == 0, "punet_conv_dgrad_t: cout must be a multiple of %d (got %d)", CK, cout);
+    PUNET_CHECK_ARG(cin > 0 && cin % 4 == 0 && cin_off >= 0 && cin_off % 4 == 0 && cin_off + cin <= cin_total &&
+                        cin_total % 4 == 0,
+                    "punet_conv_dgrad_t: bad channel window off=%d n=%d total=%d (all must be multiples of 4)", cin_off, cin,
+                    cin_total);
+    ConvArgs a{};
+    a.x0 = dz; a.x1 = nullptr; a.c0 = cout; a.c1 = 0;
+    a.w = wt + cin_off; a.w_tap_stride = (long)cin_total * cout; a.w_k_stride = cin_total; a.w_n_stride = 1; a.flip = 0;
+    a.bias = nullptr; a.bias_img_stride = 0;
+    a.y = dx; a.n_total = cin; a.mask = mask; a.accumulate = accumulate; a.relu = 0;
+    a.B = B; a.H = H; a.W = W;
+    return ksize == 3 ? launch_conv<3, false>(a, (hipStream_t)stream) : launch_conv<1, false>(a, (hipStream_t)stream);
+}
+
 extern "C" int punet_conv_dgrad(const float* dz, int cout, const float* w, int cin_total, int cin_off, int cin,
                                 float* dx, const float* mask, int accumulate, int B, int H, int W, int ksize,
                                 void* stream) {

@@ -200,16 +200,31 @@ __global__ void upsample2x_bwd_kernel(const float4* __restrict__ dy, const float
 // partial[b][s][c] = sum over the pixels of slice s of x[b][p][c]
 __global__ __launch_bounds__(256) void chan_sum_partial_kernel(const float4* __restrict__ x, float4* __restrict__ partial,
                                                                int P, int C4, int S) {
+    // thread = (pixel lane pl, channel quad c); the 256 / C4 pixel lanes of a block are combined in lane order via LDS
+    extern __shared__ __attribute__((aligned(16))) float4 sh4[];  // [ppl][C4]
     const int s = blockIdx.x, b = blockIdx.y;
     const int per = (P + S - 1) / S;
     const int p0 = s * per, p1 = min(P, p0 + per);
-    for (int c = threadIdx.x; c < C4; c += blockDim.x) {
+    const int ppl = C4 >= 256 ? 1 : 256 / C4;
+    for (int c0 = 0; c0 < C4; c0 += 256) {
+        const int c = c0 + (int)threadIdx.x % min(C4, 256), pl = (int)threadIdx.x / min(C4, 256);
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int p = p0; p < p1; ++p) {
-            const float4 v = x[((size_t)b * P + p) * C4 + c];
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        if (c < C4 && pl < ppl)
+            for (int p = p0 + pl; p < p1; p += ppl) {
+                const float4 v = x[((size_t)b * P + p) * C4 + c];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+        __syncthreads();
+        if (c < C4 && pl < ppl) sh4[pl * min(C4, 256) + (c - c0)] = a;
+        __syncthreads();
+        if (pl == 0 && c < C4) {
+            float4 t = sh4[c - c0];
+            for (int k = 1; k < ppl; ++k) {
+                const float4 v = sh4[k * min(C4, 256) + (c - c0)];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            partial[((size_t)b * S + s) * C4 + c] = t;
         }
-        partial[((size_t)b * S + s) * C4 + c] = a;
     }
 }
 
@@ -664,15 +679,19 @@ extern "C" int punet_upsample2x_bwd(const float* dy, const float* xmask, float* 
     return PUNET_OK;
 }
 
-static int chan_slices(int P) { return P < 64 ? P : 64; }
+static int chan_slices(int P, int C) {
+    const int c4 = C / 4, ppl = c4 >= 256 ? 1 : 256 / c4;
+    int s = (P + ppl * 16 - 1) / (ppl * 16);
+    return s < 1 ? 1 : (s > 256 ? 256 : s);
+}
 
-extern "C" size_t punet_chan_sum_workspace_floats(int B, int P, int C) { return (size_t)B * chan_slices(P) * C; }
+extern "C" size_t punet_chan_sum_workspace_floats(int B, int P, int C) { return (size_t)B * chan_slices(P, C) * C; }
 
 extern "C" int punet_chan_sum(const float* x, float* out, float* workspace, int B, int P, int C, float scale,
                               void* stream) {
     PUNET_CHECK_ARG(x && out && workspace && C % 4 == 0 && B > 0 && P > 0, "punet_chan_sum: bad args (C=%d)", C);
-    const int S = chan_slices(P);
-    chan_sum_partial_kernel<<<dim3(S, B), 256, 0, STREAM>>>((const float4*)x, (float4*)workspace, P, C / 4, S);
+    const int S = chan_slices(P, C);
+    chan_sum_partial_kernel<<<dim3(S, B), 256, 256 * sizeof(float4), STREAM>>>((const float4*)x, (float4*)workspace, P, C / 4, S);
     PUNET_LAUNCH_CHECK("chan_sum_partial");
     chan_sum_finalize_kernel<<<B, 256, 0, STREAM>>>(workspace, out, S, C, scale);
     PUNET_LAUNCH_CHECK("chan_sum_finalize");

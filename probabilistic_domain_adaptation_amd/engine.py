@@ -201,6 +201,7 @@ class PUNetEngine:
         _lib.load()
         self.ws = Workspace(self.device)
         self.prof = None  # when a list: (kind, algorithmic FLOPs, start event, end event) per 3x3 MFMA launch
+        self.wT = None  # flipped + transposed weight slabs for the dgrad pass (prepare_dgrad_weights)
         tab, self.l2_ntensors = layout.l2_chunk_table()
         self.l2_chunks = tab.to(self.device)
         self.l2_nchunks = tab.shape[0]
@@ -438,6 +439,27 @@ class PUNetEngine:
                     dz.data_ptr(), c.cout, dw, c.cin, ci_off, db if with_bias else None, ws.data_ptr(), ns, B, H, W, c.k,
                     int(accumulate), 1.0, _stream())
 
+    def prepare_dgrad_weights(self, flat):
+        """Bring every conv weight slab into forward-kernel orientation for the input-gradient pass
+        (wt[k*k-1-t][cout][cin] = w[t][cin][cout]); ~0.1 ms per step, after which dgrad IS the forward kernel."""
+        if self.wT is None or self.wT.numel() != flat.numel():
+            self.wT = torch.empty_like(flat)
+        for c in self.L.convs.values():
+            if c.cin > 4 and c.cin % 4 == 0 and c.cout % 8 == 0:
+                _lib.call("punet_flip_transpose_weights", self._wptr(flat, c), self.wT.data_ptr() + 4 * c.w_off, c.cin, c.cout,
+                          c.k, _stream())
+
+    def _dgrad(self, flat, c: ConvP, dz, cin_off: int, cin: int, dx, mask_ptr, acc: int, B: int, H: int, W: int):
+        """dx[..., cin_off : cin_off + cin] of conv c given dz (epilogue: ReLU gate by `mask`, accumulate)."""
+        flops = 2.0 * B * H * W * cin * c.cout * c.k * c.k
+        if c.cin % 4 == 0:
+            self._timed(f"conv{c.k}x{c.k}_dgrad", flops, "punet_conv_dgrad_t", dz.data_ptr(), c.cout,
+                        self.wT.data_ptr() + 4 * c.w_off, c.cin, cin_off, cin, dx.data_ptr(), mask_ptr, acc, B, H, W, c.k,
+                        _stream())
+        else:  # Fcomb's first layer (cin = C + latent_dim is not a multiple of 4): transposed-read variant
+            self._timed(f"conv{c.k}x{c.k}_dgrad", flops, "punet_conv_dgrad", dz.data_ptr(), c.cout, self._wptr(flat, c), c.cin,
+                        cin_off, cin, dx.data_ptr(), mask_ptr, acc, B, H, W, c.k, _stream())
+
     def _grad_into(self, gm: dict, a: Act):
         """(buffer, accumulate flag) for the gradient of activation a."""
         g = gm.get(id(a))
@@ -461,10 +483,7 @@ class PUNetEngine:
                         continue
                     if src.needs_grad:
                         g, acc = self._grad_into(gm, src)
-                        self._timed(f"conv{c.k}x{c.k}_dgrad", 2.0 * src.B * src.H * src.W * src.C * c.cout * c.k * c.k,
-                                    "punet_conv_dgrad", dz.data_ptr(), c.cout, self._wptr(flat, c), c.cin, off, src.C,
-                                    g.data_ptr(), src.ptr if src.relu_out else None, acc, src.B, src.H, src.W, c.k,
-                                    _stream())
+                        self._dgrad(flat, c, dz, off, src.C, g, src.ptr if src.relu_out else None, acc, src.B, src.H, src.W)
                     off += src.C
             elif op[0] == "pool":
                 _, x, y = op
@@ -488,6 +507,7 @@ class PUNetEngine:
         Ld, CH = L.latent_dim, L.nf[0]
         acc = int(accumulate)
         P = B * H * W
+        self.prepare_dgrad_weights(flat)
         c1, c3 = L.convs["fcomb.layers.0"], L.convs["fcomb.last_layer"]
         hs: List[Act] = st["hs"]
         feat: Act = st["feat"]
@@ -502,8 +522,7 @@ class PUNetEngine:
             xin = hs[k]
             self._wgrad(gflat, c, xin, 0, dz_h, True, accumulate)
             dprev = torch.empty_like(xin.t)
-            _lib.call("punet_conv_dgrad", dz_h.data_ptr(), c.cout, self._wptr(flat, c), c.cin, 0, xin.C, dprev.data_ptr(),
-                      xin.ptr, 0, B, H, W, 1, _stream())
+            self._dgrad(flat, c, dz_h, 0, xin.C, dprev, xin.ptr, 0, B, H, W)
             dz_h = dprev
         # first layer: feature rows by wgrad (+ bias), z rows and dz from the per-image column sums
         self._wgrad(gflat, c1, feat, 0, dz_h, True, accumulate)
@@ -515,8 +534,7 @@ class PUNetEngine:
                   dz.data_ptr(), B, Ld, CH, acc, _stream())
         gm_u = {}
         dfeat, _ = self._grad_into(gm_u, feat)
-        _lib.call("punet_conv_dgrad", dz_h.data_ptr(), CH, self._wptr(flat, c1), c1.cin, 0, CH, dfeat.data_ptr(), feat.ptr, 0,
-                  B, H, W, 1, _stream())
+        self._dgrad(flat, c1, dz_h, 0, CH, dfeat, feat.ptr, 0, B, H, W)
         del dz_h
         tq, tp, tu = st["tapes"]
         self._backward_tape(flat, gflat, tu, gm_u, accumulate)
