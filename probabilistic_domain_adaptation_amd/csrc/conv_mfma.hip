@@ -4,7 +4,7 @@
 //   prob_utils/my_models/unet_blocks.py:19-24, probabilistic_unet.py:56-61 (3x3 stacks),
 //   probabilistic_unet.py:168-173 (Fcomb 1x1 stack), and their autograd input-gradients
 //   (convolution_backward) - the dgrad form is the same contraction with the tap order
-//   flipped and the weight slab read transposed.
+//   flipped and the weight slab transposed (prepared once per step by punet_flip_transpose_weights).
 //
 // Formulation: implicit GEMM  Out[pixel][n] = sum_{tap, k} In[pixel + tap][k] * Wt[tap][k][n]
 //   M = 32 consecutive pixels of one image row (one MFMA row block), N = output channels, K = input
@@ -14,7 +14,11 @@
 // Per K chunk of 8 channels the workgroup stages the (8+2)x(32+2) halo tile [pixel][8+1] (pad -> the 32
 //   lanes of an A read hit 32 distinct banks) and the weight slab [tap][8][64] in LDS (30.6 KB), with
 //   the next chunk's global loads issued before the MFMA loop (register prefetch, one barrier pair
-//   per chunk).  3-4 workgroups are resident per CU so that staging of one overlaps MFMA of another.
+//   per chunk).  3 workgroups are resident per CU so that staging of one overlaps MFMA of another.
+// Persistent: the grid is ONE residency round (3 workgroups x 256 CUs); each workgroup strides over the
+//   (spatial tile, channel tile) list and the first chunk of its next tile is prefetched before the
+//   epilogue of the current one, so neither the prologue load latency nor the store tail idles the
+//   matrix pipe (this was worth ~15 % on the 64-channel layers, which have only 8 chunks per tile).
 // The channel concat of the U-Net up-blocks (unet_blocks.py:56, [up, bridge]) is never materialised:
 //   the K loop walks source 0 then source 1.
 // Epilogue (registers): + bias (per channel, or per image and channel: Fcomb's folded z term),
@@ -40,9 +44,15 @@ struct ConvArgs {
     const float* mask;
     int accumulate, relu;
     int B, H, W;
+    int ntiles;  // spatial tiles x channel tiles
 };
 
 constexpr int TH = 8, TW = 32, TN = 64, CK = 8;
+constexpr int CONV_WG_PER_CU = 3, NUM_CU = 256;
+
+struct TileInfo {
+    int b, ty0, tx0, n0;
+};
 
 template <int KS, bool TRANSPOSED>
 __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
@@ -62,29 +72,37 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
 
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
-    int sid = blockIdx.x;
-    const int txi = sid % tiles_x;
-    sid /= tiles_x;
-    const int tyi = sid % tiles_y;
-    const int b = sid / tiles_y;
-    const int ty0 = tyi * TH, tx0 = txi * TW;
-    const int n0 = blockIdx.y * TN;
+    const int ntn = (a.n_total + TN - 1) / TN;
     const int N = a.n_total;
     const int K = a.c0 + a.c1;
     const int nchunks = K / CK;
 
+    auto decode = [&](int tile) {
+        TileInfo t;
+        t.n0 = (tile % ntn) * TN;
+        int sid = tile / ntn;
+        t.tx0 = (sid % tiles_x) * TW;
+        sid /= tiles_x;
+        t.ty0 = (sid % tiles_y) * TH;
+        t.b = sid / tiles_y;
+        return t;
+    };
+
     f32x16 acc[2][2];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.f;
+    };
+    zero_acc();
 
     float4 rx[XITER];
     float4 rw[WITER];
 
-    auto prefetch = [&](int ch) {
+    auto prefetch = [&](const TileInfo& ti, int ch) {
         const int kbase = ch * CK;
         const float* src;
         int cs, coff;
@@ -100,9 +118,9 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
             if (u < XUNITS) {
                 const int q = u % (CK / 4), pix = u / (CK / 4);
                 const int py = pix / HTW, px = pix % HTW;
-                const int gy = ty0 + py - PAD, gx = tx0 + px - PAD;
+                const int gy = ti.ty0 + py - PAD, gx = ti.tx0 + px - PAD;
                 if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                    v = *reinterpret_cast<const float4*>(src + ((size_t)(b * a.H + gy) * a.W + gx) * cs + coff + q * 4);
+                    v = *reinterpret_cast<const float4*>(src + ((size_t)(ti.b * a.H + gy) * a.W + gx) * cs + coff + q * 4);
             }
             rx[it] = v;
         }
@@ -113,7 +131,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
             if (u < WUNITS) {
                 if (!TRANSPOSED) {
                     const int n4 = u % (TN / 4), k = (u / (TN / 4)) % CK, t = u / ((TN / 4) * CK);
-                    const int n = n0 + n4 * 4;
+                    const int n = ti.n0 + n4 * 4;
                     const int tt = a.flip ? (KK - 1 - t) : t;
                     if (n < N)
                         v = *reinterpret_cast<const float4*>(a.w + (size_t)tt * a.w_tap_stride +
@@ -121,9 +139,9 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
                 } else {
                     const int k4 = u % (CK / 4), n = (u / (CK / 4)) % TN, t = u / ((CK / 4) * TN);
                     const int tt = a.flip ? (KK - 1 - t) : t;
-                    if (n0 + n < N)
+                    if (ti.n0 + n < N)
                         v = *reinterpret_cast<const float4*>(a.w + (size_t)tt * a.w_tap_stride +
-                                                             (size_t)(n0 + n) * a.w_n_stride + kbase + k4 * 4);
+                                                             (size_t)(ti.n0 + n) * a.w_n_stride + kbase + k4 * 4);
                 }
             }
             rw[it] = v;
@@ -156,17 +174,55 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
         }
     };
 
+    auto epilogue = [&](const TileInfo& ti) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int n = ti.n0 + nb * 32 + l31;
+            if (n >= N) continue;
+            float bv = 0.f;
+            if (a.bias) bv = a.bias[(size_t)ti.b * a.bias_img_stride + n];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int gy = ti.ty0 + 2 * wave + m;
+                if (gy >= a.H) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gx = ti.tx0 + mfma32_row(r, half);
+                    if (gx >= a.W) continue;
+                    const size_t idx = ((size_t)(ti.b * a.H + gy) * a.W + gx) * N + n;
+                    float v = acc[m][nb][r] + bv;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (a.mask) v = (a.mask[idx] > 0.f) ? v : 0.f;
+                    if (a.accumulate) v += a.y[idx];
+                    a.y[idx] = v;
+                }
+            }
+        }
+    };
+
     // lane-constant LDS bases: A = sX[((2*wave + m + ky) * HTW + l31 + kx) * PST + 2*s + half]
     //                          B = sW[(t * CK + 2*s + half) * TN + nb * 32 + l31]
     const float* aBase = &sX[((2 * wave) * HTW + l31) * PST + half];
     const float* bBase = &sW[half * TN + l31];
 
-    prefetch(0);
-    for (int ch = 0; ch < nchunks; ++ch) {
+    int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    int ch = 0;
+    TileInfo ti = decode(tile);
+    prefetch(ti, 0);
+    while (true) {
         __syncthreads();
         commit();
         __syncthreads();
-        if (ch + 1 < nchunks) prefetch(ch + 1);
+        int nch = ch + 1, ntile = tile;
+        TileInfo nti = ti;
+        if (nch == nchunks) {
+            nch = 0;
+            ntile = tile + (int)gridDim.x;
+            if (ntile < a.ntiles) nti = decode(ntile);
+        }
+        const bool has_next = ntile < a.ntiles;
+        if (has_next) prefetch(nti, nch);
 #pragma unroll
         for (int t = 0; t < KK; ++t) {
             const int ky = t / KS, kx = t % KS;
@@ -182,40 +238,42 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
             }
         }
-    }
-
-    // epilogue
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int n = n0 + nb * 32 + l31;
-        if (n >= N) continue;
-        float bv = 0.f;
-        if (a.bias) bv = a.bias[(size_t)b * a.bias_img_stride + n];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int gy = ty0 + 2 * wave + m;
-            if (gy >= a.H) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gx = tx0 + mfma32_row(r, half);
-                if (gx >= a.W) continue;
-                const size_t idx = ((size_t)(b * a.H + gy) * a.W + gx) * N + n;
-                float v = acc[m][nb][r] + bv;
-                if (a.relu) v = fmaxf(v, 0.f);
-                if (a.mask) v = (a.mask[idx] > 0.f) ? v : 0.f;
-                if (a.accumulate) v += a.y[idx];
-                a.y[idx] = v;
-            }
+        if (ch == nchunks - 1) {
+            epilogue(ti);
+            zero_acc();
         }
+        if (!has_next) break;
+        tile = ntile;
+        ch = nch;
+        ti = nti;
     }
 }
 
 template <int KS, bool TR>
-int launch_conv(const ConvArgs& a, hipStream_t stream) {
-    dim3 grid(a.B * ceil_div(a.H, TH) * ceil_div(a.W, TW), ceil_div(a.n_total, TN));
+int launch_conv(ConvArgs& a, hipStream_t stream) {
+    a.ntiles = a.B * ceil_div(a.H, TH) * ceil_div(a.W, TW) * ceil_div(a.n_total, TN);
+    int grid = a.ntiles < CONV_WG_PER_CU * NUM_CU ? a.ntiles : CONV_WG_PER_CU * NUM_CU;
     conv_mfma_kernel<KS, TR><<<grid, 256, 0, stream>>>(a);
     PUNET_LAUNCH_CHECK("conv_mfma");
     return PUNET_OK;
+}
+
+// wt[kk-1-t][co][ci] = w[t][ci][co]: the dgrad's weight slab in forward-kernel orientation (32x32 LDS-tiled transpose,
+// coalesced on both sides).  grid = (cout/32, cin/32, k*k), block = 32 x 8.
+__global__ __launch_bounds__(256) void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int cin,
+                                                             int cout, int kk) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z, co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = w + (size_t)t * cin * cout;
+    float* dst = wt + (size_t)(kk - 1 - t) * cin * cout;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        if (ci0 + r < cin && co0 + tx < cout) tile[r][tx] = src[(size_t)(ci0 + r) * cout + co0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        if (co0 + r < cout && ci0 + tx < cin) dst[(size_t)(co0 + r) * cin + ci0 + tx] = tile[tx][r];
 }
 
 }  // namespace
@@ -237,26 +295,6 @@ extern "C" int punet_conv_fwd(const float* x0, int c0, const float* x1, int c1, 
     a.B = B; a.H = H; a.W = W;
     return ksize == 3 ? launch_conv<3, false>(a, (hipStream_t)stream) : launch_conv<1, false>(a, (hipStream_t)stream);
 }
-
-namespace {
-// wt[kk-1-t][co][ci] = w[t][ci][co]: the dgrad's weight slab in forward-kernel orientation (32x32 LDS-tiled transpose,
-// coalesced on both sides).  grid = (cout/32, cin/32, k*k), block = 32 x 8.
-__global__ __launch_bounds__(256) void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int cin,
-                                                             int cout, int kk) {
-    __shared__ float tile[32][33];
-    const int t = blockIdx.z, co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const float* src = w + (size_t)t * cin * cout;
-    float* dst = wt + (size_t)(kk - 1 - t) * cin * cout;
-#pragma unroll
-    for (int r = ty; r < 32; r += 8)
-        if (ci0 + r < cin && co0 + tx < cout) tile[r][tx] = src[(size_t)(ci0 + r) * cout + co0 + tx];
-    __syncthreads();
-#pragma unroll
-    for (int r = ty; r < 32; r += 8)
-        if (co0 + r < cout && ci0 + tx < cin) dst[(size_t)(co0 + r) * cin + ci0 + tx] = tile[tx][r];
-}
-}  // namespace
 
 extern "C" int punet_flip_transpose_weights(const float* w, float* wt, int cin, int cout, int ksize, void* stream) {
     PUNET_CHECK_ARG(w && wt && cin > 0 && cout > 0 && (ksize == 1 || ksize == 3), "punet_flip_transpose_weights: bad args");

@@ -30,9 +30,46 @@ struct WgradArgs {
     int B, H, W, nslices;
 };
 
-template <int KS>
-__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
+// MFMA work of one staged pixel tile for taps [T0, T0 + NT): k-step s, half h takes pixel q = 2s + h (row q/32, col q%32)
+template <int KS, int T0, int NT>
+__device__ __forceinline__ void wgrad_tile_mfma(f32x16 (&acc)[5], float& bsum, const float* aBase, const float* bBase) {
+    constexpr int HTW = WTW + KS - 1;
+#pragma unroll
+    for (int s = 0; s < WTH * WTW / 2; ++s) {
+        const int row = (2 * s) / WTW, col = (2 * s) % WTW;
+        const float bv = bBase[(2 * s) * WC];
+        bsum += bv;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int t = T0 + tt, ky = t / KS, kx = t % KS;
+            const float av = aBase[((row + ky) * HTW + col + kx) * WC];
+            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tt], 0, 0, 0);
+        }
+    }
+}
+
+template <int KS, int T0, int NT>
+__device__ __forceinline__ void wgrad_store(const f32x16 (&acc)[5], const WgradArgs& a, int slice, int ci_base, int co,
+                                            int half) {
     constexpr int KK = KS * KS;
+    if (co >= a.cout) return;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci_base + mfma32_row(r, half);
+            if (ci < a.cs) a.partial[(((size_t)slice * KK + T0 + tt) * a.cs + ci) * a.cout + co] = acc[tt][r];
+        }
+}
+
+// 3x3: 8 waves = 4 (ci block, co block) pairs x 2 tap groups (taps 0-4 | 5-8): each SIMD hosts one wave of each group,
+// so the nine taps of a pair are balanced per SIMD, every wave holds <= 5 accumulator tiles (80 VGPRs) and 4 waves per
+// SIMD (2 workgroups per CU) hide each other's LDS latencies.  1x1: 4 waves, one tap.
+template <int KS>
+__global__ __launch_bounds__(KS == 3 ? 512 : 256, KS == 3 ? 4 : 2) void wgrad_mfma_kernel(WgradArgs a) {
+    constexpr int NT_THREADS = KS == 3 ? 512 : 256;
+    constexpr int KK = KS * KS;
+    constexpr int TSPLIT = KS == 3 ? 5 : 1;
     constexpr int PAD = KS / 2;
     constexpr int HTH = WTH + KS - 1, HTW = WTW + KS - 1;
     constexpr int XUNITS = HTH * HTW * (WC / 4);
@@ -43,7 +80,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
-    const int cib = wave >> 1, cob = wave & 1;
+    const int pair = wave & 3, group = wave >> 2;
+    const int cib = pair >> 1, cob = pair & 1;
 
     const int co_tiles = (a.cout + WC - 1) / WC;
     const int ci_tile = blockIdx.y / co_tiles, co_tile = blockIdx.y % co_tiles;
@@ -53,9 +91,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     const int tiles_x = (a.W + WTW - 1) / WTW, tiles_y = (a.H + WTH - 1) / WTH;
     const int ntiles = a.B * tiles_x * tiles_y;
 
-    f32x16 acc[KK];
+    f32x16 acc[5];
 #pragma unroll
-    for (int t = 0; t < KK; ++t)
+    for (int t = 0; t < 5; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
@@ -72,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
         const int ty0 = tyi * WTH, tx0 = txi * WTW;
 
         __syncthreads();
-        for (int u = tid; u < XUNITS; u += 256) {
+        for (int u = tid; u < XUNITS; u += NT_THREADS) {
             const int c4 = u % (WC / 4), pix = u / (WC / 4);
             const int py = pix / HTW, px = pix % HTW;
             const int gy = ty0 + py - PAD, gx = tx0 + px - PAD;
@@ -82,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
                 v = *reinterpret_cast<const float4*>(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * a.cs + c);
             *reinterpret_cast<float4*>(&sX[pix * WC + c4 * 4]) = v;
         }
-        for (int u = tid; u < DUNITS; u += 256) {
+        for (int u = tid; u < DUNITS; u += NT_THREADS) {
             const int c4 = u % (WC / 4), pix = u / (WC / 4);
             const int py = pix / WTW, px = pix % WTW;
             const int gy = ty0 + py, gx = tx0 + px;
@@ -94,34 +132,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
         }
         __syncthreads();
 
-        // k-step s: half h takes pixel q = 2s + h of the tile (row q/32, col q%32)
-#pragma unroll
-        for (int s = 0; s < WTH * WTW / 2; ++s) {
-            const int row = (2 * s) / WTW, col = (2 * s) % WTW;
-            const float bv = bBase[(2 * s) * WC];
-            bsum += bv;
-#pragma unroll
-            for (int t = 0; t < KK; ++t) {
-                const int ky = t / KS, kx = t % KS;
-                const float av = aBase[((row + ky) * HTW + col + kx) * WC];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-            }
-        }
+        if (group == 0)
+            wgrad_tile_mfma<KS, 0, TSPLIT>(acc, bsum, aBase, bBase);
+        else if (KK > TSPLIT)
+            wgrad_tile_mfma<KS, TSPLIT, (KK > TSPLIT ? KK - TSPLIT : 1)>(acc, bsum, aBase, bBase);
     }
 
     // partial slab [slice][tap][cs][cout]
     const int co = co0 + cob * 32 + l31;
-    if (co < a.cout) {
-#pragma unroll
-        for (int t = 0; t < KK; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ci = ci0 + cib * 32 + mfma32_row(r, half);
-                if (ci < a.cs) a.partial[(((size_t)slice * KK + t) * a.cs + ci) * a.cout + co] = acc[t][r];
-            }
-        }
-    }
-    if (a.bias_partial && ci_tile == 0 && cib == 0) {
+    if (group == 0)
+        wgrad_store<KS, 0, TSPLIT>(acc, a, slice, ci0 + cib * 32, co, half);
+    else if (KK > TSPLIT)
+        wgrad_store<KS, TSPLIT, (KK > TSPLIT ? KK - TSPLIT : 1)>(acc, a, slice, ci0 + cib * 32, co, half);
+    if (a.bias_partial && ci_tile == 0 && cib == 0 && group == 0) {
         const float tot = bsum + __shfl_xor(bsum, 32);
         if (half == 0 && co < a.cout) a.bias_partial[(size_t)slice * a.cout + co] = tot;
     }
@@ -161,7 +184,7 @@ extern "C" int punet_conv_wgrad(const float* x, int cs, const float* dz, int cou
     a.B = B; a.H = H; a.W = W; a.nslices = nslices;
     dim3 grid(nslices, ceil_div(cs, WC) * ceil_div(cout, WC));
     if (ksize == 3)
-        wgrad_mfma_kernel<3><<<grid, 256, 0, stream>>>(a);
+        wgrad_mfma_kernel<3><<<grid, 512, 0, stream>>>(a);
     else
         wgrad_mfma_kernel<1><<<grid, 256, 0, stream>>>(a);
     PUNET_LAUNCH_CHECK("wgrad_mfma");
