@@ -200,10 +200,22 @@ def main():
             kernels = {k: {"launches": v[2], "avg_ms": round(1e3 * v[1] / v[2], 4), "tflops": round(v[0] / v[1] / 1e12, 2),
                            "share_of_step": round(v[1] / dt, 3)} for k, v in agg.items()}
             k3 = agg.get("conv3x3_fwd")
+            traffic, traffic_note = None, "not collected"
+            try:  # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.py)
+                if a.workload == "mean_teacher" and (B, H, W, N) == (4, 512, 512, 8):
+                    pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")))
+                    traffic = round(pm["kernels"]["conv_mfma_kernel<3, false>"]["hbm_bytes_per_launch"])
+                    traffic_note = ("bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE in separate "
+                                    "passes of this same workload (profiles/r01/pmc_hbm_traffic.json); the kernel also serves the "
+                                    "dgrad launches, so this is the mean over forward and dgrad launches; FETCH_SIZE counts "
+                                    "Infinity-Cache refills of the per-chunk 32-B re-reads")
+            except Exception:
+                pass
             if k3:
                 ach = k3[0] / k3[1] / 1e12
                 out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                   "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                                   "traffic_note": traffic_note,
                                    "kernel": "conv_mfma_kernel<3,false> (3x3 NHWC direct conv forward, fp32 MFMA)",
                                    "flops_per_launch_avg": k3[0] / k3[2], "avg_launch_ms": round(1e3 * k3[1] / k3[2], 4),
                                    "peak_note": "fp32-input MFMA dense peak (parity mode); bf16 MFMA is not used"}

@@ -175,6 +175,36 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
     };
 
     auto epilogue = [&](const TileInfo& ti) {
+        if (ti.ty0 + TH <= a.H && ti.tx0 + TW <= a.W && ti.n0 + TN <= N) {
+            // interior tile: straight-line code, the gate / accumulate loads of a 32x32 block are issued as one batch
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int n = ti.n0 + nb * 32 + l31;
+                const float bv = a.bias ? a.bias[(size_t)ti.b * a.bias_img_stride + n] : 0.f;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const size_t base = ((size_t)(ti.b * a.H + ti.ty0 + 2 * wave + m) * a.W + ti.tx0) * N + n;
+                    float gate[16], old[16];
+                    if (a.mask) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) gate[r] = a.mask[base + (size_t)mfma32_row(r, half) * N];
+                    }
+                    if (a.accumulate) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) old[r] = a.y[base + (size_t)mfma32_row(r, half) * N];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[m][nb][r] + bv;
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        if (a.mask) v = gate[r] > 0.f ? v : 0.f;
+                        if (a.accumulate) v += old[r];
+                        a.y[base + (size_t)mfma32_row(r, half) * N] = v;
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             const int n = ti.n0 + nb * 32 + l31;

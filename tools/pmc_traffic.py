@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter CSVs (two separate passes, as
+/opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes) into per-launch HBM bytes per kernel.
+
+Units/corrections from the guide: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the
+bytes of a wide coalesced (16 B/lane) streaming read -> doubled here (all staging loads of the MFMA kernels are float4);
+WRITE_SIZE is exact for 16 B/lane stores (the conv epilogue stores 4 B/lane in 128-B runs: uncalibrated, taken as is).
+
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def load(path, counter):
+    agg = defaultdict(lambda: [0.0, 0])
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            a = agg[row["Kernel_Name"]]
+            a[0] += float(row["Counter_Value"])
+            a[1] += 1
+    return agg
+
+
+def short(name):
+    for key in ("conv_mfma_kernel<3, false>", "conv_mfma_kernel<3, true>", "conv_mfma_kernel<1, false>",
+                "conv_mfma_kernel<1, true>", "wgrad_mfma_kernel<3>", "wgrad_mfma_kernel<1>", "fcomb_sampler_kernel<2>"):
+        if key in name:
+            return key
+    return name.split("(")[0].split("::")[-1][:60]
+
+
+def main():
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in set(fetch) | set(write):
+        f, w = fetch.get(k, [0.0, 0]), write.get(k, [0.0, 0])
+        n = max(f[1], w[1], 1)
+        out[short(k)] = {"launches": n, "fetch_bytes_per_launch": 2.0 * 1024.0 * f[0] / max(f[1], 1),
+                         "write_bytes_per_launch": 1024.0 * w[0] / max(w[1], 1)}
+        out[short(k)]["hbm_bytes_per_launch"] = out[short(k)]["fetch_bytes_per_launch"] + out[short(k)]["write_bytes_per_launch"]
+    json.dump({"note": "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM; separate --pmc passes", "kernels": out},
+              open(sys.argv[3], "w"), indent=1, sort_keys=True)
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]:
+        print(f"{k:40s} launches {v['launches']:4d}  fetch {v['fetch_bytes_per_launch']/1e6:9.1f} MB  write "
+              f"{v['write_bytes_per_launch']/1e6:9.1f} MB per launch")
+
+
+if __name__ == "__main__":
+    main()
