@@ -45,6 +45,10 @@ int punet_conv_fwd(const float* x0, int c0, const float* x1, int c1, const float
 int punet_conv_dgrad(const float* dz, int cout, const float* w, int cin_total, int cin_off, int cin, float* dx,
                      const float* mask, int accumulate, int B, int H, int W, int ksize, void* stream);
 
+/* tuning knob of K1/K2: persistent grid size in workgroups per CU (default 3 = one residency round); 0 = one workgroup
+ * per output tile. */
+int punet_set_conv_wg_per_cu(int n);
+
 /* ---- K2 fast form: the dgrad's weight slab is first brought into forward-kernel orientation,
  *      wt[k*k-1-t][cout][cin_total] = w[t][cin_total][cout] (once per step for all layers), after which the input gradient
  *      is exactly the K1 kernel.  cin_total, cin_off, cin multiples of 4. */

@@ -21,6 +21,7 @@ _SIGS = {
     "punet_device_ok": (_i, []),
     "punet_conv_fwd": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "punet_conv_dgrad": (_i, [_p, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "punet_set_conv_wg_per_cu": (_i, [_i]),
     "punet_flip_transpose_weights": (_i, [_p, _p, _i, _i, _i, _p]),
     "punet_conv_dgrad_t": (_i, [_p, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "punet_wgrad_workspace_floats": (_sz, [_i, _i, _i, _i]),

@@ -48,7 +48,8 @@ struct ConvArgs {
 };
 
 constexpr int TH = 8, TW = 32, TN = 64, CK = 8;
-constexpr int CONV_WG_PER_CU = 3, NUM_CU = 256;
+constexpr int NUM_CU = 256;
+int g_conv_wg_per_cu = 3;  // persistent grid = this many workgroups per CU; 0 = one workgroup per tile (tuning knob)
 
 struct TileInfo {
     int b, ty0, tx0, n0;
@@ -175,36 +176,6 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
     };
 
     auto epilogue = [&](const TileInfo& ti) {
-        if (ti.ty0 + TH <= a.H && ti.tx0 + TW <= a.W && ti.n0 + TN <= N) {
-            // interior tile: straight-line code, the gate / accumulate loads of a 32x32 block are issued as one batch
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const int n = ti.n0 + nb * 32 + l31;
-                const float bv = a.bias ? a.bias[(size_t)ti.b * a.bias_img_stride + n] : 0.f;
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const size_t base = ((size_t)(ti.b * a.H + ti.ty0 + 2 * wave + m) * a.W + ti.tx0) * N + n;
-                    float gate[16], old[16];
-                    if (a.mask) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) gate[r] = a.mask[base + (size_t)mfma32_row(r, half) * N];
-                    }
-                    if (a.accumulate) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) old[r] = a.y[base + (size_t)mfma32_row(r, half) * N];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = acc[m][nb][r] + bv;
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        if (a.mask) v = gate[r] > 0.f ? v : 0.f;
-                        if (a.accumulate) v += old[r];
-                        a.y[base + (size_t)mfma32_row(r, half) * N] = v;
-                    }
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             const int n = ti.n0 + nb * 32 + l31;
@@ -282,7 +253,8 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
 template <int KS, bool TR>
 int launch_conv(ConvArgs& a, hipStream_t stream) {
     a.ntiles = a.B * ceil_div(a.H, TH) * ceil_div(a.W, TW) * ceil_div(a.n_total, TN);
-    int grid = a.ntiles < CONV_WG_PER_CU * NUM_CU ? a.ntiles : CONV_WG_PER_CU * NUM_CU;
+    const int cap = g_conv_wg_per_cu > 0 ? g_conv_wg_per_cu * NUM_CU : a.ntiles;
+    int grid = a.ntiles < cap ? a.ntiles : cap;
     conv_mfma_kernel<KS, TR><<<grid, 256, 0, stream>>>(a);
     PUNET_LAUNCH_CHECK("conv_mfma");
     return PUNET_OK;
@@ -307,6 +279,12 @@ __global__ __launch_bounds__(256) void flip_transpose_kernel(const float* __rest
 }
 
 }  // namespace
+
+extern "C" int punet_set_conv_wg_per_cu(int n) {
+    PUNET_CHECK_ARG(n >= 0 && n <= 8, "punet_set_conv_wg_per_cu: 0..8");
+    g_conv_wg_per_cu = n;
+    return PUNET_OK;
+}
 
 extern "C" int punet_conv_fwd(const float* x0, int c0, const float* x1, int c1, const float* w, const float* bias,
                               int bias_img_stride, float* y, int cout, int B, int H, int W, int ksize, int relu,
