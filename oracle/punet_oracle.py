@@ -175,7 +175,7 @@ def _pool(x):
     return F.avg_pool2d(x, kernel_size=2, stride=2, padding=0, ceil_mode=True)
 
 
-def unet_features(P: Params, x: torch.Tensor, n_blocks: int, taps: Optional[dict] = None) -> torch.Tensor:
+def unet_features(P: Params, x: torch.Tensor, n_blocks: int, taps: Optional[dict] = None, prefix: str = "unet.") -> torch.Tensor:
     """Unet.forward with apply_last_layer=False (unet.py:50-69, unet_blocks.py:7-59)."""
     blocks = []
     for i in range(n_blocks):
@@ -183,7 +183,7 @@ def unet_features(P: Params, x: torch.Tensor, n_blocks: int, taps: Optional[dict
         if i != 0:
             x = _pool(x)
         for k in (0, 2, 4):
-            x = _conv_relu(P, f"unet.contracting_path.{i}.layers.{off + k}", x)
+            x = _conv_relu(P, f"{prefix}contracting_path.{i}.layers.{off + k}", x)
         if taps is not None:
             taps[f"unet.down{i}"] = x
         if i != n_blocks - 1:
@@ -194,9 +194,27 @@ def unet_features(P: Params, x: torch.Tensor, n_blocks: int, taps: Optional[dict
         assert up.shape[3] == bridge.shape[3]  # unet_blocks.py:55
         x = torch.cat([up, bridge], 1)  # unet_blocks.py:56
         for k in (0, 2, 4):
-            x = _conv_relu(P, f"unet.upsampling_path.{j}.conv_block.layers.{k}", x)
+            x = _conv_relu(P, f"{prefix}upsampling_path.{j}.conv_block.layers.{k}", x)
         if taps is not None:
             taps[f"unet.up{j}"] = x
+    return x
+
+
+def plain_unet_spec(input_channels=1, num_classes=1, num_filters=(64, 128, 256, 512), apply_last_layer=True):
+    """state_dict() of the reference's standalone Unet (unet.py:16-46), intended nf[i-1] -> nf[i] wiring."""
+    full = param_spec(input_channels, num_classes, num_filters)
+    spec = OrderedDict((k[5:], v) for k, v in full.items() if k.startswith("unet."))
+    if apply_last_layer:
+        spec["last_layer.weight"] = (num_classes, num_filters[0], 1, 1)
+        spec["last_layer.bias"] = (num_classes,)
+    return spec
+
+
+def plain_unet_forward(P: Params, x: torch.Tensor, n_blocks: int, apply_last_layer=True) -> torch.Tensor:
+    """Unet.forward(x, val=False) (unet.py:50-69) incl. the optional 1x1 last layer (:66-67)."""
+    x = unet_features(P, x, n_blocks, None, prefix="")
+    if apply_last_layer:
+        x = F.conv2d(x, P["last_layer.weight"], P["last_layer.bias"])
     return x
 
 

@@ -56,8 +56,12 @@ class ParamLayout:
     """Flat layout of all parameters; names and logical shapes follow the reference state-dict (M0)."""
 
     def __init__(self, input_channels=1, num_classes=1, num_filters=(64, 128, 256, 512), latent_dim=6,
-                 no_convs_fcomb=3):
+                 no_convs_fcomb=3, kind="punet", apply_last_layer=True):
+        """kind="punet": the full ProbabilisticUnet; kind="unet": the plain Unet of unet.py:6-69 (names without the
+        "unet." prefix, optional 1x1 `last_layer`)."""
         nf = list(num_filters)
+        self.kind = kind
+        pre = "unet." if kind == "punet" else ""
         if num_classes != 1:
             raise ValueError("the HIP path implements num_classes == 1 (every reference script uses 1)")
         if nf[0] not in (32, 64) or any(f % 32 for f in nf):
@@ -78,7 +82,7 @@ class ParamLayout:
         for i, co in enumerate(nf):
             ci = input_channels if i == 0 else nf[i - 1]
             off = 0 if i == 0 else 1
-            names = [f"unet.contracting_path.{i}.layers.{off + k}" for k in (0, 2, 4)]
+            names = [f"{pre}contracting_path.{i}.layers.{off + k}" for k in (0, 2, 4)]
             add(names[0], ci, co, 3)
             add(names[1], co, co, 3)
             add(names[2], co, co, 3)
@@ -88,13 +92,16 @@ class ParamLayout:
         for j, i in enumerate(range(n - 2, -1, -1)):
             ci = out + nf[i]
             out = nf[i]
-            names = [f"unet.upsampling_path.{j}.conv_block.layers.{k}" for k in (0, 2, 4)]
+            names = [f"{pre}upsampling_path.{j}.conv_block.layers.{k}" for k in (0, 2, 4)]
             add(names[0], ci, out, 3)
             add(names[1], out, out, 3)
             add(names[2], out, out, 3)
             self.unet_up.append(names)
         self.enc: Dict[str, List[List[str]]] = {}
-        for net, extra in (("prior", 0), ("posterior", num_classes)):
+        self.fcomb_mid = []
+        if kind == "unet" and apply_last_layer:
+            add("last_layer", nf[0], num_classes, 1)  # unet.py:45-46
+        for net, extra in (("prior", 0), ("posterior", num_classes)) if kind == "punet" else ():
             blocks = []
             for i, blk in enumerate(encoder_conv_indices(n)):
                 ci = (input_channels + extra) if i == 0 else nf[i - 1]
@@ -104,13 +111,13 @@ class ParamLayout:
                 blocks.append(names)
             self.enc[net] = blocks
             add(f"{net}.conv_layer", nf[-1], 2 * latent_dim, 1)
-        add("fcomb.layers.0", nf[0] + latent_dim, nf[0], 1)
-        self.fcomb_mid = []
-        for k in range(no_convs_fcomb - 2):
-            nm = f"fcomb.layers.{2 * (k + 1)}"
-            add(nm, nf[0], nf[0], 1)
-            self.fcomb_mid.append(nm)
-        add("fcomb.last_layer", nf[0], num_classes, 1)
+        if kind == "punet":
+            add("fcomb.layers.0", nf[0] + latent_dim, nf[0], 1)
+            for k in range(no_convs_fcomb - 2):
+                nm = f"fcomb.layers.{2 * (k + 1)}"
+                add(nm, nf[0], nf[0], 1)
+                self.fcomb_mid.append(nm)
+            add("fcomb.last_layer", nf[0], num_classes, 1)
 
         off = 0
         self.entries: List[Tuple[str, int, int, Tuple[int, ...]]] = []  # (state-dict name, offset, numel, logical shape)

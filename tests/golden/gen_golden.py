@@ -362,7 +362,34 @@ def gen_trainer_case(name, nf, B, H, W, n_samples, seeds=(3, 4, 5)):
     print(f"[gen_golden] wrote {name}.npz ({os.path.getsize(os.path.join(HERE, name + '.npz')) / 1e6:.2f} MB)")
 
 
+def gen_plain_unet_case(name, nf, H, W, seed=1):
+    """BASELINE.json configs[0]: plain Unet forward (prob_utils/my_models/unet.py, apply_last_layer=True) on one
+    synthetic patch, CPU reference."""
+    from prob_utils.my_models.unet import Unet
+    m = Unet(1, 1, nf, {'w': 'he_normal', 'b': 'normal'}, apply_last_layer=True, padding=True)
+    for i in range(1, len(nf)):  # the same in-memory channel fix (unet.py:27-28)
+        c = nn.Conv2d(nf[i - 1], nf[i], 3, stride=1, padding=1)
+        init_weights(c)
+        m.contracting_path[i].layers[1] = c
+    spec = O.plain_unet_spec(1, 1, nf, True)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(spec.keys())
+    Pnp = O.synth_params(spec, seed)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in Pnp.items()})
+    x, _, _, _ = O.synth_batch(1, 1, H, W, 0)
+    with torch.no_grad():
+        y = m(x, False)
+        yo = O.plain_unet_forward(O.to_torch(Pnp), x, len(nf), True)
+    assert (y - yo).abs().max().item() < 1e-5
+    out = {"meta": np.array([1, 1, H, W, 0, seed] + list(nf), dtype=np.int64), "chk_x": csum(x), "logits": y.numpy()}
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(f"[gen_golden] wrote {name}.npz ({os.path.getsize(os.path.join(HERE, name + '.npz')) / 1e6:.2f} MB)")
+
+
 if __name__ == "__main__":
+    if "--only-unet" in sys.argv:
+        gen_plain_unet_case("plain_unet_256", [64, 128, 256, 512], 256, 256)
+        sys.exit(0)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     # (1) literal, unmodified reference (uniform filters run as committed)
@@ -377,3 +404,5 @@ if __name__ == "__main__":
     gen_model_case("full_nf", [64, 128, 256, 512], fixed=True, B=1, C=1, H=64, W=64, n_list=[4], full_grads=False)
     # (5) one real iteration of every PUNet trainer
     gen_trainer_case("trainers_small", [32, 64, 64, 96], B=2, H=32, W=32, n_samples=4)
+    # (6) BASELINE.json configs[0]: plain Unet forward, one 256x256x1 patch
+    gen_plain_unet_case("plain_unet_256", [64, 128, 256, 512], 256, 256)

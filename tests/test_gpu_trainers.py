@@ -206,3 +206,20 @@ def test_prediction_paths(case, dev):
     assert pred.shape == img.shape and np.isfinite(pred).all() and 0.0 <= pred.min() and pred.max() <= 1.0
     mean, cons = pseudo_predict_image(m, img[:64, :64], prior_samples=3)
     assert mean.shape == (64, 64) and cons.dtype == np.uint8 and set(np.unique(cons)) <= {0, 1}
+
+
+def test_plain_unet_config0(golden_dir, dev):
+    """BASELINE.json configs[0]: plain Unet forward on one 256x256x1 patch vs the reference's output."""
+    from probabilistic_domain_adaptation_amd.my_models import Unet
+    fx = np.load(os.path.join(golden_dir, "plain_unet_256.npz"))
+    _, _, H, W, s0, seed = [int(v) for v in fx["meta"][:6]]
+    nf = [int(v) for v in fx["meta"][6:]]
+    spec = O.plain_unet_spec(1, 1, nf, True)
+    Pnp = O.synth_params(spec, seed)
+    m = Unet(1, 1, nf, {'w': 'he_normal', 'b': 'normal'}, apply_last_layer=True, padding=True, device=dev, seed=0)
+    assert list(m.state_dict().keys()) == list(spec.keys())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in Pnp.items()})
+    x, _, _, _ = O.synth_batch(1, 1, H, W, s0)
+    y = m(x.to(dev), False)
+    torch.cuda.synchronize()
+    assert np.abs(y.cpu().numpy() - fx["logits"]).max() < 1e-3
