@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 NF = [64, 128, 256, 512]
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 # algorithmic GFLOP per patch at 512x512x1
 GFLOP = {"mean_teacher": {8: 3233.4, 16: 3269.6}, "punet_source": 2539.4, "inference": {8: 694.0, 16: 730.2}}
 
@@ -190,6 +191,9 @@ def main():
                        "algorithmic_gflop_per_patch": gf,
                        "model_tflops_per_gpu": round(gf * patches / dt / world / 1e3, 2)},
         }
+        out["config"]["conv_arithmetic"] = (
+            "3x3 convs fwd+dgrad: fp32 operands split into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate "
+            "(fp32-accurate); wgrad and 1x1: fp32-input MFMA" if eng.conv_mode == "x6" else "fp32-input MFMA everywhere")
         if prof:
             agg = {}
             for kind, fl, e0, e1 in prof:
@@ -213,12 +217,23 @@ def main():
                 pass
             if k3:
                 ach = k3[0] / k3[1] / 1e12
-                out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                                   "traffic_note": traffic_note,
-                                   "kernel": "conv_mfma_kernel<3,false> (3x3 NHWC direct conv forward, fp32 MFMA)",
-                                   "flops_per_launch_avg": k3[0] / k3[2], "avg_launch_ms": round(1e3 * k3[1] / k3[2], 4),
-                                   "peak_note": "fp32-input MFMA dense peak (parity mode); bf16 MFMA is not used"}
+                if eng.conv_mode == "x6":
+                    # six bf16 MFMAs per fp32-accurate product: the roofline of THIS arithmetic is the bf16 dense peak / 6
+                    peak = BF16_MFMA_PEAK_TFLOPS / 6.0
+                    kname = "conv3x3_x6_kernel (3x3 NHWC direct conv forward, fp32-accurate 3-plane bf16 split on BF16 MFMA)"
+                    pnote = (f"bf16 dense MFMA peak {BF16_MFMA_PEAK_TFLOPS} TFLOP/s / 6 MFMAs per product = {peak:.1f} TFLOP/s of "
+                             f"algorithmic fp32 work; executed bf16 MFMA rate = 6 x achieved = {6 * ach:.0f} TFLOP/s "
+                             f"({6 * ach / BF16_MFMA_PEAK_TFLOPS:.3f} of the bf16 peak); for reference the fp32-input MFMA "
+                             f"peak is {FP32_MFMA_PEAK_TFLOPS} TFLOP/s (frac {ach / FP32_MFMA_PEAK_TFLOPS:.3f})")
+                    traffic, traffic_note = None, "PMC passes were collected for the fp32-MFMA kernel only (profiles/r01)"
+                else:
+                    peak = FP32_MFMA_PEAK_TFLOPS
+                    kname = "conv_mfma_kernel<3,false> (3x3 NHWC direct conv forward, fp32 MFMA)"
+                    pnote = "fp32-input MFMA dense peak (PUNET_CONV_MODE=f32)"
+                out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                                   "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
+                                   "kernel": kname, "flops_per_launch_avg": k3[0] / k3[2],
+                                   "avg_launch_ms": round(1e3 * k3[1] / k3[2], 4), "peak_note": pnote}
             out["kernels"] = kernels
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.workload, N, H, W)

@@ -2,7 +2,7 @@
  *
  * Drop-in boundary.  The reference (/root/reference, pure Python) has no FFI of its own: its hot path
  * is reached through nn.Module methods (prob_utils/my_models/probabilistic_unet.py:285-371) and trainer bodies
- * (prob_utils/my_trainer/*.py).  Each entry point below replaces the ATen op(s) that the cited reference line
+ * (prob_utils/my_trainer/ *.py).  Each entry point below replaces the ATen op(s) that the cited reference line
  * dispatches; the host-side mirror of the reference API that calls them lives in
  * probabilistic_domain_adaptation_amd/{my_models,my_trainer,my_predictions} (ctypes binding: _lib.py; the stub a
  * reference maintainer would add is shown in INTEGRATION.md).
@@ -55,6 +55,18 @@ int punet_set_conv_wg_per_cu(int n);
 int punet_flip_transpose_weights(const float* w, float* wt, int cin, int cout, int ksize, void* stream);
 int punet_conv_dgrad_t(const float* dz, int cout, const float* wt, int cin_total, int cin_off, int cin, float* dx,
                        const float* mask, int accumulate, int B, int H, int W, int ksize, void* stream);
+
+/* ---- K1x6 / K2x6: the same 3x3 convolution / input gradient at fp32 accuracy on the BF16 matrix cores: every operand is
+ *      split into three bf16 planes (3 x 8 = 24 significand bits) and each product evaluated as hh+hm+mh+hl+lh+mm with fp32
+ *      accumulation (dropped terms <= 2^-26 relative).  Weights are pre-split once per optimizer step:
+ *      planes[3][9][K/8][n_row][8] bf16, plane_stride elements apart; mode 0: K = cin, n = cout (forward);
+ *      mode 1: K = cout, n = cin, taps flipped (input gradient).  The conv computes output channels
+ *      [n_off, n_off + n_out) of the n_row available; mask/accumulate/relu/bias as in K1/K2. */
+int punet_split_weights_x6(const float* w, void* planes, long plane_stride, int cin, int cout, int ksize, int mode,
+                           void* stream);
+int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride, int n_row,
+                     int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
+                     int accumulate, int relu, int B, int H, int W, void* stream);
 
 /* ---- K3: autograd weight + bias gradient of K1 (convolution_backward, weight/bias), fp32 MFMA, deterministic split-K.
  *      x has cs channels and fills rows [ci_off, ci_off+cs) of dw[k][k][cin_total][cout]; dbias may be NULL.

@@ -1,0 +1,325 @@
+// K1x6 / K2x6: the 3x3 NHWC direct convolution (and its input gradient) at fp32 accuracy on the BF16 matrix cores.
+//
+// Same contraction, tiling and epilogue as conv_mfma.hip, but every fp32 operand is split into three bf16 planes
+// x = h + m + l (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): 3 x 8 significand bits = fp32's 24) and each product
+// is evaluated as  hh + hm + mh + hl + lh + mm  with v_mfma_f32_32x32x16_bf16 accumulating in fp32.  The three dropped
+// terms (ml, lm, ll) are <= 2^-26 relative, below the rounding of an fp32 fmaf chain, so this is a PARITY mode (same
+// tolerance class as the fp32-MFMA kernel), not a reduced-precision mode.  Six bf16 MFMAs do the work of sixteen fp32
+// MFMAs' worth of matrix-pipe time (bf16 issues 16x the MACs per cycle), i.e. 2.67x the fp32-MFMA peak.
+//
+// K blocking: one bf16 MFMA contracts K = 16.  A K block here is {two taps} x {8 channels}: lanes 0-31 carry tap 2j,
+// lanes 32-63 tap 2j+1 of the same 8 channels, so a chunk of 8 input channels is 5 MFMA K-steps (the 10th tap slot is a
+// zero weight slab).  That keeps the LDS images tiny - [pixel][8 ch] = one 16-byte ds_read_b128 per lane per plane,
+// consecutive pixels / output channels in consecutive 16-byte slots = conflict-free with no padding - 47 KB per
+// workgroup, 3 workgroups per CU.
+// Weights arrive pre-split (punet_split_weights_x6, once per optimizer step) as planes[3][tap][K/8][N][8] bf16, so their
+// staging is a pure copy; activations are split while being staged (v_cvt_pk_bf16_f32, ~6 VALU ops per element,
+// amortised over 9 taps x 64 output channels).
+#include "common.h"
+#include "punet_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TH = 8, TW = 32, TN = 64, CK = 8;
+constexpr int NUM_CU = 256;
+
+struct ConvX6Args {
+    const float* x0;
+    const float* x1;
+    int c0, c1;
+    const __bf16* wp;   // planes[3][9][K/8][n_row][8]
+    long plane_stride;  // elements between planes
+    int n_row, n_off;
+    const float* bias;
+    int bias_img_stride;
+    float* y;
+    int n_total;
+    const float* mask;
+    int accumulate, relu;
+    int B, H, W, ntiles;
+};
+
+struct TileInfo {
+    int b, ty0, tx0, n0;
+};
+
+union U4 {
+    uint4 u;
+    bf16x8 v;
+};
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    l = (__bf16)r2;
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
+    constexpr int KS = 3, KK = 9, PAD = 1;
+    constexpr int HTH = TH + KS - 1, HTW = TW + KS - 1;
+    constexpr int NPIX = HTH * HTW;
+    constexpr int NPAIR = (KK + 1) / 2;
+    constexpr int XUNITS = NPIX * (CK / 4);
+    constexpr int XITER = (XUNITS + 255) / 256;
+    constexpr int WUNITS = 3 * KK * TN;  // uint4 (8 bf16) units per chunk
+    constexpr int WITER = (WUNITS + 255) / 256;
+
+    __shared__ uint4 sX[3][NPIX];             // [plane][pixel] -> 8 bf16 channels
+    __shared__ uint4 sW[3][(KK + 1) * TN];     // [plane][tap][n] -> 8 bf16 channels; tap 9 = zeros
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int ntn = (a.n_total + TN - 1) / TN;
+    const int N = a.n_total;
+    const int K = a.c0 + a.c1;
+    const int nchunks = K / CK;
+
+    for (int i = tid; i < 3 * TN; i += 256) sW[i / TN][KK * TN + i % TN] = make_uint4(0u, 0u, 0u, 0u);
+
+    auto decode = [&](int tile) {
+        TileInfo t;
+        t.n0 = (tile % ntn) * TN;
+        int sid = tile / ntn;
+        t.tx0 = (sid % tiles_x) * TW;
+        sid /= tiles_x;
+        t.ty0 = (sid % tiles_y) * TH;
+        t.b = sid / tiles_y;
+        return t;
+    };
+
+    f32x16 acc[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.f;
+    };
+    zero_acc();
+
+    float4 rx[XITER];
+    uint4 rw[WITER];
+
+    auto prefetch = [&](const TileInfo& ti, int ch) {
+        const int kbase = ch * CK;
+        const float* src;
+        int cs, coff;
+        if (kbase < a.c0) {
+            src = a.x0; cs = a.c0; coff = kbase;
+        } else {
+            src = a.x1; cs = a.c1; coff = kbase - a.c0;
+        }
+#pragma unroll
+        for (int it = 0; it < XITER; ++it) {
+            const int u = tid + it * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < XUNITS) {
+                const int q = u % (CK / 4), pix = u / (CK / 4);
+                const int py = pix / HTW, px = pix % HTW;
+                const int gy = ti.ty0 + py - PAD, gx = ti.tx0 + px - PAD;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    v = *reinterpret_cast<const float4*>(src + ((size_t)(ti.b * a.H + gy) * a.W + gx) * cs + coff + q * 4);
+            }
+            rx[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) {
+            const int u = tid + it * 256;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (u < WUNITS) {
+                const int n = u % TN, t = (u / TN) % KK, p = u / (TN * KK);
+                if (ti.n0 + n < N)
+                    v = *reinterpret_cast<const uint4*>(a.wp + (size_t)p * a.plane_stride +
+                                                        (((size_t)t * nchunks + ch) * a.n_row + a.n_off + ti.n0 + n) * 8);
+            }
+            rw[it] = v;
+        }
+    };
+
+    auto commit = [&]() {
+#pragma unroll
+        for (int it = 0; it < XITER; ++it) {
+            const int u = tid + it * 256;
+            if (u < XUNITS) {
+                const int q = u % (CK / 4), pix = u / (CK / 4);
+                const float xv[4] = {rx[it].x, rx[it].y, rx[it].z, rx[it].w};
+                __bf16 hh[4], mm[4], ll[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split3(xv[e], hh[e], mm[e], ll[e]);
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                bf16x4 ph = {hh[0], hh[1], hh[2], hh[3]}, pm = {mm[0], mm[1], mm[2], mm[3]}, pl = {ll[0], ll[1], ll[2], ll[3]};
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sX[0][pix]) + q * 8) = ph;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sX[1][pix]) + q * 8) = pm;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sX[2][pix]) + q * 8) = pl;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) {
+            const int u = tid + it * 256;
+            if (u < WUNITS) {
+                const int n = u % TN, t = (u / TN) % KK, p = u / (TN * KK);
+                sW[p][t * TN + n] = rw[it];
+            }
+        }
+    };
+
+    auto epilogue = [&](const TileInfo& ti) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int n = ti.n0 + nb * 32 + l31;
+            if (n >= N) continue;
+            float bv = 0.f;
+            if (a.bias) bv = a.bias[(size_t)ti.b * a.bias_img_stride + n];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int gy = ti.ty0 + 2 * wave + m;
+                if (gy >= a.H) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gx = ti.tx0 + mfma32_row(r, half);
+                    if (gx >= a.W) continue;
+                    const size_t idx = ((size_t)(ti.b * a.H + gy) * a.W + gx) * N + n;
+                    float v = acc[m][nb][r] + bv;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (a.mask) v = (a.mask[idx] > 0.f) ? v : 0.f;
+                    if (a.accumulate) v += a.y[idx];
+                    a.y[idx] = v;
+                }
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    int ch = 0;
+    TileInfo ti = decode(tile);
+    prefetch(ti, 0);
+    while (true) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        int nch = ch + 1, ntile = tile;
+        TileInfo nti = ti;
+        if (nch == nchunks) {
+            nch = 0;
+            ntile = tile + (int)gridDim.x;
+            if (ntile < a.ntiles) nti = decode(ntile);
+        }
+        const bool has_next = ntile < a.ntiles;
+        if (has_next) prefetch(nti, nch);
+
+#pragma unroll
+        for (int j = 0; j < NPAIR; ++j) {
+            // this lane's tap: 2j (lanes 0-31) or 2j+1 (lanes 32-63); tap 9 does not exist: B reads the zero slab
+            const int t0 = 2 * j, t1 = 2 * j + 1;
+            const int offA0 = (t0 / KS) * HTW + t0 % KS;
+            const int offA1 = t1 < KK ? (t1 / KS) * HTW + t1 % KS : offA0;
+            const int offA = half ? offA1 : offA0;
+            const int tapB = half ? t1 : t0;  // t1 == KK -> zero slab
+            U4 av[3][2], bv[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) av[p][m].u = sX[p][(2 * wave + m) * HTW + l31 + offA];
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) bv[p][nb].u = sW[p][tapB * TN + nb * 32 + l31];
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    f32x16 c = acc[m][nb];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][m].v, bv[1][nb].v, c, 0, 0, 0);  // mm
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2][m].v, bv[0][nb].v, c, 0, 0, 0);  // lh
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][m].v, bv[2][nb].v, c, 0, 0, 0);  // hl
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][m].v, bv[0][nb].v, c, 0, 0, 0);  // mh
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][m].v, bv[1][nb].v, c, 0, 0, 0);  // hm
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][m].v, bv[0][nb].v, c, 0, 0, 0);  // hh
+                    acc[m][nb] = c;
+                }
+        }
+        if (ch == nchunks - 1) {
+            epilogue(ti);
+            zero_acc();
+        }
+        if (!has_next) break;
+        tile = ntile;
+        ch = nch;
+        ti = nti;
+    }
+}
+
+// planes[p][t'][k/8][n][8] <- split(w) ; mode 0 (forward): k = cin, n = cout, t' = t ;
+// mode 1 (input gradient): k = cout, n = cin, t' = kk-1-t (flipped taps)
+__global__ __launch_bounds__(256) void split_weights_x6_kernel(const float* __restrict__ w, __bf16* __restrict__ planes,
+                                                               long plane_stride, int cin, int cout, int kk, int mode) {
+    const int K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+    const int KC = K / 8;
+    const size_t total = (size_t)kk * KC * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N);
+        const int kc = (int)((i / N) % KC);
+        const int tp = (int)(i / ((size_t)N * KC));
+        const int t = mode == 0 ? tp : kk - 1 - tp;
+        __bf16 h[8], m[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = kc * 8 + e;
+            const float v = mode == 0 ? w[((size_t)t * cin + k) * cout + n] : w[((size_t)t * cin + n) * cout + k];
+            split3(v, h[e], m[e], l[e]);
+        }
+        bf16x8 vh, vm, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { vh[e] = h[e]; vm[e] = m[e]; vl[e] = l[e]; }
+        *reinterpret_cast<bf16x8*>(planes + i * 8) = vh;
+        *reinterpret_cast<bf16x8*>(planes + plane_stride + i * 8) = vm;
+        *reinterpret_cast<bf16x8*>(planes + 2 * plane_stride + i * 8) = vl;
+    }
+}
+
+int g_x6_wg_per_cu = 2;
+
+}  // namespace
+
+extern "C" int punet_split_weights_x6(const float* w, void* planes, long plane_stride, int cin, int cout, int ksize, int mode,
+                                      void* stream) {
+    PUNET_CHECK_ARG(w && planes && cin > 0 && cout > 0 && ksize == 3 && (mode == 0 || mode == 1),
+                    "punet_split_weights_x6: bad args");
+    PUNET_CHECK_ARG((mode == 0 ? cin : cout) % 8 == 0, "punet_split_weights_x6: the contracted channel count must be a multiple of 8");
+    PUNET_CHECK_ARG(plane_stride >= (long)9 * cin * cout, "punet_split_weights_x6: plane_stride too small");
+    const size_t total = (size_t)9 * cin * cout / 8;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    split_weights_x6_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(w, (__bf16*)planes, plane_stride, cin, cout, 9, mode);
+    PUNET_LAUNCH_CHECK("split_weights_x6");
+    return PUNET_OK;
+}
+
+extern "C" int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
+                                int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out,
+                                const float* mask, int accumulate, int relu, int B, int H, int W, void* stream) {
+    PUNET_CHECK_ARG(x0 && wplanes && y, "punet_conv3x3_x6: null pointer");
+    PUNET_CHECK_ARG(c0 > 0 && c0 % CK == 0 && c1 >= 0 && c1 % CK == 0 && (c1 == 0 || x1),
+                    "punet_conv3x3_x6: source channels must be multiples of %d (c0=%d c1=%d)", CK, c0, c1);
+    PUNET_CHECK_ARG(n_out > 0 && n_off >= 0 && n_off + n_out <= n_row, "punet_conv3x3_x6: bad output-channel window");
+    PUNET_CHECK_ARG(B > 0 && H > 0 && W > 0, "punet_conv3x3_x6: bad shape");
+    ConvX6Args a{};
+    a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1;
+    a.wp = (const __bf16*)wplanes; a.plane_stride = plane_stride; a.n_row = n_row; a.n_off = n_off;
+    a.bias = bias; a.bias_img_stride = bias_img_stride;
+    a.y = y; a.n_total = n_out; a.mask = mask; a.accumulate = accumulate; a.relu = relu;
+    a.B = B; a.H = H; a.W = W;
+    a.ntiles = B * ceil_div(H, TH) * ceil_div(W, TW) * ceil_div(n_out, TN);
+    const int cap = g_x6_wg_per_cu * NUM_CU;
+    const int grid = a.ntiles < cap ? a.ntiles : cap;
+    conv3x3_x6_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    PUNET_LAUNCH_CHECK("conv3x3_x6");
+    return PUNET_OK;
+}

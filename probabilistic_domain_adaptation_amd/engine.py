@@ -14,6 +14,7 @@ Data layout in HBM
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -209,6 +210,12 @@ class PUNetEngine:
         self.ws = Workspace(self.device)
         self.prof = None  # when a list: (kind, algorithmic FLOPs, start event, end event) per 3x3 MFMA launch
         self.wT = None  # flipped + transposed weight slabs for the dgrad pass (prepare_dgrad_weights)
+        # 3x3 conv arithmetic: "x6" = three-plane bf16 split on the BF16 matrix cores (fp32-accurate, ~1.55x faster),
+        # "f32" = fp32-input MFMA.  Both are parity modes with the same tolerances.
+        self.conv_mode = os.environ.get("PUNET_CONV_MODE", "x6")
+        if self.conv_mode not in ("x6", "f32"):
+            raise ValueError("PUNET_CONV_MODE must be 'x6' or 'f32'")
+        self._x6 = {}  # (flat.data_ptr(), mode) -> bf16 planes buffer [3 * numel]
         tab, self.l2_ntensors = layout.l2_chunk_table()
         self.l2_chunks = tab.to(self.device)
         self.l2_nchunks = tab.shape[0]
@@ -250,6 +257,12 @@ class PUNetEngine:
             assert x1 is None and c.k == 3
             _lib.call("punet_conv3x3_small_fwd", x0.ptr, cin, self._wptr(flat, c), self._bptr(flat, c), y.ptr, c.cout,
                       B, H, W, int(relu), _stream())
+        elif self.conv_mode == "x6" and c.k == 3:
+            planes = self._x6[(flat.data_ptr(), 0)]
+            self._timed("conv3x3_fwd", 2.0 * B * H * W * cin * c.cout * 9, "punet_conv3x3_x6", x0.ptr, x0.C,
+                        x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0,
+                        planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cout, 0, self._bptr(flat, c), 0, y.ptr, c.cout, None, 0,
+                        int(relu), B, H, W, _stream())
         else:
             self._timed(f"conv{c.k}x{c.k}_fwd", 2.0 * B * H * W * cin * c.cout * c.k * c.k, "punet_conv_fwd", x0.ptr, x0.C,
                         x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0, self._wptr(flat, c),
@@ -320,6 +333,7 @@ class PUNetEngine:
     def forward_features(self, flat, x_nhwc: torch.Tensor, taps=None):
         """ProbabilisticUnet.forward(patch, None, training=False) (probabilistic_unet.py:292-293)."""
         B, H, W, C = x_nhwc.shape
+        self.prepare_forward_weights(flat)
         xin = Act(x_nhwc, B, H, W, C, needs_grad=False)
         muls_p, _, _ = self.latent(flat, "prior", xin, None, taps)
         feat = self.unet(flat, xin, None, taps)
@@ -384,6 +398,7 @@ class PUNetEngine:
         B, H, W, C = x_nhwc.shape
         Ld, CH = L.latent_dim, L.nf[0]
         st = {"B": B, "H": H, "W": W, "gscale": gscale, "beta": beta}
+        self.prepare_forward_weights(flat)
         xin = Act(x_nhwc, B, H, W, C, needs_grad=False)
         xq = Act(torch.cat([x_nhwc, y_tgt.reshape(B, H, W, 1)], dim=3), B, H, W, C + 1, needs_grad=False)  # [patch, segm]
         tq = [] if record else None
@@ -446,12 +461,35 @@ class PUNetEngine:
                     dz.data_ptr(), c.cout, dw, c.cin, ci_off, db if with_bias else None, ws.data_ptr(), ns, B, H, W, c.k,
                     int(accumulate), 1.0, _stream())
 
+    def _split_x6(self, flat, mode: int):
+        """(Re)build the three-plane bf16 split of every 3x3 conv weight slab of `flat` (mode 0: forward orientation,
+        mode 1: input-gradient orientation).  Weights change every optimizer step, so callers refresh per pass."""
+        key = (flat.data_ptr(), mode)
+        planes = self._x6.get(key)
+        if planes is None:
+            planes = torch.empty(3 * flat.numel(), dtype=torch.bfloat16, device=self.device)
+            self._x6[key] = planes
+        for c in self.L.convs.values():
+            if c.k != 3 or c.cin <= 4:
+                continue
+            _lib.call("punet_split_weights_x6", self._wptr(flat, c), planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cin,
+                      c.cout, 3, mode, _stream())
+        return planes
+
+    def prepare_forward_weights(self, flat):
+        if self.conv_mode == "x6":
+            self._split_x6(flat, 0)
+
     def prepare_dgrad_weights(self, flat):
         """Bring every conv weight slab into forward-kernel orientation for the input-gradient pass
         (wt[k*k-1-t][cout][cin] = w[t][cin][cout]); ~0.1 ms per step, after which dgrad IS the forward kernel."""
+        if self.conv_mode == "x6":
+            self._split_x6(flat, 1)
         if self.wT is None or self.wT.numel() != flat.numel():
             self.wT = torch.empty_like(flat)
         for c in self.L.convs.values():
+            if self.conv_mode == "x6" and c.k == 3:
+                continue  # served by the x6 planes
             if c.cin > 4 and c.cin % 4 == 0 and c.cout % 8 == 0:
                 _lib.call("punet_flip_transpose_weights", self._wptr(flat, c), self.wT.data_ptr() + 4 * c.w_off, c.cin, c.cout,
                           c.k, _stream())
@@ -459,7 +497,12 @@ class PUNetEngine:
     def _dgrad(self, flat, c: ConvP, dz, cin_off: int, cin: int, dx, mask_ptr, acc: int, B: int, H: int, W: int):
         """dx[..., cin_off : cin_off + cin] of conv c given dz (epilogue: ReLU gate by `mask`, accumulate)."""
         flops = 2.0 * B * H * W * cin * c.cout * c.k * c.k
-        if c.cin % 4 == 0:
+        if self.conv_mode == "x6" and c.k == 3:
+            planes = self._x6[(flat.data_ptr(), 1)]
+            self._timed("conv3x3_dgrad", flops, "punet_conv3x3_x6", dz.data_ptr(), c.cout, None, 0,
+                        planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cin, cin_off, None, 0, dx.data_ptr(), cin, mask_ptr, acc,
+                        0, B, H, W, _stream())
+        elif c.cin % 4 == 0:
             self._timed(f"conv{c.k}x{c.k}_dgrad", flops, "punet_conv_dgrad_t", dz.data_ptr(), c.cout,
                         self.wT.data_ptr() + 4 * c.w_off, c.cin, cin_off, cin, dx.data_ptr(), mask_ptr, acc, B, H, W, c.k,
                         _stream())

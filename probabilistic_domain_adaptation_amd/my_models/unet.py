@@ -47,6 +47,7 @@ class Unet(nn.Module):
         eng = self.engine
         xn = eng.to_nhwc(x)
         B, H, W, C = xn.shape
+        eng.prepare_forward_weights(self._flat)
         feat = eng.unet(self._flat, Act(xn, B, H, W, C, needs_grad=False))
         if val:
             self.activation_maps.append(feat.t.permute(0, 3, 1, 2))

@@ -1,0 +1,77 @@
+"""GPU: the bf16x6 (three-plane split, fp32-accurate) 3x3 convolution kernels against PyTorch CPU fp32 at the SAME
+tolerance as the fp32-MFMA kernels (it is a parity mode, not a reduced-precision mode)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(1, 8, 32, 8, 0, 32), (2, 16, 16, 64, 0, 64), (1, 24, 40, 32, 0, 96), (2, 8, 8, 128, 0, 128),
+         (1, 16, 32, 64, 32, 32), (1, 64, 64, 96, 64, 64), (1, 4, 4, 192, 0, 160)]
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from probabilistic_domain_adaptation_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def S():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def rel_err(a, b):
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,cout", CASES)
+def test_conv_x6_fwd_and_dgrad(L, B, H, W, c0, c1, cout):
+    g = torch.Generator().manual_seed(11)
+    cin = c0 + c1
+    # wide dynamic range on purpose: magnitudes spread over ~2^20
+    scale = torch.exp2(torch.randint(-10, 10, (B, cin, H, W), generator=g).float())
+    x = (torch.randn(B, cin, H, W, generator=g) * scale).requires_grad_(True)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)).requires_grad_(True)
+    b = torch.randn(cout, generator=g)
+    y = F.conv2d(x, w, b, padding=1)
+    dz = torch.randn(B, cout, H, W, generator=g)
+    y.backward(dz)
+    Wp = w.detach().permute(2, 3, 1, 0).contiguous().cuda()  # [3][3][cin][cout]
+    nw = 9 * cin * cout
+    pf = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+    pd = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+    L.call("punet_split_weights_x6", Wp.data_ptr(), pf.data_ptr(), nw, cin, cout, 3, 0, S())
+    L.call("punet_split_weights_x6", Wp.data_ptr(), pd.data_ptr(), nw, cin, cout, 3, 1, S())
+    X = nhwc(x.detach())
+    X0 = X[..., :c0].contiguous()
+    X1 = X[..., c0:].contiguous() if c1 else None
+    Y = torch.full((B, H, W, cout), float("nan"), device="cuda")
+    Bd = b.cuda()
+    L.call("punet_conv3x3_x6", X0.data_ptr(), c0, X1.data_ptr() if c1 else None, c1, pf.data_ptr(), nw, cout, 0, Bd.data_ptr(), 0,
+           Y.data_ptr(), cout, None, 0, 1, B, H, W, S())
+    torch.cuda.synchronize()
+    assert rel_err(nchw(Y), F.relu(y.detach())) < 2e-6
+    DZ = nhwc(dz)
+    off = 0
+    for cs in [c0] + ([c1] if c1 else []):
+        mask = torch.randn(B, cs, H, W, generator=g)
+        prev = torch.randn(B, cs, H, W, generator=g)
+        M, DX = nhwc(mask), nhwc(prev)
+        L.call("punet_conv3x3_x6", DZ.data_ptr(), cout, None, 0, pd.data_ptr(), nw, cin, off, None, 0, DX.data_ptr(), cs,
+               M.data_ptr(), 1, 0, B, H, W, S())
+        torch.cuda.synchronize()
+        ref = prev + x.grad[:, off:off + cs] * (mask > 0)
+        assert rel_err(nchw(DX), ref) < 3e-6
+        off += cs
