@@ -77,6 +77,12 @@ int punet_conv_wgrad(const float* x, int cs, const float* dz, int cout, float* d
                      float* dbias, float* workspace, int nslices, int B, int H, int W, int ksize, int accumulate,
                      float scale, void* stream);
 
+/* ---- K3x6: the 3x3 weight (+ bias) gradient with the same three-plane bf16 arithmetic as K1x6 (fp32-accurate); operands
+ *      are fetched with the transposing LDS read ds_read_b64_tr_b16.  Arguments as punet_conv_wgrad (ksize = 3). */
+int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off,
+                        float* dbias, float* workspace, int nslices, int B, int H, int W, int accumulate, float scale,
+                        void* stream);
+
 /* ---- K1s: first-layer 3x3 conv with cin in 1..4 (image / [image, mask], probabilistic_unet.py:39-42,118) and its
  *      weight + bias gradient (no input gradient exists). */
 int punet_conv3x3_small_fwd(const float* x, int cin, const float* w, const float* bias, float* y, int cout, int B,

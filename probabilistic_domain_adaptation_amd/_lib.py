@@ -29,6 +29,7 @@ _SIGS = {
     "punet_wgrad_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "punet_wgrad_slices": (_i, [_i, _i, _i, _i, _i]),
     "punet_conv_wgrad": (_i, [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "punet_conv_wgrad_x6": (_i, [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "punet_conv3x3_small_fwd": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "punet_small_wgrad_workspace_floats": (_sz, [_i, _i]),
     "punet_conv3x3_small_wgrad": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p]),

@@ -1,0 +1,252 @@
+// K3x6: weight (+ bias) gradient of the 3x3 NHWC convolutions at fp32 accuracy on the BF16 matrix cores.
+//
+// Same split-K structure, slab layout and deterministic second pass as wgrad_mfma.hip; the arithmetic is the
+// three-plane bf16 split of conv_x6.hip (x = h + m + l, products hh + hm + mh + hl + lh + mm, fp32 accumulate).
+//
+//   dW[tap][ci][co] = sum_pixels X[pixel + tap][ci] * dZ[pixel][co]
+//
+// Per tap a GEMM with M = ci, N = co and the PIXELS as the contracted index: the MFMA operands are "8 consecutive pixels
+// of one channel", i.e. the transpose of the NHWC images.  The LDS images stay [pixel][32 channels] (64-byte rows, one
+// image per 32-channel block and per bf16 plane) and the operands are fetched with ds_read_b64_tr_b16, the gfx950
+// transposing LDS read: a 16-lane group reads a 4-pixel x 16-channel block and each lane receives its channel's four
+// pixels.  Tap shifts are whole-row offsets, so every read stays aligned; 4 rows x 2 channel groups of a half-wave
+// cover the 64 banks exactly once (conflict-free).
+// Workgroup = 8 waves = 4 (ci block, co block) pairs x 2 tap groups (taps 0-4 | 5-8), as in the fp32 kernel.
+// The bias gradient (exact fp32 column sums of dZ) is accumulated while dZ is being staged.
+#include "common.h"
+#include "punet_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WTH = 2, WTW = 32, WC = 64;
+constexpr int HTH = WTH + 2, HTW = WTW + 2;
+constexpr int NPX = HTH * HTW;   // 136 halo pixels
+constexpr int NPD = WTH * WTW;   // 64 pixels
+constexpr int ROWB = 64;         // bytes per [pixel][32 ch] bf16 row
+constexpr int XIMG = NPX * ROWB;  // one (plane, ci block) image
+constexpr int DIMG = NPD * ROWB;  // one (plane, co block) image
+
+struct WgradX6Args {
+    const float* x;
+    int cs;
+    const float* dz;
+    int cout;
+    float* partial;
+    float* bias_partial;
+    int B, H, W, nslices;
+};
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    l = (__bf16)r2;
+}
+
+union Frag {
+    bf16x8 v;
+    s16x4 half4[2];
+};
+
+__device__ __forceinline__ s16x4 tr_read(const char* lds_base, int byte_off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_base + byte_off));
+}
+
+// taps [T0, T0 + NT) of one staged tile.  aoff/boff: this lane's byte offset inside an image (see kernel body).
+template <int T0, int NT>
+__device__ __forceinline__ void tile_mfma(f32x16 (&acc)[5], const char* sX, const char* sD, int cib, int cob, int aoff, int boff) {
+#pragma unroll 1
+    for (int s = 0; s < NPD / 16; ++s) {
+        const int row = (16 * s) / WTW, col0 = (16 * s) % WTW;
+        Frag b[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                b[p].half4[r] = tr_read(sD, (p * 2 + cob) * DIMG + (16 * s + 4 * r) * ROWB + boff);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int t = T0 + tt, ky = t / 3, kx = t % 3;
+            Frag a[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    a[p].half4[r] = tr_read(sX, (p * 2 + cib) * XIMG + ((row + ky) * HTW + col0 + kx + 4 * r) * ROWB + aoff);
+            f32x16 c = acc[tt];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].v, b[1].v, c, 0, 0, 0);  // mm
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2].v, b[0].v, c, 0, 0, 0);  // lh
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[2].v, c, 0, 0, 0);  // hl
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].v, b[0].v, c, 0, 0, 0);  // mh
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[1].v, c, 0, 0, 0);  // hm
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[0].v, c, 0, 0, 0);  // hh
+            acc[tt] = c;
+        }
+    }
+}
+
+template <int T0, int NT>
+__device__ __forceinline__ void store_partial(const f32x16 (&acc)[5], const WgradX6Args& a, int slice, int ci_base, int co, int half) {
+    if (co >= a.cout) return;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci_base + mfma32_row(r, half);
+            if (ci < a.cs) a.partial[(((size_t)slice * 9 + T0 + tt) * a.cs + ci) * a.cout + co] = acc[tt][r];
+        }
+}
+
+__global__ __launch_bounds__(512, 4) void wgrad3x3_x6_kernel(WgradX6Args a) {
+    constexpr int XUNITS = NPX * (WC / 4), DUNITS = NPD * (WC / 4);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sX = smem;                // [3 planes][2 ci blocks][NPX][32] bf16
+    char* sD = smem + 6 * XIMG;     // [3 planes][2 co blocks][NPD][32] bf16
+    float* sBias = reinterpret_cast<float*>(smem);  // reused after the last tile
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int pair = wave & 3, group = wave >> 2;
+    const int cib = pair >> 1, cob = pair & 1;
+
+    const int co_tiles = (a.cout + WC - 1) / WC;
+    const int ci_tile = blockIdx.y / co_tiles, co_tile = blockIdx.y % co_tiles;
+    const int ci0 = ci_tile * WC, co0 = co_tile * WC;
+    const int slice = blockIdx.x;
+    const int tiles_x = (a.W + WTW - 1) / WTW, tiles_y = (a.H + WTH - 1) / WTH;
+    const int ntiles = a.B * tiles_x * tiles_y;
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);  // this thread's channel quad (tid % 16) of dZ, summed over its pixels
+
+    // transposing read: 16-lane group g = lane / 16 -> (k half = g / 2, channel sub-block cb = g % 2); lane 4q + p of the
+    // group addresses pixel row q, channels 16 cb + 4 p .. + 3 and receives channel 16 cb + (lane % 16) of the 4 rows.
+    const int l16 = lane & 15, q = l16 >> 2, p4 = l16 & 3, cb = (lane >> 4) & 1;
+    const int lane_off = (8 * half + q) * ROWB + (16 * cb + 4 * p4) * 2;
+
+    for (int tile = slice; tile < ntiles; tile += a.nslices) {
+        int sid = tile;
+        const int txi = sid % tiles_x;
+        sid /= tiles_x;
+        const int tyi = sid % tiles_y;
+        const int b = sid / tiles_y;
+        const int ty0 = tyi * WTH, tx0 = txi * WTW;
+
+        __syncthreads();
+        for (int u = tid; u < XUNITS; u += 512) {
+            const int c4 = u % (WC / 4), pix = u / (WC / 4);
+            const int py = pix / HTW, px = pix % HTW;
+            const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+            const int c = ci0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.cs)
+                v = *reinterpret_cast<const float4*>(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * a.cs + c);
+            const float xv[4] = {v.x, v.y, v.z, v.w};
+            bf16x4 ph, pm, pl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 h_, m_, l_;
+                split3(xv[e], h_, m_, l_);
+                ph[e] = h_; pm[e] = m_; pl[e] = l_;
+            }
+            const int off = (c4 >> 3) * XIMG + pix * ROWB + (c4 & 7) * 8;
+            *reinterpret_cast<bf16x4*>(sX + 0 * 2 * XIMG + off) = ph;
+            *reinterpret_cast<bf16x4*>(sX + 1 * 2 * XIMG + off) = pm;
+            *reinterpret_cast<bf16x4*>(sX + 2 * 2 * XIMG + off) = pl;
+        }
+        for (int u = tid; u < DUNITS; u += 512) {
+            const int c4 = u % (WC / 4), pix = u / (WC / 4);
+            const int py = pix / WTW, px = pix % WTW;
+            const int gy = ty0 + py, gx = tx0 + px;
+            const int c = co0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < a.H && gx < a.W && c < a.cout)
+                v = *reinterpret_cast<const float4*>(a.dz + ((size_t)(b * a.H + gy) * a.W + gx) * a.cout + c);
+            bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+            const float xv[4] = {v.x, v.y, v.z, v.w};
+            bf16x4 ph, pm, pl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 h_, m_, l_;
+                split3(xv[e], h_, m_, l_);
+                ph[e] = h_; pm[e] = m_; pl[e] = l_;
+            }
+            const int off = (c4 >> 3) * DIMG + pix * ROWB + (c4 & 7) * 8;
+            *reinterpret_cast<bf16x4*>(sD + 0 * 2 * DIMG + off) = ph;
+            *reinterpret_cast<bf16x4*>(sD + 1 * 2 * DIMG + off) = pm;
+            *reinterpret_cast<bf16x4*>(sD + 2 * 2 * DIMG + off) = pl;
+        }
+        __syncthreads();
+
+        if (group == 0)
+            tile_mfma<0, 5>(acc, sX, sD, cib, cob, lane_off, lane_off);
+        else
+            tile_mfma<5, 4>(acc, sX, sD, cib, cob, lane_off, lane_off);
+    }
+
+    const int co = co0 + cob * 32 + l31;
+    if (group == 0)
+        store_partial<0, 5>(acc, a, slice, ci0 + cib * 32, co, half);
+    else
+        store_partial<5, 4>(acc, a, slice, ci0 + cib * 32, co, half);
+
+    if (a.bias_partial && ci_tile == 0) {  // block-uniform
+        // threads with equal tid % 16 hold the same channel quad: combine the 32 of them in thread order
+        __syncthreads();
+        sBias[tid * 4 + 0] = bsum.x; sBias[tid * 4 + 1] = bsum.y; sBias[tid * 4 + 2] = bsum.z; sBias[tid * 4 + 3] = bsum.w;
+        __syncthreads();
+        if (tid < WC) {
+            const int c4 = tid >> 2, e = tid & 3;
+            float s = 0.f;
+            for (int k = 0; k < 32; ++k) s += sBias[(k * 16 + c4) * 4 + e];
+            if (co0 + tid < a.cout) a.bias_partial[(size_t)slice * a.cout + co0 + tid] = s;
+        }
+    }
+}
+
+constexpr int SMEM_BYTES = 6 * XIMG + 6 * DIMG;  // 76,800 B
+
+}  // namespace
+
+extern "C" int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off,
+                                   float* dbias, float* workspace, int nslices, int B, int H, int W, int accumulate,
+                                   float scale, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    PUNET_CHECK_ARG(x && dz && dw && workspace, "punet_conv_wgrad_x6: null pointer");
+    PUNET_CHECK_ARG(cs > 0 && cs % 4 == 0 && cout > 0 && cout % 4 == 0,
+                    "punet_conv_wgrad_x6: channels must be multiples of 4 (cs=%d cout=%d)", cs, cout);
+    PUNET_CHECK_ARG(ci_off >= 0 && ci_off + cs <= cin_total, "punet_conv_wgrad_x6: bad channel window");
+    PUNET_CHECK_ARG(nslices >= 1, "punet_conv_wgrad_x6: nslices must be >= 1");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)wgrad3x3_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) !=
+            hipSuccess) {
+            punet_set_error("punet_conv_wgrad_x6: cannot reserve %d bytes of LDS", SMEM_BYTES);
+            return PUNET_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    WgradX6Args a{};
+    a.x = x; a.cs = cs; a.dz = dz; a.cout = cout;
+    a.partial = workspace;
+    a.bias_partial = dbias ? workspace + (size_t)nslices * 9 * cs * cout : nullptr;
+    a.B = B; a.H = H; a.W = W; a.nslices = nslices;
+    dim3 grid(nslices, ceil_div(cs, WC) * ceil_div(cout, WC));
+    wgrad3x3_x6_kernel<<<grid, 512, SMEM_BYTES, stream>>>(a);
+    PUNET_LAUNCH_CHECK("wgrad3x3_x6");
+    const size_t n = (size_t)9 * cs * cout;
+    int rc = punet_launch_reduce_slabs(a.partial, nslices, n, 9 * cs, cout, cs, cin_total, ci_off, dw, accumulate, scale, stream);
+    if (rc != PUNET_OK) return rc;
+    if (dbias)
+        rc = punet_launch_reduce_slabs(a.bias_partial, nslices, (size_t)cout, 1, cout, 1, 1, 0, dbias, accumulate, scale, stream);
+    return rc;
+}

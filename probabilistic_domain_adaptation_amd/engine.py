@@ -457,6 +457,11 @@ class PUNetEngine:
             return
         ns = _lib.call("punet_wgrad_slices", x.C, c.cout, B, H, W)
         ws = self.ws.get("wgrad", _lib.call("punet_wgrad_workspace_floats", x.C, c.cout, c.k, ns))
+        if self.conv_mode == "x6" and c.k == 3:
+            self._timed("conv3x3_wgrad", 2.0 * B * H * W * x.C * c.cout * 9, "punet_conv_wgrad_x6", x.ptr, x.C, dz.data_ptr(),
+                        c.cout, dw, c.cin, ci_off, db if with_bias else None, ws.data_ptr(), ns, B, H, W, int(accumulate), 1.0,
+                        _stream())
+            return
         self._timed(f"conv{c.k}x{c.k}_wgrad", 2.0 * B * H * W * x.C * c.cout * c.k * c.k, "punet_conv_wgrad", x.ptr, x.C,
                     dz.data_ptr(), c.cout, dw, c.cin, ci_off, db if with_bias else None, ws.data_ptr(), ns, B, H, W, c.k,
                     int(accumulate), 1.0, _stream())

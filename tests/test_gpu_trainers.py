@@ -187,6 +187,7 @@ def test_validation_and_fit_loop(case, dev, tmp_path):
     assert 0.0 <= best <= 1.0 and tr._iteration == 4
     ck = torch.load(os.path.join(str(tmp_path), "checkpoints", "mt", "best.pt"), weights_only=False)
     assert set(["model_state", "teacher_state", "optimizer_state", "iteration", "best_metric"]) <= set(ck)
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoints", "mt", "latest.pt"), weights_only=False)  # == current state
     m2 = _model(case, dev)
     m2.load_state_dict(ck["teacher_state"])
     assert torch.equal(m2.flat_params.cpu(), tr.teacher.flat_params.cpu())

@@ -1,0 +1,45 @@
+"""GPU: the bf16x6 weight-gradient kernel (transposing LDS reads) against autograd at the fp32-MFMA kernel's tolerance."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(1, 8, 32, 8, 32), (2, 16, 16, 64, 64), (1, 24, 40, 32, 96), (2, 8, 8, 128, 128), (1, 64, 64, 96, 64), (1, 4, 4, 192, 160),
+         (2, 32, 64, 64, 32)]
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", CASES)
+def test_wgrad_x6(B, H, W, cin, cout):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from probabilistic_domain_adaptation_amd import _lib as L
+    S = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(21)
+    scale = torch.exp2(torch.randint(-8, 8, (B, cin, H, W), generator=g).float())
+    x = torch.randn(B, cin, H, W, generator=g) * scale
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)).requires_grad_(True)
+    b = torch.randn(cout, generator=g).requires_grad_(True)
+    dz = torch.randn(B, cout, H, W, generator=g) * torch.exp2(torch.randint(-6, 6, (B, cout, H, W), generator=g).float())
+    F.conv2d(x, w, b, padding=1).backward(dz)
+    X = x.permute(0, 2, 3, 1).contiguous().cuda()
+    DZ = dz.permute(0, 2, 3, 1).contiguous().cuda()
+    # embed in a wider weight (channel window) and test accumulate + scale too
+    tot, off = cin + 8, 8
+    dw = torch.zeros(3, 3, tot, cout, device="cuda")
+    db = torch.full((cout,), float("nan"), device="cuda")
+    ns = L.call("punet_wgrad_slices", cin, cout, B, H, W)
+    ws = torch.empty(L.call("punet_wgrad_workspace_floats", cin, cout, 3, ns), device="cuda")
+    L.call("punet_conv_wgrad_x6", X.data_ptr(), cin, DZ.data_ptr(), cout, dw.data_ptr(), tot, off, db.data_ptr(), ws.data_ptr(), ns,
+           B, H, W, 0, 1.0, S)
+    torch.cuda.synchronize()
+    got = dw[:, :, off:, :].permute(3, 2, 0, 1).cpu()
+    rel = lambda a_, b_: (a_ - b_).abs().max().item() / (b_.abs().max().item() + 1e-12)
+    assert rel(got, w.grad) < 5e-6
+    assert rel(db.cpu(), b.grad) < 5e-6
+    assert dw[:, :, :off, :].abs().max().item() == 0.0
+    L.call("punet_conv_wgrad_x6", X.data_ptr(), cin, DZ.data_ptr(), cout, dw.data_ptr(), tot, off, None, ws.data_ptr(), ns, B, H, W,
+           1, 0.5, S)
+    torch.cuda.synchronize()
+    assert rel(dw[:, :, off:, :].permute(3, 2, 0, 1).cpu(), 1.5 * w.grad) < 5e-6
