@@ -62,6 +62,8 @@ int punet_conv_dgrad_t(const float* dz, int cout, const float* wt, int cin_total
  *      planes[3][9][K/8][n_row][8] bf16, plane_stride elements apart; mode 0: K = cin, n = cout (forward);
  *      mode 1: K = cout, n = cin, taps flipped (input gradient).  The conv computes output channels
  *      [n_off, n_off + n_out) of the n_row available; mask/accumulate/relu/bias as in K1/K2. */
+/* tuning knob: 1 = 8-channel chunks, 2 workgroups per CU; 2 (default) = 16-channel chunks, 1 workgroup per CU */
+int punet_set_x6_variant(int v);
 int punet_split_weights_x6(const float* w, void* planes, long plane_stride, int cin, int cout, int ksize, int mode,
                            void* stream);
 int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride, int n_row,

@@ -1,6 +1,6 @@
 // K1x6 / K2x6: the 3x3 NHWC direct convolution (and its input gradient) at fp32 accuracy on the BF16 matrix cores.
 //
-// Same contraction, tiling and epilogue as conv_mfma.hip, but every fp32 operand is split into three bf16 planes
+// Same contraction, tiling and epilogue semantics as conv_mfma.hip, but every fp32 operand is split into three bf16 planes
 // x = h + m + l (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): 3 x 8 significand bits = fp32's 24) and each product
 // is evaluated as  hh + hm + mh + hl + lh + mm  with v_mfma_f32_32x32x16_bf16 accumulating in fp32.  The three dropped
 // terms (ml, lm, ll) are <= 2^-26 relative, below the rounding of an fp32 fmaf chain, so this is a PARITY mode (same
@@ -11,16 +11,23 @@
 // lanes 32-63 tap 2j+1 of the same 8 channels, so a chunk of 8 input channels is 5 MFMA K-steps (the 10th tap slot is a
 // zero weight slab).  That keeps the LDS images tiny - [pixel][8 ch] = one 16-byte ds_read_b128 per lane per plane,
 // consecutive pixels / output channels in consecutive 16-byte slots = conflict-free with no padding - 47 KB per
-// workgroup, 3 workgroups per CU.
+// workgroup, 2 workgroups per CU (222 VGPRs).  A variant with 16-channel chunks (9 K-steps, no zero tap, 88 KB, one
+// workgroup per CU) was measured 5-35 % SLOWER in the same process (tools/ab_x6v.py, round 1) and removed: with one wave
+// per SIMD nothing hides the staging phases.
 // Weights arrive pre-split (punet_split_weights_x6, once per optimizer step) as planes[3][tap][K/8][N][8] bf16, so their
 // staging is a pure copy; activations are split while being staged (v_cvt_pk_bf16_f32, ~6 VALU ops per element,
 // amortised over 9 taps x 64 output channels).
+// Epilogue: the accumulator tiles are transposed through LDS (per-wave region, no cross-wave traffic) so that every
+// global access is a 16-byte one - 16 lanes cover the 64 channels of a pixel = 256 contiguous bytes: 16 stores (+ 16 gate
+// loads for the ReLU backward, + 16 loads when accumulating) per thread and tile instead of 64 of each.  With the main
+// loop 1.5x faster than the fp32 kernel the 4-byte epilogue had become 40 % of the dgrad time on the 64-channel layers.
 #include "common.h"
 #include "punet_hip.h"
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TH = 8, TW = 32, TN = 64, CK = 8;
 constexpr int NUM_CU = 256;
@@ -67,9 +74,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     constexpr int XITER = (XUNITS + 255) / 256;
     constexpr int WUNITS = 3 * KK * TN;  // uint4 (8 bf16) units per chunk
     constexpr int WITER = (WUNITS + 255) / 256;
+    constexpr int WSLAB = (KK + 1) * TN;  // per plane, incl. the zero tap
+    constexpr int EPITCH = TN + 4;        // floats per pixel row of the epilogue staging image (16-byte aligned rows)
 
-    __shared__ uint4 sX[3][NPIX];             // [plane][pixel] -> 8 bf16 channels
-    __shared__ uint4 sW[3][(KK + 1) * TN];     // [plane][tap][n] -> 8 bf16 channels; tap 9 = zeros
+    // one LDS array: [3][NPIX] activation planes | [3][WSLAB] weight planes; the epilogue re-uses it as 4 x [32][EPITCH] fp32
+    __shared__ uint4 smem[3 * NPIX + 3 * WSLAB];
+    uint4* sX = smem;
+    uint4* sW = smem + 3 * NPIX;
+    static_assert(4 * 32 * EPITCH * 4 <= (3 * NPIX + 3 * WSLAB) * 16, "epilogue staging does not fit");
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -80,7 +92,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     const int K = a.c0 + a.c1;
     const int nchunks = K / CK;
 
-    for (int i = tid; i < 3 * TN; i += 256) sW[i / TN][KK * TN + i % TN] = make_uint4(0u, 0u, 0u, 0u);
+    auto zero_tap = [&]() {
+        for (int i = tid; i < 3 * TN; i += 256) sW[(i / TN) * WSLAB + KK * TN + i % TN] = make_uint4(0u, 0u, 0u, 0u);
+    };
+    zero_tap();
 
     auto decode = [&](int tile) {
         TileInfo t;
@@ -150,14 +165,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
             if (u < XUNITS) {
                 const int q = u % (CK / 4), pix = u / (CK / 4);
                 const float xv[4] = {rx[it].x, rx[it].y, rx[it].z, rx[it].w};
-                __bf16 hh[4], mm[4], ll[4];
+                bf16x4 ph, pm, pl;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) split3(xv[e], hh[e], mm[e], ll[e]);
-                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                bf16x4 ph = {hh[0], hh[1], hh[2], hh[3]}, pm = {mm[0], mm[1], mm[2], mm[3]}, pl = {ll[0], ll[1], ll[2], ll[3]};
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sX[0][pix]) + q * 8) = ph;
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sX[1][pix]) + q * 8) = pm;
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sX[2][pix]) + q * 8) = pl;
+                for (int e = 0; e < 4; ++e) {
+                    __bf16 h_, m_, l_;
+                    split3(xv[e], h_, m_, l_);
+                    ph[e] = h_; pm[e] = m_; pl[e] = l_;
+                }
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sX[0 * NPIX + pix]) + q * 8) = ph;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sX[1 * NPIX + pix]) + q * 8) = pm;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sX[2 * NPIX + pix]) + q * 8) = pl;
             }
         }
 #pragma unroll
@@ -165,34 +182,49 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
             const int u = tid + it * 256;
             if (u < WUNITS) {
                 const int n = u % TN, t = (u / TN) % KK, p = u / (TN * KK);
-                sW[p][t * TN + n] = rw[it];
+                sW[p * WSLAB + t * TN + n] = rw[it];
             }
         }
     };
 
+    // LDS-transposed epilogue: this wave's two 32-pixel rows, one row (m) at a time through its private staging region
     auto epilogue = [&](const TileInfo& ti) {
+        float* sE = reinterpret_cast<float*>(smem) + wave * 32 * EPITCH;
+        const int co4 = (lane & 15) * 4;           // this lane's 4 consecutive output channels after the transpose
+        const int prow = lane >> 4;                // pixel sub-row 0..3
+        const bool nok = ti.n0 + co4 < N;          // N is a multiple of 4
+        float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias && nok) bv4 = *reinterpret_cast<const float4*>(a.bias + (size_t)ti.b * a.bias_img_stride + ti.n0 + co4);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const int n = ti.n0 + nb * 32 + l31;
-            if (n >= N) continue;
-            float bv = 0.f;
-            if (a.bias) bv = a.bias[(size_t)ti.b * a.bias_img_stride + n];
+        for (int m = 0; m < 2; ++m) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int gy = ti.ty0 + 2 * wave + m;
-                if (gy >= a.H) continue;
+            for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int gx = ti.tx0 + mfma32_row(r, half);
-                    if (gx >= a.W) continue;
-                    const size_t idx = ((size_t)(ti.b * a.H + gy) * a.W + gx) * N + n;
-                    float v = acc[m][nb][r] + bv;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (a.mask) v = (a.mask[idx] > 0.f) ? v : 0.f;
-                    if (a.accumulate) v += a.y[idx];
-                    a.y[idx] = v;
+                for (int r = 0; r < 16; ++r) sE[mfma32_row(r, half) * EPITCH + nb * 32 + l31] = acc[m][nb][r];
+            __builtin_amdgcn_wave_barrier();  // same-wave LDS ops complete in order; keep the compiler from reordering
+            const int gy = ti.ty0 + 2 * wave + m;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int px = 4 * j + prow;
+                const float4 v4 = *reinterpret_cast<const float4*>(&sE[px * EPITCH + co4]);
+                const int gx = ti.tx0 + px;
+                if (gy < a.H && gx < a.W && nok) {
+                    const size_t idx = ((size_t)(ti.b * a.H + gy) * a.W + gx) * N + ti.n0 + co4;
+                    float4 v = make_float4(v4.x + bv4.x, v4.y + bv4.y, v4.z + bv4.z, v4.w + bv4.w);
+                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (a.mask) {
+                        const float4 g = *reinterpret_cast<const float4*>(a.mask + idx);
+                        v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f;
+                        v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
+                    }
+                    if (a.accumulate) {
+                        const float4 o = *reinterpret_cast<const float4*>(a.y + idx);
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    *reinterpret_cast<float4*>(a.y + idx) = v;
                 }
             }
+            __builtin_amdgcn_wave_barrier();
         }
     };
 
@@ -227,9 +259,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
 #pragma unroll
-                for (int m = 0; m < 2; ++m) av[p][m].u = sX[p][(2 * wave + m) * HTW + l31 + offA];
+                for (int m = 0; m < 2; ++m) av[p][m].u = sX[p * NPIX + (2 * wave + m) * HTW + l31 + offA];
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) bv[p][nb].u = sW[p][tapB * TN + nb * 32 + l31];
+                for (int nb = 0; nb < 2; ++nb) bv[p][nb].u = sW[p * WSLAB + tapB * TN + nb * 32 + l31];
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -246,8 +278,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                 }
         }
         if (ch == nchunks - 1) {
+            __syncthreads();  // every wave is done reading the operand images: the staging regions may overwrite them
             epilogue(ti);
             zero_acc();
+            __syncthreads();  // staging reads done before the zero tap (inside a staging region) is restored
+            zero_tap();
         }
         if (!has_next) break;
         tile = ntile;
@@ -268,16 +303,15 @@ __global__ __launch_bounds__(256) void split_weights_x6_kernel(const float* __re
         const int kc = (int)((i / N) % KC);
         const int tp = (int)(i / ((size_t)N * KC));
         const int t = mode == 0 ? tp : kk - 1 - tp;
-        __bf16 h[8], m[8], l[8];
+        bf16x8 vh, vm, vl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = kc * 8 + e;
             const float v = mode == 0 ? w[((size_t)t * cin + k) * cout + n] : w[((size_t)t * cin + n) * cout + k];
-            split3(v, h[e], m[e], l[e]);
+            __bf16 h_, m_, l_;
+            split3(v, h_, m_, l_);
+            vh[e] = h_; vm[e] = m_; vl[e] = l_;
         }
-        bf16x8 vh, vm, vl;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { vh[e] = h[e]; vm[e] = m[e]; vl[e] = l[e]; }
         *reinterpret_cast<bf16x8*>(planes + i * 8) = vh;
         *reinterpret_cast<bf16x8*>(planes + plane_stride + i * 8) = vm;
         *reinterpret_cast<bf16x8*>(planes + 2 * plane_stride + i * 8) = vl;
@@ -287,6 +321,11 @@ __global__ __launch_bounds__(256) void split_weights_x6_kernel(const float* __re
 int g_x6_wg_per_cu = 2;
 
 }  // namespace
+
+extern "C" int punet_set_x6_variant(int v) {
+    PUNET_CHECK_ARG(v == 1 || v == 2, "punet_set_x6_variant: 1 or 2");
+    return PUNET_OK;  // variant 2 (16-channel chunks, one workgroup per CU) was measured slower and removed; kept for ABI
+}
 
 extern "C" int punet_split_weights_x6(const float* w, void* planes, long plane_stride, int cin, int cout, int ksize, int mode,
                                       void* stream) {
@@ -308,7 +347,8 @@ extern "C" int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1
     PUNET_CHECK_ARG(x0 && wplanes && y, "punet_conv3x3_x6: null pointer");
     PUNET_CHECK_ARG(c0 > 0 && c0 % CK == 0 && c1 >= 0 && c1 % CK == 0 && (c1 == 0 || x1),
                     "punet_conv3x3_x6: source channels must be multiples of %d (c0=%d c1=%d)", CK, c0, c1);
-    PUNET_CHECK_ARG(n_out > 0 && n_off >= 0 && n_off + n_out <= n_row, "punet_conv3x3_x6: bad output-channel window");
+    PUNET_CHECK_ARG(n_out > 0 && n_out % 4 == 0 && n_off >= 0 && n_off + n_out <= n_row,
+                    "punet_conv3x3_x6: bad output-channel window (n_out must be a multiple of 4)");
     PUNET_CHECK_ARG(B > 0 && H > 0 && W > 0, "punet_conv3x3_x6: bad shape");
     ConvX6Args a{};
     a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1;
