@@ -30,14 +30,19 @@ NF = [64, 128, 256, 512]
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 # algorithmic GFLOP per patch at 512x512x1
-GFLOP = {"mean_teacher": {8: 3233.4, 16: 3269.6}, "punet_source": 2539.4, "inference": {8: 694.0, 16: 730.2}}
+GFLOP = {"mean_teacher": {8: 3233.4, 16: 3269.6}, "punet_source": 2539.4, "inference": {8: 694.0, 16: 730.2},
+         "fixmatch": {8: 3233.4, 16: 3269.6}, "adamt": {8: 5772.8, 16: 5809.1}, "adamatch": {8: 5772.8, 16: 5809.1}}
+# the same at 704x704x3 (BASELINE.json configs[3]); other shapes are scaled by the pixel count
+GFLOP_704x3 = {"mean_teacher": {8: 6125.7, 16: 6194.2}, "fixmatch": {8: 6125.7, 16: 6194.2}, "punet_source": 4811.4,
+               "inference": {8: 1314.3, 16: 1382.8}, "adamt": {8: 10937.1, 16: 11005.6}, "adamatch": {8: 10937.1, 16: 11005.6}}
 
 
-def synth(B, H, W, seed, dev):
+def synth(B, H, W, seed, dev, C=1):
     g = torch.Generator().manual_seed(seed)
     k = torch.ones(1, 1, 5, 5) / 25.0
-    blur = lambda t: torch.nn.functional.conv2d(torch.nn.functional.pad(t, (2, 2, 2, 2), mode="reflect"), k)
-    x = blur(torch.randn(B, 1, H, W, generator=g))
+    blur = lambda t: torch.nn.functional.conv2d(torch.nn.functional.pad(t, (2, 2, 2, 2), mode="reflect"),
+                                                k.expand(t.shape[1], 1, 5, 5), groups=t.shape[1])
+    x = blur(torch.randn(B, C, H, W, generator=g))
     x = (x - x.mean(dim=(1, 2, 3), keepdim=True)) / (x.std(dim=(1, 2, 3), keepdim=True) + 1e-7)
     x1 = x + 0.1 * torch.randn(x.shape, generator=g)
     x2 = 1.5 * blur(x) + 0.25 * torch.randn(x.shape, generator=g)
@@ -94,7 +99,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="mean_teacher", choices=["mean_teacher", "punet_source", "inference"])
+    ap.add_argument("--workload", default="mean_teacher", choices=["mean_teacher", "punet_source", "inference", "fixmatch", "adamt", "adamatch"])
+    ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--samples", type=int, default=8)
@@ -128,13 +134,14 @@ def main():
     from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
 
     B, H, W, N = a.batch, a.size, a.size, a.samples
-    model = ProbabilisticUnet(1, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=1)
+    model = ProbabilisticUnet(a.channels, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=1)
     teacher = None
-    if a.workload == "mean_teacher":
+    if a.workload in ("mean_teacher", "adamt"):
         import copy
         teacher = copy.deepcopy(model)
     opt = FusedAdam(model, lr=1e-5)
-    x, x1, x2, y = synth(B, H, W, 100 + rank, dev)  # every rank its own shard of the synthetic stream
+    x, x1, x2, y = synth(B, H, W, 100 + rank, dev, a.channels)  # every rank its own shard of the synthetic stream
+    xs, _, _, ys = synth(B, H, W, 500 + rank, dev, a.channels)  # source-domain batch of the joint trainers
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
     model.generator = gen
     if teacher is not None:
@@ -145,6 +152,12 @@ def main():
             FU.fused_self_training_step(model, teacher, opt, x1, x2, N, True, None, None, 0.999, 1e-5)
         elif a.workload == "punet_source":
             FU.fused_supervised_step(model, opt, x2, y, None, None, 1e-5)
+        elif a.workload == "fixmatch":  # fixmatch_trainer.py:67-95 (no EMA, pseudo-labels from the model itself)
+            FU.fused_self_training_step(model, model, opt, x1, x2, N, True, None, None, None, 1e-5)
+        elif a.workload == "adamt":  # adamt_trainer.py:89-128: one source + one target patch per "patch"
+            FU.fused_joint_step(model, teacher, opt, xs, ys, x1, x2, N, True, None, None, None, 0.999, True, 1e-5)
+        elif a.workload == "adamatch":  # adamatch_trainer.py:62-107
+            FU.fused_joint_step(model, model, opt, xs, ys, x1, x2, N, True, None, None, None, None, True, 1e-5)
         else:
             FU.pseudo_labels(model, x1, N, True)
 
@@ -176,9 +189,10 @@ def main():
 
     if rank == 0:
         patches = world * B * a.steps
-        gf = GFLOP[a.workload]
+        exact = (H, W, a.channels) == (704, 704, 3)
+        gf = (GFLOP_704x3 if exact else GFLOP)[a.workload]
         gf = gf[N] if isinstance(gf, dict) else gf
-        if (H, W) != (512, 512):
+        if not exact and (H, W) != (512, 512):
             gf = gf * (H * W) / (512 * 512)
         out = {
             "metric": "training patches/sec (512x512, N=8 MC samples)" if a.workload != "inference" else "inference patches/sec",
@@ -186,7 +200,7 @@ def main():
             "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"PUNet {a.workload} step: nf={NF}, latent 6, fcomb 3, BCE+KL, consensus masking, "
-                                   f"{H}x{W}x1 patches, batch {B}/GPU, N={N} MC samples, Adam lr 1e-5, EMA 0.999",
+                                   f"{H}x{W}x{a.channels} patches, batch {B}/GPU, N={N} MC samples, Adam lr 1e-5, EMA 0.999",
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "algorithmic_gflop_per_patch": gf,
                        "model_tflops_per_gpu": round(gf * patches / dt / world / 1e3, 2)},
