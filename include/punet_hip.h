@@ -62,10 +62,15 @@ int punet_conv_dgrad_t(const float* dz, int cout, const float* wt, int cin_total
  *      planes[3][9][K/8][n_row][8] bf16, plane_stride elements apart; mode 0: K = cin, n = cout (forward);
  *      mode 1: K = cout, n = cin, taps flipped (input gradient).  The conv computes output channels
  *      [n_off, n_off + n_out) of the n_row available; mask/accumulate/relu/bias as in K1/K2. */
-/* tuning knob: 1 = 8-channel chunks, 2 workgroups per CU; 2 (default) = 16-channel chunks, 1 workgroup per CU */
+/* tuning knob: 1 (default) = 4-wave workgroups, 2x2 MFMA tiles per wave; 2 = 8-wave workgroups, one pixel row per wave */
 int punet_set_x6_variant(int v);
 int punet_split_weights_x6(const float* w, void* planes, long plane_stride, int cin, int cout, int ksize, int mode,
                            void* stream);
+/* every 3x3 slab of a flat parameter buffer in ONE launch.  table (device, int64) has nconv+1 rows of 4:
+ * {w_off, cin, cout, first_unit}, first_unit = running sum of 9*cin*cout/8, last row = {0,0,0,total_units};
+ * slab j's planes land at planes + 3*w_off (bf16 elements) with plane stride 9*cin*cout. */
+int punet_split_weights_x6_batch(const float* flat, void* planes, const long* table, int nconv, long total_units,
+                                 int mode, void* stream);
 int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride, int n_row,
                      int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
                      int accumulate, int relu, int B, int H, int W, void* stream);

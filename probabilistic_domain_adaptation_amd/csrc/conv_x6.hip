@@ -545,6 +545,45 @@ __global__ __launch_bounds__(256) void split_weights_x6_kernel(const float* __re
     }
 }
 
+// Every 3x3 slab of a flat parameter buffer in one launch.  table[j] = {w_off, cin, cout, first_unit}; a unit is one
+// 16-byte (8 x bf16) group of one plane; table[nconv][3] = total units.  The planes of slab j start at planes + 3*w_off
+// with plane stride 9*cin*cout (same placement the per-slab entry point is called with by the engine).
+__global__ __launch_bounds__(256) void split_weights_x6_batch_kernel(const float* __restrict__ flat, __bf16* __restrict__ planes,
+                                                                     const long* __restrict__ table, int nconv, int mode) {
+    const long total = table[(size_t)nconv * 4 + 3];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = nconv - 1;  // last slab whose first_unit <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (table[(size_t)mid * 4 + 3] <= i) lo = mid; else hi = mid - 1;
+        }
+        const long w_off = table[(size_t)lo * 4 + 0];
+        const int cin = (int)table[(size_t)lo * 4 + 1], cout = (int)table[(size_t)lo * 4 + 2];
+        const long u = i - table[(size_t)lo * 4 + 3];
+        const float* w = flat + w_off;
+        __bf16* pl = planes + 3 * w_off;
+        const long plane_stride = 9l * cin * cout;
+        const int K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+        const int KC = K / 8;
+        const int n = (int)(u % N);
+        const int kc = (int)((u / N) % KC);
+        const int tp = (int)(u / ((long)N * KC));
+        const int t = mode == 0 ? tp : 8 - tp;
+        bf16x8 vh, vm, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = kc * 8 + e;
+            const float v = mode == 0 ? w[((size_t)t * cin + k) * cout + n] : w[((size_t)t * cin + n) * cout + k];
+            __bf16 h_, m_, l_;
+            split3(v, h_, m_, l_);
+            vh[e] = h_; vm[e] = m_; vl[e] = l_;
+        }
+        *reinterpret_cast<bf16x8*>(pl + u * 8) = vh;
+        *reinterpret_cast<bf16x8*>(pl + plane_stride + u * 8) = vm;
+        *reinterpret_cast<bf16x8*>(pl + 2 * plane_stride + u * 8) = vl;
+    }
+}
+
 int g_x6_wg_per_cu = 2;
 // 1 (default): 4-wave workgroups (2x2 tiles per wave); 2: 8-wave workgroups (one row per wave), 4 waves per SIMD.
 // A/B in one process (tools/ab_x6v.py): variant 2 is 3-8 % slower; MFMA-busy cycles vs duration put variant 1 at ~87 %
@@ -571,6 +610,17 @@ extern "C" int punet_split_weights_x6(const float* w, void* planes, long plane_s
     if (grid > 4096) grid = 4096;
     split_weights_x6_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(w, (__bf16*)planes, plane_stride, cin, cout, 9, mode);
     PUNET_LAUNCH_CHECK("split_weights_x6");
+    return PUNET_OK;
+}
+
+extern "C" int punet_split_weights_x6_batch(const float* flat, void* planes, const long* table, int nconv, long total_units,
+                                            int mode, void* stream) {
+    PUNET_CHECK_ARG(flat && planes && table && nconv > 0 && total_units > 0 && (mode == 0 || mode == 1),
+                    "punet_split_weights_x6_batch: bad args");
+    long grid = (total_units + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    split_weights_x6_batch_kernel<<<(int)grid, 256, 0, (hipStream_t)stream>>>(flat, (__bf16*)planes, table, nconv, mode);
+    PUNET_LAUNCH_CHECK("split_weights_x6_batch");
     return PUNET_OK;
 }
 

@@ -216,6 +216,7 @@ class PUNetEngine:
         if self.conv_mode not in ("x6", "f32"):
             raise ValueError("PUNET_CONV_MODE must be 'x6' or 'f32'")
         self._x6 = {}  # (flat.data_ptr(), mode) -> bf16 planes buffer [3 * numel]
+        self._x6_table = None  # (device int64 [nconv+1, 4], nconv, total_units) for punet_split_weights_x6_batch
         tab, self.l2_ntensors = layout.l2_chunk_table()
         self.l2_chunks = tab.to(self.device)
         self.l2_nchunks = tab.shape[0]
@@ -474,11 +475,17 @@ class PUNetEngine:
         if planes is None:
             planes = torch.empty(3 * flat.numel(), dtype=torch.bfloat16, device=self.device)
             self._x6[key] = planes
-        for c in self.L.convs.values():
-            if c.k != 3 or c.cin <= 4:
-                continue
-            _lib.call("punet_split_weights_x6", self._wptr(flat, c), planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cin,
-                      c.cout, 3, mode, _stream())
+        if self._x6_table is None:
+            rows, units = [], 0
+            for c in self.L.convs.values():
+                if c.k == 3 and c.cin > 4:
+                    rows.append([c.w_off, c.cin, c.cout, units])
+                    units += c.w_numel // 8
+            rows.append([0, 0, 0, units])
+            self._x6_table = (torch.tensor(rows, dtype=torch.int64, device=self.device), len(rows) - 1, units)
+        table, nconv, units = self._x6_table
+        _lib.call("punet_split_weights_x6_batch", flat.data_ptr(), planes.data_ptr(), table.data_ptr(), nconv, units, mode,
+                  _stream())
         return planes
 
     def prepare_forward_weights(self, flat):

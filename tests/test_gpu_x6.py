@@ -75,3 +75,27 @@ def test_conv_x6_fwd_and_dgrad(L, B, H, W, c0, c1, cout):
         ref = prev + x.grad[:, off:off + cs] * (mask > 0)
         assert rel_err(nchw(DX), ref) < 3e-6
         off += cs
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_split_weights_batch_matches_per_slab(L, mode):
+    """One table-driven launch over a flat buffer == one launch per slab (bit-identical planes)."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(8, 32), (32, 32), (64, 24), (40, 128)]  # (cin, cout); a gap between slabs stands in for biases
+    offs, off = [], 0
+    for cin, cout in shapes:
+        offs.append(off)
+        off += 9 * cin * cout + cout + 8 - (cout % 8 or 8) + 8
+    flat = torch.randn(off, generator=g).cuda()
+    one = torch.zeros(3 * off, dtype=torch.bfloat16, device="cuda")
+    bat = torch.zeros(3 * off, dtype=torch.bfloat16, device="cuda")
+    rows, units = [], 0
+    for (cin, cout), o in zip(shapes, offs):
+        L.call("punet_split_weights_x6", flat.data_ptr() + 4 * o, one.data_ptr() + 2 * 3 * o, 9 * cin * cout, cin, cout, 3, mode, S())
+        rows.append([o, cin, cout, units])
+        units += 9 * cin * cout // 8
+    rows.append([0, 0, 0, units])
+    table = torch.tensor(rows, dtype=torch.int64, device="cuda")
+    L.call("punet_split_weights_x6_batch", flat.data_ptr(), bat.data_ptr(), table.data_ptr(), len(shapes), units, mode, S())
+    torch.cuda.synchronize()
+    assert torch.equal(one.view(torch.int16), bat.view(torch.int16))
