@@ -8,12 +8,14 @@
 // MFMAs' worth of matrix-pipe time (bf16 issues 16x the MACs per cycle), i.e. 2.67x the fp32-MFMA peak.
 //
 // K blocking: one bf16 MFMA contracts K = 16.  A K block here is {two taps} x {8 channels}: lanes 0-31 carry tap 2j,
-// lanes 32-63 tap 2j+1 of the same 8 channels, so a chunk of 8 input channels is 5 MFMA K-steps (the 10th tap slot is a
-// zero weight slab).  That keeps the LDS images tiny - [pixel][8 ch] = one 16-byte ds_read_b128 per lane per plane,
-// consecutive pixels / output channels in consecutive 16-byte slots = conflict-free with no padding - 47 KB per
-// workgroup, 2 workgroups per CU (222 VGPRs).  A variant with 16-channel chunks (9 K-steps, no zero tap, 88 KB, one
-// workgroup per CU) was measured 5-35 % SLOWER in the same process (tools/ab_x6v.py, round 1) and removed: with one wave
-// per SIMD nothing hides the staging phases.
+// lanes 32-63 tap 2j+1 of the same 8 channels; taps 0-7 of a chunk of 8 input channels are 4 K-steps, and tap 8 is
+// contracted for an even/odd PAIR of chunks in one K-step (the activation image is double-buffered by chunk parity, the
+// even chunk's tap-8 weight slab parked in a tenth slot), so 16 channels cost 9 K-steps.  (The first version paired tap 8
+// with a zero slab - 10 K-steps, 10 % wasted MFMAs on a kernel that is matrix-pipe-power-bound.)  That keeps the LDS
+// images small - [pixel][8 ch] = one 16-byte ds_read_b128 per lane per plane, consecutive pixels / output channels in
+// consecutive 16-byte slots = conflict-free with no padding - 62 KB per workgroup, 2 workgroups per CU (<= 256 VGPRs).
+// A variant staging 16 channels at once (88 KB, one workgroup per CU) was measured 5-35 % SLOWER in the same process
+// (tools/ab_x6v.py, round 1) and removed: with one wave per SIMD nothing hides the staging phases.
 // Weights arrive pre-split (punet_split_weights_x6, once per optimizer step) as planes[3][tap][K/8][N][8] bf16, so their
 // staging is a pure copy; activations are split while being staged (v_cvt_pk_bf16_f32, ~6 VALU ops per element,
 // amortised over 9 taps x 64 output channels).
@@ -21,6 +23,7 @@
 // global access is a 16-byte one - 16 lanes cover the 64 channels of a pixel = 256 contiguous bytes: 16 stores (+ 16 gate
 // loads for the ReLU backward, + 16 loads when accumulating) per thread and tile instead of 64 of each.  With the main
 // loop 1.5x faster than the fp32 kernel the 4-byte epilogue had become 40 % of the dgrad time on the 64-channel layers.
+#include <type_traits>
 #include "common.h"
 #include "punet_hip.h"
 
@@ -69,19 +72,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     constexpr int KS = 3, KK = 9, PAD = 1;
     constexpr int HTH = TH + KS - 1, HTW = TW + KS - 1;
     constexpr int NPIX = HTH * HTW;
-    constexpr int NPAIR = (KK + 1) / 2;
     constexpr int XUNITS = NPIX * (CK / 4);
     constexpr int XITER = (XUNITS + 255) / 256;
     constexpr int WUNITS = 3 * KK * TN;  // uint4 (8 bf16) units per chunk
     constexpr int WITER = (WUNITS + 255) / 256;
-    constexpr int WSLAB = (KK + 1) * TN;  // per plane, incl. the zero tap
+    constexpr int WSLAB = (KK + 1) * TN;  // per plane: slots 0-7 = taps 0-7 of the current chunk, slot 8 = tap 8 of the
+                                          // current ODD chunk, slot 9 = tap 8 of the preceding EVEN chunk
+    constexpr int XBUF = 3 * NPIX;        // one activation image (3 planes); two of them, indexed by chunk parity
     constexpr int EPITCH = TN + 4;        // floats per pixel row of the epilogue staging image (16-byte aligned rows)
 
-    // one LDS array: [3][NPIX] activation planes | [3][WSLAB] weight planes; the epilogue re-uses it as 4 x [32][EPITCH] fp32
-    __shared__ uint4 smem[3 * NPIX + 3 * WSLAB];
+    // one LDS array: [2][3][NPIX] activation planes | [3][WSLAB] weight planes (63,360 B, 2 workgroups per CU); the epilogue
+    // re-uses it as 4 x [32][EPITCH] fp32
+    __shared__ uint4 smem[2 * XBUF + 3 * WSLAB];
     uint4* sX = smem;
-    uint4* sW = smem + 3 * NPIX;
-    static_assert(4 * 32 * EPITCH * 4 <= (3 * NPIX + 3 * WSLAB) * 16, "epilogue staging does not fit");
+    uint4* sW = smem + 2 * XBUF;
+    static_assert(4 * 32 * EPITCH * 4 <= (2 * XBUF + 3 * WSLAB) * 16, "epilogue staging does not fit");
+    static_assert((2 * XBUF + 3 * WSLAB) * 16 <= 65536, "static LDS limit");
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -91,11 +97,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     const int N = a.n_total;
     const int K = a.c0 + a.c1;
     const int nchunks = K / CK;
-
-    auto zero_tap = [&]() {
-        for (int i = tid; i < 3 * TN; i += 256) sW[(i / TN) * WSLAB + KK * TN + i % TN] = make_uint4(0u, 0u, 0u, 0u);
-    };
-    zero_tap();
 
     auto decode = [&](int tile) {
         TileInfo t;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     float4 rx[XITER];
     uint4 rw[WITER];
 
-    auto prefetch = [&](const TileInfo& ti, int ch) {
+    auto prefetch = [&](const TileInfo& ti, int ch) __attribute__((always_inline)) {
         const int kbase = ch * CK;
         const float* src;
         int cs, coff;
@@ -158,7 +159,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
         }
     };
 
-    auto commit = [&]() {
+    auto commit = [&](int par) __attribute__((always_inline)) {
+        uint4* sXc = sX + par * XBUF;
 #pragma unroll
         for (int it = 0; it < XITER; ++it) {
             const int u = tid + it * 256;
@@ -172,9 +174,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                     split3(xv[e], h_, m_, l_);
                     ph[e] = h_; pm[e] = m_; pl[e] = l_;
                 }
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sX[0 * NPIX + pix]) + q * 8) = ph;
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sX[1 * NPIX + pix]) + q * 8) = pm;
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sX[2 * NPIX + pix]) + q * 8) = pl;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[0 * NPIX + pix]) + q * 8) = ph;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[1 * NPIX + pix]) + q * 8) = pm;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[2 * NPIX + pix]) + q * 8) = pl;
             }
         }
 #pragma unroll
@@ -182,13 +184,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
             const int u = tid + it * 256;
             if (u < WUNITS) {
                 const int n = u % TN, t = (u / TN) % KK, p = u / (TN * KK);
-                sW[p * WSLAB + t * TN + n] = rw[it];
+                const int slot = t < KK - 1 ? t : KK - par;  // tap 8: slot 8 (odd chunk) or 9 (even chunk)
+                sW[p * WSLAB + slot * TN + n] = rw[it];
             }
         }
     };
 
     // LDS-transposed epilogue: this wave's two 32-pixel rows, one row (m) at a time through its private staging region
-    auto epilogue = [&](const TileInfo& ti) {
+    auto epilogue = [&](const TileInfo& ti) __attribute__((always_inline)) {
         float* sE = reinterpret_cast<float*>(smem) + wave * 32 * EPITCH;
         const int co4 = (lane & 15) * 4;           // this lane's 4 consecutive output channels after the transpose
         const int prow = lane >> 4;                // pixel sub-row 0..3
@@ -233,9 +236,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     int ch = 0;
     TileInfo ti = decode(tile);
     prefetch(ti, 0);
-    while (true) {
+    // one K-step: 24 MFMAs on the fragments at sX[offA + ...] (offset incl. the image base) and weight slot slotB; both
+    // arguments are per-half-wave values (lanes 0-31 and 32-63 contract different {tap, chunk} blocks of 8 channels)
+    auto kstep = [&](int offA, int slotB, bool zero_a) __attribute__((always_inline)) {
+        U4 av[3][2], bv[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                av[p][m].u = sX[offA + p * NPIX + (2 * wave + m) * HTW + l31];
+                if (zero_a) av[p][m].u = make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) bv[p][nb].u = sW[p * WSLAB + slotB * TN + nb * 32 + l31];
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                f32x16 c = acc[m][nb];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][m].v, bv[1][nb].v, c, 0, 0, 0);  // mm
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2][m].v, bv[0][nb].v, c, 0, 0, 0);  // lh
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][m].v, bv[2][nb].v, c, 0, 0, 0);  // hl
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][m].v, bv[0][nb].v, c, 0, 0, 0);  // mh
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][m].v, bv[1][nb].v, c, 0, 0, 0);  // hm
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][m].v, bv[0][nb].v, c, 0, 0, 0);  // hh
+                acc[m][nb] = c;
+            }
+    };
+    constexpr int OFF8 = ((KK - 1) / KS) * HTW + (KK - 1) % KS;  // halo offset of tap 8
+
+    // one chunk of 8 input channels; the parity of the chunk index is a compile-time constant so that every LDS offset
+    // below is an instruction immediate.  Returns true when this workgroup has no further work.
+    auto phase = [&](auto par_c) __attribute__((always_inline)) -> bool {
+        constexpr int par = decltype(par_c)::value;
         __syncthreads();
-        commit();
+        commit(par);
         __syncthreads();
         int nch = ch + 1, ntile = tile;
         TileInfo nti = ti;
@@ -247,47 +283,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
         const bool has_next = ntile < a.ntiles;
         if (has_next) prefetch(nti, nch);
 
+        // taps 0-7 of this chunk, two per K-step: lanes 0-31 tap 2j, lanes 32-63 tap 2j+1
 #pragma unroll
-        for (int j = 0; j < NPAIR; ++j) {
-            // this lane's tap: 2j (lanes 0-31) or 2j+1 (lanes 32-63); tap 9 does not exist: B reads the zero slab
+        for (int j = 0; j < (KK - 1) / 2; ++j) {
             const int t0 = 2 * j, t1 = 2 * j + 1;
-            const int offA0 = (t0 / KS) * HTW + t0 % KS;
-            const int offA1 = t1 < KK ? (t1 / KS) * HTW + t1 % KS : offA0;
-            const int offA = half ? offA1 : offA0;
-            const int tapB = half ? t1 : t0;  // t1 == KK -> zero slab
-            U4 av[3][2], bv[3][2];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m) av[p][m].u = sX[p * NPIX + (2 * wave + m) * HTW + l31 + offA];
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) bv[p][nb].u = sW[p * WSLAB + tapB * TN + nb * 32 + l31];
-            }
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    f32x16 c = acc[m][nb];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][m].v, bv[1][nb].v, c, 0, 0, 0);  // mm
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2][m].v, bv[0][nb].v, c, 0, 0, 0);  // lh
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][m].v, bv[2][nb].v, c, 0, 0, 0);  // hl
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][m].v, bv[0][nb].v, c, 0, 0, 0);  // mh
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][m].v, bv[1][nb].v, c, 0, 0, 0);  // hm
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][m].v, bv[0][nb].v, c, 0, 0, 0);  // hh
-                    acc[m][nb] = c;
-                }
+            const int offA0 = (t0 / KS) * HTW + t0 % KS, offA1 = (t1 / KS) * HTW + t1 % KS;
+            kstep(par * XBUF + (half ? offA1 : offA0), half ? t1 : t0, false);
         }
+        // tap 8 is contracted for two chunks at once (the even chunk's image is still resident in the other buffer), so 16
+        // channels cost 9 K-steps, not 10; a trailing unpaired chunk (odd chunk count) pairs its tap 8 with a zero A
+        if (par == 1)
+            kstep((half ? XBUF : 0) + OFF8, half ? KK - 1 : KK, false);
+        else if (ch == nchunks - 1)
+            kstep(OFF8, KK, half != 0);
         if (ch == nchunks - 1) {
             __syncthreads();  // every wave is done reading the operand images: the staging regions may overwrite them
             epilogue(ti);
             zero_acc();
-            __syncthreads();  // staging reads done before the zero tap (inside a staging region) is restored
-            zero_tap();
         }
-        if (!has_next) break;
         tile = ntile;
         ch = nch;
         ti = nti;
+        return !has_next;
+    };
+    while (true) {
+        if (phase(std::integral_constant<int, 0>{})) break;
+        if (ch == 0) continue;  // odd chunk count: the tile ended on an even chunk, the next tile starts even again
+        if (phase(std::integral_constant<int, 1>{})) break;
     }
 }
 
