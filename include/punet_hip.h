@@ -174,6 +174,19 @@ int punet_adam_ema(float* p, const float* g, float* m, float* v, float* teacher,
                    float beta1, float beta2, float eps, int step, float ema_momentum, int do_adam, void* stream);
 int punet_scale(float* x, long n, float s, void* stream);
 
+/* ---- K13: weak / strong view generation on NCHW fp32 planes (the transform chains of LIVECell/livecell_fm.py:43-67 and
+ *      MitoEM/common.py:50-68: my_standardize_torch (prob_utils/my_utils/util.py:9-14), then randomly applied Gaussian
+ *      blur, additive Gaussian noise, contrast).  The host draws the random decisions; the device does the arithmetic.
+ *      stats[b] = {mean, Bessel-corrected std} over the n = C*H*W values of item b (fp64 accumulation).
+ *      params[b] = {kernel size (odd, 1 = no blur), sigma, noise scale (0 = none), contrast alpha (1 = none)}.
+ *      out = cmean + alpha * ((blur((x - mean) / (std + eps)) + noise_scale * noise) - cmean); stats == NULL skips the
+ *      standardisation, noise == NULL the noise.  Blur: separable, taps exp(-0.5 (i/sigma)^2) / sum, reflect padding.
+ *      tmp: B*C*H*W floats, must not alias x or out. */
+size_t punet_standardize_workspace_doubles(int B);
+int punet_standardize_stats(const float* x, float* stats, double* workspace, int B, long n, void* stream);
+int punet_augment_view(const float* x, const float* stats, const float* noise, const float* params, int max_ksize,
+                       float contrast_mean, float eps, float* tmp, float* out, int B, int C, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -499,3 +499,44 @@ def mc_prediction(P: Params, cfg: PUNetConfig, raw, eps_n):
         st = punet_forward(P, cfg, raw, None, False)
         n = eps_n.shape[0]
         return torch.stack([torch.sigmoid(punet_sample(P, cfg, st, eps_n[i])) for i in range(n)], 0).sum(0) / n
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# View generation.  ``my_standardize`` follows prob_utils/my_utils/util.py:9-14 and is pinned by torch.
+# The three random transforms live in the un-vendored, un-pinned ``torch_em.transform.raw`` / ``torchvision`` ->
+# "parity unpinned": recalled definitions (torchvision GaussianBlur = reflect padding + depthwise conv with the outer
+# product of exp(-0.5 (i/sigma)^2)/sum taps; AdditiveGaussianNoise = x + N(0, scale); RandomContrast = mean + alpha (x - mean)).
+# The call sites that fix the parameter ranges are LIVECell/livecell_fm.py:43-67 and MitoEM/common.py:50-68.
+# ----------------------------------------------------------------------------------------------------------------------
+def my_standardize(x: torch.Tensor, eps: float = 1e-7) -> torch.Tensor:
+    """util.py:9-14 on one item: (x - mean) / (std + eps), torch's Bessel-corrected std."""
+    x = x.clone().float()
+    x -= x.mean()
+    x /= (x.std() + eps)
+    return x
+
+
+def gaussian_taps(ksize: int, sigma: float) -> torch.Tensor:
+    half = (ksize - 1) * 0.5
+    t = torch.linspace(-half, half, steps=ksize)
+    pdf = torch.exp(-0.5 * (t / sigma).pow(2)) if ksize > 1 else torch.ones(1)
+    return pdf / pdf.sum()
+
+
+def augment_view(x: torch.Tensor, params, noise: Optional[torch.Tensor], contrast_mean: float = 0.0,
+                 standardize: bool = True, eps: float = 1e-7) -> torch.Tensor:
+    """x [B,C,H,W]; params[b] = (ksize, sigma, noise_scale, alpha); noise [B,C,H,W] ~ N(0,1) or None."""
+    out = []
+    for b in range(x.shape[0]):
+        ks, sigma, nscale, alpha = int(params[b][0]), float(params[b][1]), float(params[b][2]), float(params[b][3])
+        v = my_standardize(x[b], eps) if standardize else x[b].clone().float()
+        if ks > 1:
+            k1 = gaussian_taps(ks, sigma)
+            k2 = torch.outer(k1, k1)[None, None].expand(v.shape[0], 1, ks, ks)
+            r = ks // 2
+            v = F.conv2d(F.pad(v[None], (r, r, r, r), mode="reflect"), k2, groups=v.shape[0])[0]
+        if noise is not None and nscale != 0.0:
+            v = v + nscale * noise[b]
+        v = contrast_mean + alpha * (v - contrast_mean)
+        out.append(v)
+    return torch.stack(out)

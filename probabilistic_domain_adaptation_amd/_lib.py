@@ -61,11 +61,14 @@ _SIGS = {
     "punet_l2_reg_add_grad": (_i, [_p, _p, _p, _i, _p, _f, _p]),
     "punet_adam_ema": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _f, _i, _p]),
     "punet_scale": (_i, [_p, _l, _f, _p]),
+    "punet_standardize_workspace_doubles": (_sz, [_i]),
+    "punet_standardize_stats": (_i, [_p, _p, _p, _i, _l, _p]),
+    "punet_augment_view": (_i, [_p, _p, _p, _p, _i, _f, _f, _p, _p, _i, _i, _i, _i, _p]),
 }
 
 _NO_WRAP = {"punet_last_error", "punet_build_info", "punet_device_ok", "punet_wgrad_workspace_floats",
             "punet_wgrad_slices", "punet_small_wgrad_workspace_floats", "punet_chan_sum_workspace_floats",
-            "punet_dot_bwd_workspace_floats", "punet_loss_workspace_floats"}
+            "punet_dot_bwd_workspace_floats", "punet_loss_workspace_floats", "punet_standardize_workspace_doubles"}
 
 _lib = None
 _fn = {}
