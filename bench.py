@@ -2,17 +2,23 @@
 """Benchmark of the hot path: training patches/s of the PUNet Mean-Teacher step on 512x512 LIVECell-shaped synthetic
 patches (BASELINE.json metric), N GPUs of one node, one process per GPU, RCCL all-reduce of the flat gradient.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mean_teacher|punet_source|inference]
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+                  [--workload mean_teacher|punet_source|inference|fixmatch|adamt|adamatch] [--channels C] [--size S]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
 One "step" = one Mean-Teacher iteration on a batch of 4 patches per GPU (mean_teacher_trainer.py:101-131):
 teacher forward + N=8 Monte-Carlo samples + consensus masking, student forward, ELBO (BCE + KL) + L2 regulariser,
 full backward, gradient all-reduce, Adam, EMA teacher update.  Inputs are resident in HBM before the timed region.
-fp32 everywhere (parity mode: exact-fp32 MFMA, logits within 1e-3 of the reference); nothing is skipped or cached.
+fp32 storage and fp32-accurate arithmetic everywhere (default conv arithmetic "x6": every fp32 product evaluated as six
+bf16 MFMAs with fp32 accumulation, logits within 1e-3 of the reference, masks bit-exact); nothing is skipped or cached.
+`--conv-mode f32` selects the fp32-input MFMA kernels (same tolerances); `--conv-mode x3|bf16` are the opt-in
+reduced-precision fast modes (the reference scripts' mixed_precision=True analogue) - their lines say so in `dtype`
+and are NOT the headline number.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel = the 3x3 MFMA
-convolution, algorithmic FLOPs / HIP-event duration measured live in the timed region, against the 157.3 TFLOP/s fp32
-matrix peak) and `cpu_baseline` (the CPU oracle = a port of the reference's path, timed on the host cores, rank 0, N=1).
+convolution, algorithmic FLOPs / HIP-event duration measured live in the timed region, against the matrix peak of the
+arithmetic in use) and `cpu_baseline` (the CPU oracle = a port of the reference's path, timed on the host cores,
+rank 0, N=1).
 """
 import argparse
 import json
@@ -104,6 +110,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--samples", type=int, default=8)
+    ap.add_argument("--conv-mode", default=None, choices=["x6", "f32", "x3", "bf16"],
+                    help="3x3 conv arithmetic (default: $PUNET_CONV_MODE or x6); x3/bf16 are reduced-precision fast modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI; the default) or gloo (rehearsal on one GPU)")
@@ -134,7 +142,8 @@ def main():
     from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
 
     B, H, W, N = a.batch, a.size, a.size, a.samples
-    model = ProbabilisticUnet(a.channels, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=1)
+    model = ProbabilisticUnet(a.channels, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=1,
+                              conv_mode=a.conv_mode)
     teacher = None
     if a.workload in ("mean_teacher", "adamt"):
         import copy
@@ -198,16 +207,22 @@ def main():
             "metric": "training patches/sec (512x512, N=8 MC samples)" if a.workload != "inference" else "inference patches/sec",
             "value": round(patches / dt, 4), "unit": "patches/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": {"x6": "f32", "f32": "f32", "x3": "bf16x3 (fp32 storage, 16-bit significand products; reduced precision)",
+                      "bf16": "bf16 (fp32 storage; reduced precision)"}[eng.conv_mode], "data": "synthetic",
             "config": {"workload": f"PUNet {a.workload} step: nf={NF}, latent 6, fcomb 3, BCE+KL, consensus masking, "
                                    f"{H}x{W}x{a.channels} patches, batch {B}/GPU, N={N} MC samples, Adam lr 1e-5, EMA 0.999",
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "algorithmic_gflop_per_patch": gf,
                        "model_tflops_per_gpu": round(gf * patches / dt / world / 1e3, 2)},
         }
-        out["config"]["conv_arithmetic"] = (
-            "3x3 convs fwd+dgrad: fp32 operands split into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate "
-            "(fp32-accurate); wgrad and 1x1: fp32-input MFMA" if eng.conv_mode == "x6" else "fp32-input MFMA everywhere")
+        out["config"]["conv_arithmetic"] = {
+            "x6": "3x3 convs fwd+dgrad+wgrad: fp32 operands split into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 "
+                  "accumulate (fp32-accurate); 1x1 convs: fp32-input MFMA",
+            "f32": "fp32-input MFMA everywhere",
+            "x3": "REDUCED PRECISION fast mode: 3x3 convs with 2 bf16 planes per operand, 3 bf16 MFMAs per product "
+                  "(16 significand bits), fp32 accumulate and storage; 1x1 convs fp32-input MFMA",
+            "bf16": "REDUCED PRECISION fast mode: 3x3 convs in plain bf16 (1 MFMA per product), fp32 accumulate and "
+                    "storage; 1x1 convs fp32-input MFMA"}[eng.conv_mode]
         if prof:
             agg = {}
             for kind, fl, e0, e1 in prof:
@@ -231,14 +246,17 @@ def main():
                 pass
             if k3:
                 ach = k3[0] / k3[1] / 1e12
-                if eng.conv_mode == "x6":
-                    # six bf16 MFMAs per fp32-accurate product: the roofline of THIS arithmetic is the bf16 dense peak / 6
-                    peak = BF16_MFMA_PEAK_TFLOPS / 6.0
-                    kname = "conv3x3_x6_kernel (3x3 NHWC direct conv forward, fp32-accurate 3-plane bf16 split on BF16 MFMA)"
-                    pnote = (f"bf16 dense MFMA peak {BF16_MFMA_PEAK_TFLOPS} TFLOP/s / 6 MFMAs per product = {peak:.1f} TFLOP/s of "
-                             f"algorithmic fp32 work; executed bf16 MFMA rate = 6 x achieved = {6 * ach:.0f} TFLOP/s "
-                             f"({6 * ach / BF16_MFMA_PEAK_TFLOPS:.3f} of the bf16 peak); for reference the fp32-input MFMA "
-                             f"peak is {FP32_MFMA_PEAK_TFLOPS} TFLOP/s (frac {ach / FP32_MFMA_PEAK_TFLOPS:.3f})")
+                if eng.x6:
+                    # n bf16 MFMAs per product: the roofline of THIS arithmetic is the bf16 dense peak / n
+                    n = {"x6": 6, "x3": 3, "bf16": 1}[eng.conv_mode]
+                    peak = BF16_MFMA_PEAK_TFLOPS / n
+                    kname = f"conv3x3_x6_kernel<{(n + 1) // 2 if n > 1 else 1} planes> (3x3 NHWC direct conv forward on BF16 MFMA)"
+                    pnote = (f"bf16 dense MFMA peak {BF16_MFMA_PEAK_TFLOPS} TFLOP/s / {n} MFMAs per product = {peak:.1f} TFLOP/s of "
+                             f"algorithmic work; executed bf16 MFMA rate = {n} x achieved = {n * ach:.0f} TFLOP/s "
+                             f"({n * ach / BF16_MFMA_PEAK_TFLOPS:.3f} of the bf16 peak; a register-only MFMA loop with "
+                             f"random operands sustains ~1790 TFLOP/s on this part, profiles/r01/mfma_peak_microbench.log); "
+                             f"for reference the fp32-input MFMA peak is {FP32_MFMA_PEAK_TFLOPS} TFLOP/s "
+                             f"(frac {ach / FP32_MFMA_PEAK_TFLOPS:.3f})")
                     traffic, traffic_note = None, "PMC passes were collected for the fp32-MFMA kernel only (profiles/r01)"
                 else:
                     peak = FP32_MFMA_PEAK_TFLOPS

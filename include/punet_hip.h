@@ -64,6 +64,10 @@ int punet_conv_dgrad_t(const float* dz, int cout, const float* wt, int cin_total
  *      [n_off, n_off + n_out) of the n_row available; mask/accumulate/relu/bias as in K1/K2. */
 /* tuning knob: 1 (default) = 4-wave workgroups, 2x2 MFMA tiles per wave; 2 = 8-wave workgroups, one pixel row per wave */
 int punet_set_x6_variant(int v);
+/* bf16 products per fp32 product for K1x6/K2x6/K3x6 (process state): 6 (default) = fp32-accurate parity arithmetic;
+ * 3 = two planes, hh+hm+mh, 16 significand bits; 1 = plain bf16.  3 and 1 are opt-in fast modes, the counterpart of the
+ * reference scripts' mixed_precision=True (LIVECell/livecell_mt.py:107); they are NOT parity modes. */
+int punet_set_x6_products(int n);
 int punet_split_weights_x6(const float* w, void* planes, long plane_stride, int cin, int cout, int ksize, int mode,
                            void* stream);
 /* every 3x3 slab of a flat parameter buffer in ONE launch.  table (device, int64) has nconv+1 rows of 4:

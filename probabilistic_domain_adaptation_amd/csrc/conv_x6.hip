@@ -68,26 +68,29 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)r2;
 }
 
+// NP = number of bf16 planes per operand: 3 -> six products (fp32-accurate, the parity arithmetic); 2 -> hh + hm + mh
+// (16 significand bits, opt-in fast mode); 1 -> plain bf16 (opt-in).
+template <int NP>
 __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     constexpr int KS = 3, KK = 9, PAD = 1;
     constexpr int HTH = TH + KS - 1, HTW = TW + KS - 1;
     constexpr int NPIX = HTH * HTW;
     constexpr int XUNITS = NPIX * (CK / 4);
     constexpr int XITER = (XUNITS + 255) / 256;
-    constexpr int WUNITS = 3 * KK * TN;  // uint4 (8 bf16) units per chunk
+    constexpr int WUNITS = NP * KK * TN;  // uint4 (8 bf16) units per chunk
     constexpr int WITER = (WUNITS + 255) / 256;
     constexpr int WSLAB = (KK + 1) * TN;  // per plane: slots 0-7 = taps 0-7 of the current chunk, slot 8 = tap 8 of the
                                           // current ODD chunk, slot 9 = tap 8 of the preceding EVEN chunk
-    constexpr int XBUF = 3 * NPIX;        // one activation image (3 planes); two of them, indexed by chunk parity
+    constexpr int XBUF = NP * NPIX;       // one activation image (NP planes); two of them, indexed by chunk parity
     constexpr int EPITCH = TN + 4;        // floats per pixel row of the epilogue staging image (16-byte aligned rows)
+    constexpr int OPERANDS = 2 * XBUF + NP * WSLAB, STAGING = 4 * 32 * EPITCH / 4;  // in uint4 units
 
-    // one LDS array: [2][3][NPIX] activation planes | [3][WSLAB] weight planes (63,360 B, 2 workgroups per CU); the epilogue
-    // re-uses it as 4 x [32][EPITCH] fp32
-    __shared__ uint4 smem[2 * XBUF + 3 * WSLAB];
+    // one LDS array: [2][NP][NPIX] activation planes | [NP][WSLAB] weight planes (63,360 B at NP = 3, 2 workgroups per CU);
+    // the epilogue re-uses it as 4 x [32][EPITCH] fp32
+    __shared__ uint4 smem[OPERANDS > STAGING ? OPERANDS : STAGING];
     uint4* sX = smem;
     uint4* sW = smem + 2 * XBUF;
-    static_assert(4 * 32 * EPITCH * 4 <= (2 * XBUF + 3 * WSLAB) * 16, "epilogue staging does not fit");
-    static_assert((2 * XBUF + 3 * WSLAB) * 16 <= 65536, "static LDS limit");
+    static_assert(OPERANDS * 16 <= 65536, "static LDS limit");
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -175,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                     ph[e] = h_; pm[e] = m_; pl[e] = l_;
                 }
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[0 * NPIX + pix]) + q * 8) = ph;
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[1 * NPIX + pix]) + q * 8) = pm;
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[2 * NPIX + pix]) + q * 8) = pl;
+                if (NP > 1) *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[(NP > 1) * NPIX + pix]) + q * 8) = pm;
+                if (NP > 2) *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[(NP > 2) * 2 * NPIX + pix]) + q * 8) = pl;
             }
         }
 #pragma unroll
@@ -239,9 +242,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     // one K-step: 24 MFMAs on the fragments at sX[offA + ...] (offset incl. the image base) and weight slot slotB; both
     // arguments are per-half-wave values (lanes 0-31 and 32-63 contract different {tap, chunk} blocks of 8 channels)
     auto kstep = [&](int offA, int slotB, bool zero_a) __attribute__((always_inline)) {
-        U4 av[3][2], bv[3][2];
+        constexpr int P1 = NP > 1 ? 1 : 0, P2 = NP > 2 ? 2 : 0;  // plane indices that exist for this NP
+        U4 av[NP][2], bv[NP][2];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 av[p][m].u = sX[offA + p * NPIX + (2 * wave + m) * HTW + l31];
@@ -255,11 +259,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
                 f32x16 c = acc[m][nb];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][m].v, bv[1][nb].v, c, 0, 0, 0);  // mm
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2][m].v, bv[0][nb].v, c, 0, 0, 0);  // lh
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][m].v, bv[2][nb].v, c, 0, 0, 0);  // hl
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1][m].v, bv[0][nb].v, c, 0, 0, 0);  // mh
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][m].v, bv[1][nb].v, c, 0, 0, 0);  // hm
+                if (NP > 2) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[P1][m].v, bv[P1][nb].v, c, 0, 0, 0);  // mm
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[P2][m].v, bv[0][nb].v, c, 0, 0, 0);   // lh
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][m].v, bv[P2][nb].v, c, 0, 0, 0);   // hl
+                }
+                if (NP > 1) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[P1][m].v, bv[0][nb].v, c, 0, 0, 0);  // mh
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][m].v, bv[P1][nb].v, c, 0, 0, 0);  // hm
+                }
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][m].v, bv[0][nb].v, c, 0, 0, 0);  // hh
                 acc[m][nb] = c;
             }
@@ -615,6 +623,15 @@ int g_x6_variant = 1;
 
 }  // namespace
 
+// shared with wgrad_x6.hip: bf16 planes per operand (3 = six products = the fp32-accurate parity arithmetic)
+int g_punet_x6_planes = 3;
+
+extern "C" int punet_set_x6_products(int n) {
+    PUNET_CHECK_ARG(n == 6 || n == 3 || n == 1, "punet_set_x6_products: 6 (fp32-accurate), 3 (16-bit significand) or 1 (bf16)");
+    g_punet_x6_planes = n == 6 ? 3 : (n == 3 ? 2 : 1);
+    return PUNET_OK;
+}
+
 extern "C" int punet_set_x6_variant(int v) {
     PUNET_CHECK_ARG(v == 1 || v == 2, "punet_set_x6_variant: 1 or 2");
     g_x6_variant = v;
@@ -662,7 +679,7 @@ extern "C" int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1
     a.y = y; a.n_total = n_out; a.mask = mask; a.accumulate = accumulate; a.relu = relu;
     a.B = B; a.H = H; a.W = W;
     a.ntiles = B * ceil_div(H, TH) * ceil_div(W, TW) * ceil_div(n_out, TN);
-    if (g_x6_variant == 2) {
+    if (g_x6_variant == 2 && g_punet_x6_planes == 3) {
         const int cap8 = 2 * NUM_CU;
         const int grid8 = a.ntiles < cap8 ? a.ntiles : cap8;
         conv3x3_x6w8_kernel<<<grid8, 512, 0, (hipStream_t)stream>>>(a);
@@ -671,7 +688,12 @@ extern "C" int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1
     }
     const int cap = g_x6_wg_per_cu * NUM_CU;
     const int grid = a.ntiles < cap ? a.ntiles : cap;
-    conv3x3_x6_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    if (g_punet_x6_planes == 3)
+        conv3x3_x6_kernel<3><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    else if (g_punet_x6_planes == 2)
+        conv3x3_x6_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    else
+        conv3x3_x6_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
     PUNET_LAUNCH_CHECK("conv3x3_x6");
     return PUNET_OK;
 }

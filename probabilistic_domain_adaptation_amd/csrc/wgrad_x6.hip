@@ -58,32 +58,37 @@ __device__ __forceinline__ s16x4 tr_read(const char* lds_base, int byte_off) {
 }
 
 // taps [T0, T0 + NT) of one staged tile.  aoff/boff: this lane's byte offset inside an image (see kernel body).
-template <int T0, int NT>
+template <int NP, int T0, int NT>
 __device__ __forceinline__ void tile_mfma(f32x16 (&acc)[5], const char* sX, const char* sD, int cib, int cob, int aoff, int boff) {
+    constexpr int P1 = NP > 1 ? 1 : 0, P2 = NP > 2 ? 2 : 0;  // plane indices that exist for this NP
 #pragma unroll 1
     for (int s = 0; s < NPD / 16; ++s) {
         const int row = (16 * s) / WTW, col0 = (16 * s) % WTW;
-        Frag b[3];
+        Frag b[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int r = 0; r < 2; ++r)
                 b[p].half4[r] = tr_read(sD, (p * 2 + cob) * DIMG + (16 * s + 4 * r) * ROWB + boff);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
             const int t = T0 + tt, ky = t / 3, kx = t % 3;
-            Frag a[3];
+            Frag a[NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
                     a[p].half4[r] = tr_read(sX, (p * 2 + cib) * XIMG + ((row + ky) * HTW + col0 + kx + 4 * r) * ROWB + aoff);
             f32x16 c = acc[tt];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].v, b[1].v, c, 0, 0, 0);  // mm
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2].v, b[0].v, c, 0, 0, 0);  // lh
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[2].v, c, 0, 0, 0);  // hl
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].v, b[0].v, c, 0, 0, 0);  // mh
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[1].v, c, 0, 0, 0);  // hm
+            if (NP > 2) {
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P1].v, b[P1].v, c, 0, 0, 0);  // mm
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P2].v, b[0].v, c, 0, 0, 0);   // lh
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[P2].v, c, 0, 0, 0);   // hl
+            }
+            if (NP > 1) {
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P1].v, b[0].v, c, 0, 0, 0);  // mh
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[P1].v, c, 0, 0, 0);  // hm
+            }
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[0].v, c, 0, 0, 0);  // hh
             acc[tt] = c;
         }
@@ -102,11 +107,13 @@ __device__ __forceinline__ void store_partial(const f32x16 (&acc)[5], const Wgra
         }
 }
 
+// NP = bf16 planes per operand (3: six products, fp32-accurate; 2: hh + hm + mh; 1: plain bf16), see conv_x6.hip
+template <int NP>
 __global__ __launch_bounds__(512, 4) void wgrad3x3_x6_kernel(WgradX6Args a) {
     constexpr int XUNITS = NPX * (WC / 4), DUNITS = NPD * (WC / 4);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sX = smem;                // [3 planes][2 ci blocks][NPX][32] bf16
-    char* sD = smem + 6 * XIMG;     // [3 planes][2 co blocks][NPD][32] bf16
+    char* sX = smem;                    // [NP planes][2 ci blocks][NPX][32] bf16
+    char* sD = smem + NP * 2 * XIMG;    // [NP planes][2 co blocks][NPD][32] bf16
     float* sBias = reinterpret_cast<float*>(smem);  // reused after the last tile
 
     const int tid = threadIdx.x;
@@ -160,8 +167,8 @@ __global__ __launch_bounds__(512, 4) void wgrad3x3_x6_kernel(WgradX6Args a) {
             }
             const int off = (c4 >> 3) * XIMG + pix * ROWB + (c4 & 7) * 8;
             *reinterpret_cast<bf16x4*>(sX + 0 * 2 * XIMG + off) = ph;
-            *reinterpret_cast<bf16x4*>(sX + 1 * 2 * XIMG + off) = pm;
-            *reinterpret_cast<bf16x4*>(sX + 2 * 2 * XIMG + off) = pl;
+            if (NP > 1) *reinterpret_cast<bf16x4*>(sX + (NP > 1) * 2 * XIMG + off) = pm;
+            if (NP > 2) *reinterpret_cast<bf16x4*>(sX + (NP > 2) * 4 * XIMG + off) = pl;
         }
         for (int u = tid; u < DUNITS; u += 512) {
             const int c4 = u % (WC / 4), pix = u / (WC / 4);
@@ -182,15 +189,15 @@ __global__ __launch_bounds__(512, 4) void wgrad3x3_x6_kernel(WgradX6Args a) {
             }
             const int off = (c4 >> 3) * DIMG + pix * ROWB + (c4 & 7) * 8;
             *reinterpret_cast<bf16x4*>(sD + 0 * 2 * DIMG + off) = ph;
-            *reinterpret_cast<bf16x4*>(sD + 1 * 2 * DIMG + off) = pm;
-            *reinterpret_cast<bf16x4*>(sD + 2 * 2 * DIMG + off) = pl;
+            if (NP > 1) *reinterpret_cast<bf16x4*>(sD + (NP > 1) * 2 * DIMG + off) = pm;
+            if (NP > 2) *reinterpret_cast<bf16x4*>(sD + (NP > 2) * 4 * DIMG + off) = pl;
         }
         __syncthreads();
 
         if (group == 0)
-            tile_mfma<0, 5>(acc, sX, sD, cib, cob, lane_off, lane_off);
+            tile_mfma<NP, 0, 5>(acc, sX, sD, cib, cob, lane_off, lane_off);
         else
-            tile_mfma<5, 4>(acc, sX, sD, cib, cob, lane_off, lane_off);
+            tile_mfma<NP, 5, 4>(acc, sX, sD, cib, cob, lane_off, lane_off);
     }
 
     const int co = co0 + cob * 32 + l31;
@@ -213,9 +220,29 @@ __global__ __launch_bounds__(512, 4) void wgrad3x3_x6_kernel(WgradX6Args a) {
     }
 }
 
-constexpr int SMEM_BYTES = 6 * XIMG + 6 * DIMG;  // 76,800 B
+constexpr int smem_bytes(int np) {
+    const int operands = np * 2 * (XIMG + DIMG);  // 76,800 B at NP = 3
+    return operands > 512 * 16 ? operands : 512 * 16;  // the bias staging (512 threads x float4) re-uses the region
+}
+
+template <int NP>
+int launch_wgrad(const WgradX6Args& a, dim3 grid, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)wgrad3x3_x6_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                smem_bytes(NP)) != hipSuccess) {
+            punet_set_error("punet_conv_wgrad_x6: cannot reserve %d bytes of LDS", smem_bytes(NP));
+            return PUNET_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    wgrad3x3_x6_kernel<NP><<<grid, 512, smem_bytes(NP), stream>>>(a);
+    return PUNET_OK;
+}
 
 }  // namespace
+
+extern int g_punet_x6_planes;  // conv_x6.hip (punet_set_x6_products)
 
 extern "C" int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off,
                                    float* dbias, float* workspace, int nslices, int B, int H, int W, int accumulate,
@@ -226,22 +253,15 @@ extern "C" int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int 
                     "punet_conv_wgrad_x6: channels must be multiples of 4 (cs=%d cout=%d)", cs, cout);
     PUNET_CHECK_ARG(ci_off >= 0 && ci_off + cs <= cin_total, "punet_conv_wgrad_x6: bad channel window");
     PUNET_CHECK_ARG(nslices >= 1, "punet_conv_wgrad_x6: nslices must be >= 1");
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)wgrad3x3_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) !=
-            hipSuccess) {
-            punet_set_error("punet_conv_wgrad_x6: cannot reserve %d bytes of LDS", SMEM_BYTES);
-            return PUNET_ERR_HIP;
-        }
-        attr_set = true;
-    }
     WgradX6Args a{};
     a.x = x; a.cs = cs; a.dz = dz; a.cout = cout;
     a.partial = workspace;
     a.bias_partial = dbias ? workspace + (size_t)nslices * 9 * cs * cout : nullptr;
     a.B = B; a.H = H; a.W = W; a.nslices = nslices;
     dim3 grid(nslices, ceil_div(cs, WC) * ceil_div(cout, WC));
-    wgrad3x3_x6_kernel<<<grid, 512, SMEM_BYTES, stream>>>(a);
+    int rc0 = g_punet_x6_planes == 3 ? launch_wgrad<3>(a, grid, stream)
+              : g_punet_x6_planes == 2 ? launch_wgrad<2>(a, grid, stream) : launch_wgrad<1>(a, grid, stream);
+    if (rc0 != PUNET_OK) return rc0;
     PUNET_LAUNCH_CHECK("wgrad3x3_x6");
     const size_t n = (size_t)9 * cs * cout;
     int rc = punet_launch_reduce_slabs(a.partial, nslices, n, 9 * cs, cout, cs, cin_total, ci_off, dw, accumulate, scale, stream);

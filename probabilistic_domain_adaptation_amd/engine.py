@@ -182,6 +182,18 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# bf16 products per fp32 product in the split-plane kernels; the library holds the current value as process state
+_X6_PRODUCTS = {"x6": 6, "x3": 3, "bf16": 1}
+_products_now = [None]
+
+
+def set_x6_products(n: int):
+    """The library keeps the product count as process state; route every change through here (tests too)."""
+    if _products_now[0] != n:
+        _lib.call("punet_set_x6_products", n)
+        _products_now[0] = n
+
+
 class Workspace:
     """Grow-only scratch buffers keyed by purpose (split-K slabs, reduction partials)."""
 
@@ -201,7 +213,7 @@ class PUNetEngine:
     """Enqueues the kernels for one model configuration on one GPU.  Stateless w.r.t. weights: every call takes the
     flat parameter tensor to use (student or teacher)."""
 
-    def __init__(self, layout: ParamLayout, device):
+    def __init__(self, layout: ParamLayout, device, conv_mode: Optional[str] = None):
         self.L = layout
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -210,11 +222,14 @@ class PUNetEngine:
         self.ws = Workspace(self.device)
         self.prof = None  # when a list: (kind, algorithmic FLOPs, start event, end event) per 3x3 MFMA launch
         self.wT = None  # flipped + transposed weight slabs for the dgrad pass (prepare_dgrad_weights)
-        # 3x3 conv arithmetic: "x6" = three-plane bf16 split on the BF16 matrix cores (fp32-accurate, ~1.55x faster),
-        # "f32" = fp32-input MFMA.  Both are parity modes with the same tolerances.
-        self.conv_mode = os.environ.get("PUNET_CONV_MODE", "x6")
-        if self.conv_mode not in ("x6", "f32"):
-            raise ValueError("PUNET_CONV_MODE must be 'x6' or 'f32'")
+        # 3x3 conv arithmetic.  Parity modes (same tolerances): "x6" = three-plane bf16 split on the BF16 matrix cores
+        # (fp32-accurate, default), "f32" = fp32-input MFMA.  Opt-in fast modes (the analogue of the reference scripts'
+        # mixed_precision=True, e.g. livecell_mt.py:107; NOT parity modes): "x3" = two planes, hh+hm+mh (16 significand
+        # bits, more than the fp16 autocast of the reference), "bf16" = one plane.  Storage stays fp32 in every mode.
+        self.conv_mode = conv_mode or os.environ.get("PUNET_CONV_MODE", "x6")
+        if self.conv_mode not in _X6_PRODUCTS and self.conv_mode != "f32":
+            raise ValueError("PUNET_CONV_MODE must be one of 'x6', 'f32', 'x3', 'bf16'")
+        self.x6 = self.conv_mode in _X6_PRODUCTS  # the split-plane kernel family
         self._x6 = {}  # (flat.data_ptr(), mode) -> bf16 planes buffer [3 * numel]
         self._x6_table = None  # (device int64 [nconv+1, 4], nconv, total_units) for punet_split_weights_x6_batch
         tab, self.l2_ntensors = layout.l2_chunk_table()
@@ -223,6 +238,8 @@ class PUNetEngine:
 
     def _timed(self, kind, flops, name, *args):
         """Launch through the C ABI; with self.prof set, bracket the launch with HIP events on the launch stream."""
+        if self.x6:
+            set_x6_products(_X6_PRODUCTS[self.conv_mode])
         if self.prof is None:
             return _lib.call(name, *args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -258,7 +275,7 @@ class PUNetEngine:
             assert x1 is None and c.k == 3
             _lib.call("punet_conv3x3_small_fwd", x0.ptr, cin, self._wptr(flat, c), self._bptr(flat, c), y.ptr, c.cout,
                       B, H, W, int(relu), _stream())
-        elif self.conv_mode == "x6" and c.k == 3:
+        elif self.x6 and c.k == 3:
             planes = self._x6[(flat.data_ptr(), 0)]
             self._timed("conv3x3_fwd", 2.0 * B * H * W * cin * c.cout * 9, "punet_conv3x3_x6", x0.ptr, x0.C,
                         x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0,
@@ -458,7 +475,7 @@ class PUNetEngine:
             return
         ns = _lib.call("punet_wgrad_slices", x.C, c.cout, B, H, W)
         ws = self.ws.get("wgrad", _lib.call("punet_wgrad_workspace_floats", x.C, c.cout, c.k, ns))
-        if self.conv_mode == "x6" and c.k == 3:
+        if self.x6 and c.k == 3:
             self._timed("conv3x3_wgrad", 2.0 * B * H * W * x.C * c.cout * 9, "punet_conv_wgrad_x6", x.ptr, x.C, dz.data_ptr(),
                         c.cout, dw, c.cin, ci_off, db if with_bias else None, ws.data_ptr(), ns, B, H, W, int(accumulate), 1.0,
                         _stream())
@@ -489,18 +506,18 @@ class PUNetEngine:
         return planes
 
     def prepare_forward_weights(self, flat):
-        if self.conv_mode == "x6":
+        if self.x6:
             self._split_x6(flat, 0)
 
     def prepare_dgrad_weights(self, flat):
         """Bring every conv weight slab into forward-kernel orientation for the input-gradient pass
         (wt[k*k-1-t][cout][cin] = w[t][cin][cout]); ~0.1 ms per step, after which dgrad IS the forward kernel."""
-        if self.conv_mode == "x6":
+        if self.x6:
             self._split_x6(flat, 1)
         if self.wT is None or self.wT.numel() != flat.numel():
             self.wT = torch.empty_like(flat)
         for c in self.L.convs.values():
-            if self.conv_mode == "x6" and c.k == 3:
+            if self.x6 and c.k == 3:
                 continue  # served by the x6 planes
             if c.cin > 4 and c.cin % 4 == 0 and c.cout % 8 == 0:
                 _lib.call("punet_flip_transpose_weights", self._wptr(flat, c), self.wT.data_ptr() + 4 * c.w_off, c.cin, c.cout,
@@ -509,7 +526,7 @@ class PUNetEngine:
     def _dgrad(self, flat, c: ConvP, dz, cin_off: int, cin: int, dx, mask_ptr, acc: int, B: int, H: int, W: int):
         """dx[..., cin_off : cin_off + cin] of conv c given dz (epilogue: ReLU gate by `mask`, accumulate)."""
         flops = 2.0 * B * H * W * cin * c.cout * c.k * c.k
-        if self.conv_mode == "x6" and c.k == 3:
+        if self.x6 and c.k == 3:
             planes = self._x6[(flat.data_ptr(), 1)]
             self._timed("conv3x3_dgrad", flops, "punet_conv3x3_x6", dz.data_ptr(), c.cout, None, 0,
                         planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cin, cin_off, None, 0, dx.data_ptr(), cin, mask_ptr, acc,

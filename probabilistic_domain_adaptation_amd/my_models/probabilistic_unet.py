@@ -75,7 +75,10 @@ class ProbabilisticUnet(nn.Module):
     (probabilistic_unet.py:227-237)."""
 
     def __init__(self, input_channels=1, num_classes=1, num_filters=[32, 64, 128, 192], latent_dim=6, no_convs_fcomb=4,
-                 beta=10.0, consensus_masking=False, rl_swap=False, device=None, seed: Optional[int] = None):
+                 beta=10.0, consensus_masking=False, rl_swap=False, device=None, seed: Optional[int] = None,
+                 conv_mode: Optional[str] = None):
+        """conv_mode (extension): None = $PUNET_CONV_MODE or "x6" (fp32-accurate); "x3" / "bf16" are the opt-in fast
+        modes standing in for the reference's mixed_precision=True (engine.PUNetEngine)."""
         super().__init__()
         self.input_channels = input_channels
         self.num_classes = num_classes
@@ -94,7 +97,7 @@ class ProbabilisticUnet(nn.Module):
         if dev is None or dev.type != "cuda":
             raise RuntimeError("ProbabilisticUnet (MI355X build) needs a ROCm GPU: there is no CPU fallback")
         self.layout = ParamLayout(input_channels, num_classes, self.num_filters, latent_dim, no_convs_fcomb)
-        self.engine = PUNetEngine(self.layout, dev)
+        self.engine = PUNetEngine(self.layout, dev, conv_mode)
         self._flat = torch.zeros(self.layout.numel, dtype=torch.float32, device=dev)
         self._views = self.layout.views(self._flat)
         for name, v in self._views.items():
@@ -135,7 +138,8 @@ class ProbabilisticUnet(nn.Module):
     def __deepcopy__(self, memo):
         """deepcopy(model) -> teacher (mean_teacher_trainer.py:40): a new flat buffer with the same values."""
         m = ProbabilisticUnet(self.input_channels, self.num_classes, self.num_filters, self.latent_dim, self.no_convs_fcomb,
-                              self.beta, self.consensus_masking, self.rl_swap, device=self.device, seed=0)
+                              self.beta, self.consensus_masking, self.rl_swap, device=self.device, seed=0,
+                              conv_mode=self.engine.conv_mode)
         with torch.no_grad():
             m._flat.copy_(self._flat)
         for p, q in zip(m.parameters(), self.parameters()):
