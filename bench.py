@@ -235,13 +235,17 @@ def main():
             k3 = agg.get("conv3x3_fwd")
             traffic, traffic_note = None, "not collected"
             try:  # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.py)
-                if a.workload == "mean_teacher" and (B, H, W, N) == (4, 512, 512, 8):
-                    pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")))
-                    traffic = round(pm["kernels"]["conv_mfma_kernel<3, false>"]["hbm_bytes_per_launch"])
+                if a.workload == "mean_teacher" and (B, H, W, N) == (4, 512, 512, 8) and eng.conv_mode in ("x6", "f32"):
+                    fn, key = {"x6": ("pmc_hbm_traffic_x6.json", "conv3x3_x6_kernel<3>"),
+                               "f32": ("pmc_hbm_traffic.json", "conv_mfma_kernel<3, false>")}[eng.conv_mode]
+                    pm = json.load(open(os.path.join(ROOT, "profiles", "r01", fn)))
+                    traffic = round(pm["kernels"][key]["hbm_bytes_per_launch"])
                     traffic_note = ("bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE in separate "
-                                    "passes of this same workload (profiles/r01/pmc_hbm_traffic.json); the kernel also serves the "
-                                    "dgrad launches, so this is the mean over forward and dgrad launches; FETCH_SIZE counts "
-                                    "Infinity-Cache refills of the per-chunk 32-B re-reads")
+                                    f"passes of this same workload (profiles/r01/{fn}); the kernel also serves the input-gradient "
+                                    "launches, so this is the mean over forward and input-gradient launches (algorithmic mean "
+                                    "over the same launches: 312 MB = activations in + out (+ ReLU gate) + weight planes); "
+                                    "FETCH_SIZE includes halo re-reads (1.33x) and Infinity-Cache refills of tiles shared by "
+                                    "the output-channel blocks")
             except Exception:
                 pass
             if k3:
@@ -257,7 +261,6 @@ def main():
                              f"random operands sustains ~1790 TFLOP/s on this part, profiles/r01/mfma_peak_microbench.log); "
                              f"for reference the fp32-input MFMA peak is {FP32_MFMA_PEAK_TFLOPS} TFLOP/s "
                              f"(frac {ach / FP32_MFMA_PEAK_TFLOPS:.3f})")
-                    traffic, traffic_note = None, "PMC passes were collected for the fp32-MFMA kernel only (profiles/r01)"
                 else:
                     peak = FP32_MFMA_PEAK_TFLOPS
                     kname = "conv_mfma_kernel<3,false> (3x3 NHWC direct conv forward, fp32 MFMA)"
