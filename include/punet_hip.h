@@ -62,8 +62,6 @@ int punet_conv_dgrad_t(const float* dz, int cout, const float* wt, int cin_total
  *      planes[3][9][K/8][n_row][8] bf16, plane_stride elements apart; mode 0: K = cin, n = cout (forward);
  *      mode 1: K = cout, n = cin, taps flipped (input gradient).  The conv computes output channels
  *      [n_off, n_off + n_out) of the n_row available; mask/accumulate/relu/bias as in K1/K2. */
-/* tuning knob: 1 (default) = 4-wave workgroups, 2x2 MFMA tiles per wave; 2 = 8-wave workgroups, one pixel row per wave */
-int punet_set_x6_variant(int v);
 /* bf16 products per fp32 product for K1x6/K2x6/K3x6 (process state): 6 (default) = fp32-accurate parity arithmetic;
  * 3 = two planes, hh+hm+mh, 16 significand bits; 1 = plain bf16.  3 and 1 are opt-in fast modes, the counterpart of the
  * reference scripts' mixed_precision=True (LIVECell/livecell_mt.py:107); they are NOT parity modes. */

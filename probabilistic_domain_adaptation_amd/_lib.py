@@ -24,7 +24,6 @@ _SIGS = {
     "punet_set_conv_wg_per_cu": (_i, [_i]),
     "punet_flip_transpose_weights": (_i, [_p, _p, _i, _i, _i, _p]),
     "punet_conv_dgrad_t": (_i, [_p, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "punet_set_x6_variant": (_i, [_i]),
     "punet_set_x6_products": (_i, [_i]),
     "punet_split_weights_x6": (_i, [_p, _p, _l, _i, _i, _i, _i, _p]),
     "punet_split_weights_x6_batch": (_i, [_p, _p, _p, _i, _l, _i, _p]),

@@ -14,8 +14,10 @@
 // with a zero slab - 10 K-steps, 10 % wasted MFMAs on a kernel that is matrix-pipe-power-bound.)  That keeps the LDS
 // images small - [pixel][8 ch] = one 16-byte ds_read_b128 per lane per plane, consecutive pixels / output channels in
 // consecutive 16-byte slots = conflict-free with no padding - 62 KB per workgroup, 2 workgroups per CU (<= 256 VGPRs).
-// A variant staging 16 channels at once (88 KB, one workgroup per CU) was measured 5-35 % SLOWER in the same process
-// (tools/ab_x6v.py, round 1) and removed: with one wave per SIMD nothing hides the staging phases.
+// Measured and removed in round 1 (same-process A/B): staging 16 channels at once (88 KB, one workgroup per CU): 5-35 %
+// slower - with one wave per SIMD nothing hides the staging phases; an 8-wave workgroup with one pixel row per wave
+// (128 VGPRs, 4 waves per SIMD): 3-8 % slower - consistent with tools/mfma_peak.hip, where 4 waves per SIMD sustain
+// less MFMA throughput than 1 or 2; a ping-pong MFMA/staging split of an 8-wave workgroup: 3-8 % slower.
 // Weights arrive pre-split (punet_split_weights_x6, once per optimizer step) as planes[3][tap][K/8][N][8] bf16, so their
 // staging is a pure copy; activations are split while being staged (v_cvt_pk_bf16_f32, ~6 VALU ops per element,
 // amortised over 9 taps x 64 output channels).
@@ -321,233 +323,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// 8-wave variant.  PMC on the 4-wave kernel above: each wave parks ~1.9k cycles per 8-channel chunk, almost all of it
-// in the s_waitcnt lgkmcnt(0) that opens each of the five K-steps (12 ds_read_b128 feeding 24 MFMAs, no registers left
-// to software-pipeline the next step's fragments under a 256-VGPR cap), and with only two waves per SIMD the matrix
-// pipe idles ~35 % of the time.  (A ping-pong split of one 8-wave workgroup into an MFMA group and a staging group
-// was tried and measured 3-8 % slower: the LDS latency sits INSIDE the MFMA phase.)  Here the same 8x32x64 tile is
-// worked by 8 waves, one 32-pixel row each: accumulators 64 -> 32 VGPRs, fragments 48 -> 36, staging registers
-// 40 -> 24, so the kernel fits 128 VGPRs and FOUR waves share each SIMD (2 workgroups per CU): three other waves
-// cover every LDS / barrier / staging gap of a wave.
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 4) void conv3x3_x6w8_kernel(ConvX6Args a) {
-    constexpr int KS = 3, KK = 9, PAD = 1, NT = 512;
-    constexpr int HTH = TH + KS - 1, HTW = TW + KS - 1;
-    constexpr int NPIX = HTH * HTW;
-    constexpr int NPAIR = (KK + 1) / 2;
-    constexpr int XUNITS = NPIX * (CK / 4);
-    constexpr int XITER = (XUNITS + NT - 1) / NT;
-    constexpr int WUNITS = 3 * KK * TN;
-    constexpr int WITER = (WUNITS + NT - 1) / NT;
-    constexpr int WSLAB = (KK + 1) * TN;
-    constexpr int EPITCH = 32 + 4;
-
-    __shared__ uint4 smem[3 * NPIX + 3 * WSLAB];
-    uint4* sX = smem;
-    uint4* sW = smem + 3 * NPIX;
-    static_assert(8 * 32 * EPITCH * 4 <= (3 * NPIX + 3 * WSLAB) * 16, "epilogue staging does not fit");
-
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
-
-    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
-    const int ntn = (a.n_total + TN - 1) / TN;
-    const int N = a.n_total;
-    const int K = a.c0 + a.c1;
-    const int nchunks = K / CK;
-
-    auto zero_tap = [&]() {
-        for (int i = tid; i < 3 * TN; i += NT) sW[(i / TN) * WSLAB + KK * TN + i % TN] = make_uint4(0u, 0u, 0u, 0u);
-    };
-    zero_tap();
-
-    auto decode = [&](int tile) {
-        TileInfo t;
-        t.n0 = (tile % ntn) * TN;
-        int sid = tile / ntn;
-        t.tx0 = (sid % tiles_x) * TW;
-        sid /= tiles_x;
-        t.ty0 = (sid % tiles_y) * TH;
-        t.b = sid / tiles_y;
-        return t;
-    };
-
-    f32x16 acc[2];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-    };
-    zero_acc();
-
-    float4 rx[XITER];
-    uint4 rw[WITER];
-
-    auto prefetch = [&](const TileInfo& ti, int ch) {
-        const int kbase = ch * CK;
-        const float* src;
-        int cs, coff;
-        if (kbase < a.c0) {
-            src = a.x0; cs = a.c0; coff = kbase;
-        } else {
-            src = a.x1; cs = a.c1; coff = kbase - a.c0;
-        }
-#pragma unroll
-        for (int it = 0; it < XITER; ++it) {
-            const int u = tid + it * NT;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < XUNITS) {
-                const int q = u % (CK / 4), pix = u / (CK / 4);
-                const int py = pix / HTW, px = pix % HTW;
-                const int gy = ti.ty0 + py - PAD, gx = ti.tx0 + px - PAD;
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                    v = *reinterpret_cast<const float4*>(src + ((size_t)(ti.b * a.H + gy) * a.W + gx) * cs + coff + q * 4);
-            }
-            rx[it] = v;
-        }
-#pragma unroll
-        for (int it = 0; it < WITER; ++it) {
-            const int u = tid + it * NT;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (u < WUNITS) {
-                const int n = u % TN, t = (u / TN) % KK, p = u / (TN * KK);
-                if (ti.n0 + n < N)
-                    v = *reinterpret_cast<const uint4*>(a.wp + (size_t)p * a.plane_stride +
-                                                        (((size_t)t * nchunks + ch) * a.n_row + a.n_off + ti.n0 + n) * 8);
-            }
-            rw[it] = v;
-        }
-    };
-
-    auto commit = [&]() {
-#pragma unroll
-        for (int it = 0; it < XITER; ++it) {
-            const int u = tid + it * NT;
-            if (u < XUNITS) {
-                const int q = u % (CK / 4), pix = u / (CK / 4);
-                const float xv[4] = {rx[it].x, rx[it].y, rx[it].z, rx[it].w};
-                bf16x4 ph, pm, pl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    __bf16 h_, m_, l_;
-                    split3(xv[e], h_, m_, l_);
-                    ph[e] = h_; pm[e] = m_; pl[e] = l_;
-                }
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sX[0 * NPIX + pix]) + q * 8) = ph;
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sX[1 * NPIX + pix]) + q * 8) = pm;
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sX[2 * NPIX + pix]) + q * 8) = pl;
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < WITER; ++it) {
-            const int u = tid + it * NT;
-            if (u < WUNITS) {
-                const int n = u % TN, t = (u / TN) % KK, p = u / (TN * KK);
-                sW[p * WSLAB + t * TN + n] = rw[it];
-            }
-        }
-    };
-
-    // per-wave LDS transpose, one 32-channel half at a time: 8 lanes cover the 32 channels of a pixel (128 B)
-    auto epilogue = [&](const TileInfo& ti) {
-        float* sE = reinterpret_cast<float*>(smem) + wave * 32 * EPITCH;
-        const int co4 = (lane & 7) * 4, prow = lane >> 3;
-        const int gy = ti.ty0 + wave;
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const int nbase = ti.n0 + nb * 32 + co4;
-            const bool nok = nbase < N;
-            float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.bias && nok) bv4 = *reinterpret_cast<const float4*>(a.bias + (size_t)ti.b * a.bias_img_stride + nbase);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sE[mfma32_row(r, half) * EPITCH + l31] = acc[nb][r];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int px = 8 * j + prow;
-                const float4 v4 = *reinterpret_cast<const float4*>(&sE[px * EPITCH + co4]);
-                const int gx = ti.tx0 + px;
-                if (gy < a.H && gx < a.W && nok) {
-                    const size_t idx = ((size_t)(ti.b * a.H + gy) * a.W + gx) * N + nbase;
-                    float4 v = make_float4(v4.x + bv4.x, v4.y + bv4.y, v4.z + bv4.z, v4.w + bv4.w);
-                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (a.mask) {
-                        const float4 g = *reinterpret_cast<const float4*>(a.mask + idx);
-                        v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f;
-                        v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
-                    }
-                    if (a.accumulate) {
-                        const float4 o = *reinterpret_cast<const float4*>(a.y + idx);
-                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                    }
-                    *reinterpret_cast<float4*>(a.y + idx) = v;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    };
-
-    int tile = blockIdx.x;
-    if (tile >= a.ntiles) return;
-    int ch = 0;
-    TileInfo ti = decode(tile);
-    prefetch(ti, 0);
-    while (true) {
-        __syncthreads();
-        commit();
-        __syncthreads();
-        int nch = ch + 1, ntile = tile;
-        TileInfo nti = ti;
-        if (nch == nchunks) {
-            nch = 0;
-            ntile = tile + (int)gridDim.x;
-            if (ntile < a.ntiles) nti = decode(ntile);
-        }
-        const bool has_next = ntile < a.ntiles;
-        if (has_next) prefetch(nti, nch);
-
-#pragma unroll
-        for (int j = 0; j < NPAIR; ++j) {
-            const int t0 = 2 * j, t1 = 2 * j + 1;
-            const int offA0 = (t0 / KS) * HTW + t0 % KS;
-            const int offA1 = t1 < KK ? (t1 / KS) * HTW + t1 % KS : offA0;
-            const int offA = half ? offA1 : offA0;
-            const int tapB = half ? t1 : t0;
-            U4 av[3], bv[3][2];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                av[p].u = sX[p * NPIX + wave * HTW + l31 + offA];
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) bv[p][nb].u = sW[p * WSLAB + tapB * TN + nb * 32 + l31];
-            }
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                f32x16 c = acc[nb];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1].v, bv[1][nb].v, c, 0, 0, 0);  // mm
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2].v, bv[0][nb].v, c, 0, 0, 0);  // lh
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0].v, bv[2][nb].v, c, 0, 0, 0);  // hl
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1].v, bv[0][nb].v, c, 0, 0, 0);  // mh
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0].v, bv[1][nb].v, c, 0, 0, 0);  // hm
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0].v, bv[0][nb].v, c, 0, 0, 0);  // hh
-                acc[nb] = c;
-            }
-        }
-        if (ch == nchunks - 1) {
-            __syncthreads();
-            epilogue(ti);
-            zero_acc();
-            __syncthreads();
-            zero_tap();
-        }
-        if (!has_next) break;
-        tile = ntile;
-        ch = nch;
-        ti = nti;
-    }
-}
-
 // planes[p][t'][k/8][n][8] <- split(w) ; mode 0 (forward): k = cin, n = cout, t' = t ;
 // mode 1 (input gradient): k = cout, n = cin, t' = kk-1-t (flipped taps)
 __global__ __launch_bounds__(256) void split_weights_x6_kernel(const float* __restrict__ w, __bf16* __restrict__ planes,
@@ -615,12 +390,6 @@ __global__ __launch_bounds__(256) void split_weights_x6_batch_kernel(const float
 }
 
 int g_x6_wg_per_cu = 2;
-// 1 (default): 4-wave workgroups (2x2 tiles per wave); 2: 8-wave workgroups (one row per wave), 4 waves per SIMD.
-// A/B in one process (tools/ab_x6v.py): variant 2 is 3-8 % slower; MFMA-busy cycles vs duration put variant 1 at ~87 %
-// matrix-pipe occupancy at the ~1.6 GHz the chip holds under this load, i.e. the kernel is power/clock-bound, not
-// issue-bound - which is why neither more waves, nor a ping-pong split, nor bigger chunks helped.
-int g_x6_variant = 1;
-
 }  // namespace
 
 // shared with wgrad_x6.hip: bf16 planes per operand (3 = six products = the fp32-accurate parity arithmetic)
@@ -629,12 +398,6 @@ int g_punet_x6_planes = 3;
 extern "C" int punet_set_x6_products(int n) {
     PUNET_CHECK_ARG(n == 6 || n == 3 || n == 1, "punet_set_x6_products: 6 (fp32-accurate), 3 (16-bit significand) or 1 (bf16)");
     g_punet_x6_planes = n == 6 ? 3 : (n == 3 ? 2 : 1);
-    return PUNET_OK;
-}
-
-extern "C" int punet_set_x6_variant(int v) {
-    PUNET_CHECK_ARG(v == 1 || v == 2, "punet_set_x6_variant: 1 or 2");
-    g_x6_variant = v;
     return PUNET_OK;
 }
 
@@ -679,13 +442,6 @@ extern "C" int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1
     a.y = y; a.n_total = n_out; a.mask = mask; a.accumulate = accumulate; a.relu = relu;
     a.B = B; a.H = H; a.W = W;
     a.ntiles = B * ceil_div(H, TH) * ceil_div(W, TW) * ceil_div(n_out, TN);
-    if (g_x6_variant == 2 && g_punet_x6_planes == 3) {
-        const int cap8 = 2 * NUM_CU;
-        const int grid8 = a.ntiles < cap8 ? a.ntiles : cap8;
-        conv3x3_x6w8_kernel<<<grid8, 512, 0, (hipStream_t)stream>>>(a);
-        PUNET_LAUNCH_CHECK("conv3x3_x6w8");
-        return PUNET_OK;
-    }
     const int cap = g_x6_wg_per_cu * NUM_CU;
     const int grid = a.ntiles < cap ? a.ntiles : cap;
     if (g_punet_x6_planes == 3)
