@@ -19,7 +19,7 @@ typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
         }                                                                                          \
     } while (0)
 
-template <int WITH_LDS>
+template <int WITH_LDS, int ORDER>
 __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ src, float* __restrict__ out, int iters) {
     __shared__ uint4 sm[WITH_LDS ? 2048 : 1];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -53,12 +53,21 @@ __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ src, 
         for (int t = 0; t < 4; ++t) {
             const int mb = t >> 1, nb = t & 1;
             f32x16 c = acc[t];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 + mb].v, b[2 + nb].v, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[4 + mb].v, b[0 + nb].v, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0 + mb].v, b[4 + nb].v, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 + mb].v, b[0 + nb].v, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0 + mb].v, b[2 + nb].v, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0 + mb].v, b[0 + nb].v, c, 0, 0, 0);
+            if (ORDER == 0) {  // the kernels' order: small terms first (mm lh hl mh hm hh)
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 + mb].v, b[2 + nb].v, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[4 + mb].v, b[0 + nb].v, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0 + mb].v, b[4 + nb].v, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 + mb].v, b[0 + nb].v, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0 + mb].v, b[2 + nb].v, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0 + mb].v, b[0 + nb].v, c, 0, 0, 0);
+            } else {  // consecutive MFMAs share one operand (lh | mh mm | hm hh hl)
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[4 + mb].v, b[0 + nb].v, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 + mb].v, b[0 + nb].v, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 + mb].v, b[2 + nb].v, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0 + mb].v, b[2 + nb].v, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0 + mb].v, b[0 + nb].v, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0 + mb].v, b[4 + nb].v, c, 0, 0, 0);
+            }
             acc[t] = c;
         }
     }
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ src, 
     if (s == 12345.678f) out[0] = s;  // keep the chains alive
 }
 
-template <int WITH_LDS>
+template <int WITH_LDS, int ORDER = 0>
 static void run(const char* label, const uint4* src, float* out, int wg_per_cu, int iters, int reps) {
     hipDeviceProp_t p;
     CK(hipGetDeviceProperties(&p, 0));
@@ -78,11 +87,11 @@ static void run(const char* label, const uint4* src, float* out, int wg_per_cu, 
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    mfma_loop<WITH_LDS><<<grid, 256>>>(src, out, iters);  // warm
+    mfma_loop<WITH_LDS, ORDER><<<grid, 256>>>(src, out, iters);  // warm
     CK(hipDeviceSynchronize());
     for (int r = 0; r < reps; ++r) {
         CK(hipEventRecord(e0));
-        mfma_loop<WITH_LDS><<<grid, 256>>>(src, out, iters);
+        mfma_loop<WITH_LDS, ORDER><<<grid, 256>>>(src, out, iters);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -128,6 +137,10 @@ int main() {
             snprintf(label, sizeof label, "+12 ds_read_b128/24 mfma, %s", d);
             run<1>(label, src, out, w, iters, 3);
         }
+        snprintf(label, sizeof label, "operand-sharing order, %s", d);
+        run<0, 1>(label, src, out, 2, iters, 3);
+        snprintf(label, sizeof label, "sharing order + LDS, %s", d);
+        run<1, 1>(label, src, out, 2, iters, 3);
     }
     return 0;
 }
