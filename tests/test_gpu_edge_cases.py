@@ -1,0 +1,71 @@
+"""GPU: edge cases of the model surface - the error behaviour the reference has (or the explicit error this build raises
+where the reference would fail later), smallest sizes, batch 1, a single MC sample, ragged (non multiple-of-32) widths."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import punet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+NF = [32, 32, 64, 64]
+
+
+@pytest.fixture(scope="module")
+def model():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    return ProbabilisticUnet(1, 1, NF, 6, 3, 1.0, consensus_masking=True, device="cuda:0", seed=3)
+
+
+def test_size_not_divisible_by_8_raises(model):
+    # probabilistic_unet.py / unet_blocks.py:55: the reference asserts equal sizes at the skip concat
+    with torch.no_grad(), pytest.raises(ValueError):
+        model.forward(torch.zeros(1, 1, 36, 64).cuda(), None, training=False)
+        model.sample(testing=True)
+
+
+def test_training_forward_needs_segm(model):
+    with pytest.raises(ValueError):
+        model.forward(torch.zeros(1, 1, 32, 32).cuda(), None, training=True)
+
+
+def test_elbo_before_forward_raises():
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    m = ProbabilisticUnet(1, 1, NF, 6, 3, device="cuda:0", seed=0)
+    with pytest.raises(RuntimeError):
+        m.elbo(torch.zeros(1, 1, 32, 32).cuda())
+    with pytest.raises(RuntimeError):
+        m.sample()
+
+
+def test_wrong_channel_count_raises(model):
+    with torch.no_grad(), pytest.raises((ValueError, AssertionError, RuntimeError)):
+        model.forward(torch.zeros(1, 2, 32, 32).cuda(), None, training=False)
+        model.sample(testing=True)
+
+
+@pytest.mark.parametrize("B,H,W,n", [(1, 8, 8, 1), (1, 8, 40, 3), (3, 24, 8, 2), (1, 72, 104, 1)])
+def test_smallest_and_ragged_shapes_match_oracle(model, B, H, W, n):
+    """8x8 is the smallest legal patch (1x1 at the bottom of the encoder); widths that are not multiples of the 32-pixel
+    MFMA tile; batch 1; a single MC sample."""
+    cfg = O.PUNetConfig(1, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    x = torch.randn(B, 1, H, W, generator=torch.Generator().manual_seed(H * W))
+    eps = torch.randn(n, B, 6, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        st = O.punet_forward(P, cfg, x, None, False)
+        logits = torch.stack([O.punet_sample(P, cfg, st, eps[i]) for i in range(n)])
+    eng = model.engine
+    with torch.no_grad():
+        out = eng.forward_features(model.flat_params, eng.to_nhwc(x))
+        z = eng.reparam(out["prior_muls"], eps.cuda())
+        ym, cz, lg = eng.sample(model.flat_params, out["features"], z, 0.9, 0.1, True, want_logits=True)
+    torch.cuda.synchronize()
+    assert np.abs(lg.cpu().numpy() - logits.numpy()).max() < 1e-3
+    probs = torch.sigmoid(logits)
+    ref_mask = (((probs >= 0.9) | (probs <= 0.1)).float().sum(0) == n).float()
+    safe = ((probs - 0.9).abs().min(0).values > 1e-5) & ((probs - 0.1).abs().min(0).values > 1e-5)
+    assert torch.equal(cz.cpu()[safe], ref_mask[safe])
+    assert (ym.cpu() - probs.mean(0)).abs().max() < 1e-4
