@@ -132,6 +132,8 @@ class ParamLayout:
             off = (off + 3) // 4 * 4  # keep every tensor 16-byte aligned (float4 loads)
         self.numel = off
         self.n_params = sum(e[2] for e in self.entries)
+        # the U-Net's tensors come first (state-dict order): [0, unet_numel) is its slice of every flat buffer
+        self.unet_numel = next((o for nm, o, _, _ in self.entries if not nm.startswith(pre)), off) if kind == "punet" else off
 
     def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
         """Logical (reference-shaped) view of one tensor inside a flat buffer (no copy)."""
@@ -578,9 +580,11 @@ class PUNetEngine:
                 _lib.call("punet_upsample2x_bwd", dy.data_ptr(), x.ptr if x.relu_out else None, g.data_ptr(), x.B, x.H, x.W,
                           x.C, _stream())
 
-    def elbo_backward(self, flat, gflat, st, accumulate=False):
+    def elbo_backward(self, flat, gflat, st, accumulate=False, after_unet=None):
         """Gradient of gscale * (reconstruction_loss + beta * kl) w.r.t. every parameter into gflat
-        (= d(-elbo)/d theta, probabilistic_unet.py:371), written or accumulated."""
+        (= d(-elbo)/d theta, probabilistic_unet.py:371), written or accumulated.  `after_unet()` is called once the
+        U-Net's slice of gflat (the first L.unet_numel floats) is final - the data-parallel step starts that slice's
+        all-reduce there, under the encoders' backward."""
         L = self.L
         B, H, W = st["B"], st["H"], st["W"]
         Ld, CH = L.latent_dim, L.nf[0]
@@ -617,6 +621,8 @@ class PUNetEngine:
         del dz_h
         tq, tp, tu = st["tapes"]
         self._backward_tape(flat, gflat, tu, gm_u, accumulate)
+        if after_unet is not None:
+            after_unet()
         # latent heads: KL + reparameterisation
         dq = self._empty(B, 2 * Ld)
         dp = self._empty(B, 2 * Ld)

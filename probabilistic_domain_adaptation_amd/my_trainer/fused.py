@@ -85,11 +85,17 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-def allreduce_grads(gflat: torch.Tensor) -> float:
-    """Sum the flat gradient over ranks (one RCCL ring all-reduce over xGMI); returns the scale to apply (1/world)."""
+def allreduce_grads(gflat: torch.Tensor, started: Optional[dict] = None) -> float:
+    """Sum the flat gradient over ranks (RCCL ring all-reduce over xGMI); returns the scale to apply (1/world).
+    `started` = what `elbo_grad_pass(..., overlap=True)` returned in st["allreduce"]: the U-Net slice is then already
+    in flight (launched under the encoders' backward) and only the remainder is reduced here."""
     w = _world()
     if w > 1:
-        dist.all_reduce(gflat, op=dist.ReduceOp.SUM)
+        if started:
+            dist.all_reduce(gflat[started["numel"]:], op=dist.ReduceOp.SUM)
+            started["work"].wait()
+        else:
+            dist.all_reduce(gflat, op=dist.ReduceOp.SUM)
     return 1.0 / w
 
 
@@ -101,8 +107,10 @@ def pseudo_labels(net: ProbabilisticUnet, x1, n_samples: int, masking: bool, eps
         return net.sample_consensus(n_samples, upper, lower, masking, eps)
 
 
-def elbo_grad_pass(model: ProbabilisticUnet, gflat, x, y, z, eps, gscale: float, accumulate: bool):
-    """forward(x, y, True); elbo(y, z); backward of gscale * (-elbo) into gflat.  Returns device scalars."""
+def elbo_grad_pass(model: ProbabilisticUnet, gflat, x, y, z, eps, gscale: float, accumulate: bool, overlap: bool = False):
+    """forward(x, y, True); elbo(y, z); backward of gscale * (-elbo) into gflat.  Returns device scalars.
+    overlap=True (the LAST gradient pass of a data-parallel step): the all-reduce of the U-Net slice of gflat is launched
+    asynchronously as soon as that slice is final; finish with allreduce_grads(gflat, st["allreduce"])."""
     eng = model.engine
     B = x.shape[0]
     xn = eng.to_nhwc(x)
@@ -113,17 +121,26 @@ def elbo_grad_pass(model: ProbabilisticUnet, gflat, x, y, z, eps, gscale: float,
         cm = z.to(device=model.device, dtype=torch.float32).reshape(B, 1, H, W).contiguous()
     e = model._eps(1, B, eps)[0]
     st = eng.elbo_forward(model.flat_params, xn, yt, cm, e, "dice" if model.rl_swap else "bce", model.beta, gscale, True)
-    eng.elbo_backward(model.flat_params, gflat, st, accumulate)
+    started = {}
+    hook = None
+    if overlap and _world() > 1:
+        n = model.layout.unet_numel
+
+        def hook():
+            started["numel"] = n
+            started["work"] = dist.all_reduce(gflat[:n], op=dist.ReduceOp.SUM, async_op=True)
+    eng.elbo_backward(model.flat_params, gflat, st, accumulate, after_unet=hook)
+    st["allreduce"] = started
     return st["rec"][0], st["kl"][0], st
 
 
 def fused_supervised_step(model, opt: FusedAdam, x, y, z=None, eps=None, reg_weight=1e-5):
     """PUNetTrainer / PseudoTrainerPUNet iteration (punet_trainer.py:24-36, punet_target_trainer.py:105-118)."""
     eng = model.engine
-    rec, kl, _ = elbo_grad_pass(model, opt.grad_flat, x, y, z, eps, 1.0, False)
+    rec, kl, st = elbo_grad_pass(model, opt.grad_flat, x, y, z, eps, 1.0, False, overlap=True)
     reg, norms = eng.l2_reg(model.flat_params)
     eng.l2_reg_add_grad(model.flat_params, opt.grad_flat, norms, reg_weight)
-    scale = allreduce_grads(opt.grad_flat)
+    scale = allreduce_grads(opt.grad_flat, st["allreduce"])
     opt.fused_step(None, grad_scale=scale)
     return rec + model.beta * kl + reg_weight * reg[0]
 
@@ -137,10 +154,10 @@ def fused_self_training_step(model, teacher, opt: FusedAdam, x1, x2, n_samples: 
     ratio = None
     if source_distribution is not None:
         y, ratio = distribution_alignment(y, source_distribution)
-    rec, kl, _ = elbo_grad_pass(model, opt.grad_flat, x2, y, z, eps_s, 1.0, False)
+    rec, kl, st = elbo_grad_pass(model, opt.grad_flat, x2, y, z, eps_s, 1.0, False, overlap=True)
     reg, norms = eng.l2_reg(model.flat_params)
     eng.l2_reg_add_grad(model.flat_params, opt.grad_flat, norms, reg_weight)
-    scale = allreduce_grads(opt.grad_flat)
+    scale = allreduce_grads(opt.grad_flat, st["allreduce"])
     do_ema = momentum is not None and teacher is not model and bool(opt.lr)  # `if lr:` gate, mean_teacher_trainer.py:126
     opt.fused_step(teacher if do_ema else None, ema_momentum=momentum if do_ema else 0.0, grad_scale=scale)
     return rec + model.beta * kl + reg_weight * reg[0], y, z, ratio
@@ -153,10 +170,10 @@ def fused_joint_step(model, teacher, opt: FusedAdam, xs, ys, xt1, xt2, n_samples
     eng = model.engine
     rec_s, kl_s, _ = elbo_grad_pass(model, opt.grad_flat, xs, ys, None, eps_sup, 0.5, False)
     y, z = pseudo_labels(teacher, xt1, n_samples, masking, eps_pl)
-    rec_t, kl_t, _ = elbo_grad_pass(model, opt.grad_flat, xt2, y, z if use_consensus else None, eps_s, 0.5, True)
+    rec_t, kl_t, st = elbo_grad_pass(model, opt.grad_flat, xt2, y, z if use_consensus else None, eps_s, 0.5, True, overlap=True)
     reg, norms = eng.l2_reg(model.flat_params)
     eng.l2_reg_add_grad(model.flat_params, opt.grad_flat, norms, reg_weight)  # (reg + reg) / 2
-    scale = allreduce_grads(opt.grad_flat)
+    scale = allreduce_grads(opt.grad_flat, st["allreduce"])
     ema = momentum is not None and teacher is not model
     opt.fused_step(teacher if ema else None, ema_momentum=momentum if ema else 0.0, grad_scale=scale)
     loss = 0.5 * (rec_s + model.beta * kl_s + rec_t + model.beta * kl_t) + reg_weight * reg[0]

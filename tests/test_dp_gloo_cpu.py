@@ -51,3 +51,45 @@ def test_single_process_is_identity():
     from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
     g = torch.ones(8)
     assert FU.allreduce_grads(g) == 1.0 and torch.equal(g, torch.ones(8))
+
+
+def _worker_split(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    # what elbo_grad_pass(overlap=True) does at the after_unet hook: the leading slice goes out early, asynchronously
+    started = {"numel": 384, "work": dist.all_reduce(g[:384], op=dist.ReduceOp.SUM, async_op=True)}
+    g[384:] += 1.0  # the rest of the backward still writes the remainder
+    scale = FU.allreduce_grads(g, started)
+    q.put((rank, scale, g[:2].tolist(), g[384:386].tolist(), float(g.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_grads_overlapped_slice_world2():
+    """Two-part reduction (U-Net slice early + remainder) == one reduction of the final buffer."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_split, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, scale, head, mid, tot in res:
+        assert scale == 0.5
+        assert head == [0.0, 3.0]
+        assert mid == [3.0 * 384 + 2.0, 3.0 * 385 + 2.0]
+        assert tot == 3.0 * sum(range(1000)) + 2.0 * (1000 - 384)
+
+
+def test_unet_slice_of_the_flat_layout():
+    from probabilistic_domain_adaptation_amd.engine import ParamLayout
+    L = ParamLayout(1, 1, [64, 128, 256, 512], 6, 3)
+    names = [nm for nm, off, n, _ in L.entries if off < L.unet_numel]
+    assert L.unet_numel == 11690688 and all(nm.startswith("unet.") for nm in names)
+    assert all(not nm.startswith("unet.") for nm, off, n, _ in L.entries if off >= L.unet_numel)
+    assert L.unet_numel % 4 == 0
