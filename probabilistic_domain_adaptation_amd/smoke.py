@@ -36,11 +36,17 @@ def run(verbose=True):
     loss = tr.last_loss.item()
     assert abs(loss - r["loss"].item()) <= 2e-4 * abs(r["loss"].item()), (loss, r["loss"].item())
     worst_s = worst_t = 0.0
+    n_all = n_off = 0
     for (k, v), p, q in zip(Ps.items(), model.parameters(), tr.teacher.parameters()):
-        worst_s = max(worst_s, (p.detach().cpu() - v.detach()).abs().max().item())
+        ds = (p.detach().cpu() - v.detach()).abs()
+        worst_s = max(worst_s, ds.max().item())
         worst_t = max(worst_t, (q.detach().cpu() - Pt[k]).abs().max().item())
-    # first Adam step is sign-like: tolerance in units of lr (entries with |g| ~ eps are ill-conditioned)
-    assert worst_s <= 0.05 * lr and worst_t <= 0.05 * lr, (worst_s, worst_t)
+        n_all += ds.numel()
+        n_off += int((ds > 0.05 * lr).sum())
+    # The first Adam step is sign-like (update = lr * g / (|g| + 1e-8)): a gradient entry whose true value is ~0 may
+    # come out with either sign within fp32 rounding, which moves that one weight by up to 2 lr.  So: every entry
+    # within the 2 lr bound, all but a vanishing fraction within 0.05 lr; the EMA teacher (x 1e-3) within 0.05 lr.
+    assert worst_s <= 2.05 * lr and n_off <= 1e-4 * n_all and worst_t <= 0.05 * lr, (worst_s, n_off, n_all, worst_t)
     if verbose:
         print(f"[smoke] mean-teacher step ok: loss {loss:.4f} (oracle {r['loss'].item():.4f}), "
-              f"max |dparam| student {worst_s:.2e} teacher {worst_t:.2e}")
+              f"max |dparam| student {worst_s:.2e} ({n_off} of {n_all} entries beyond 0.05 lr) teacher {worst_t:.2e}")
