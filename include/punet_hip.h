@@ -76,6 +76,17 @@ int punet_split_weights_x6_batch(const float* flat, void* planes, const long* ta
 int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride, int n_row,
                      int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
                      int accumulate, int relu, int B, int H, int W, void* stream);
+/* The same with the ReLU gate as BITS (1/32 of the fp32 gate's traffic and no per-lane load chain in the epilogue).
+ * A [B,H,W,C] activation has punet_gate_dwords(B,H,W,C) = B*H*ceil(W/32)*ceil(C/64)*64 dwords: the block {row y,
+ * pixels 32t..32t+31, channels 64cb..64cb+63} owns dwords ((((b*H + y)*ceil(W/32) + t)*ceil(C/64) + cb)*64 + l),
+ * l = 16*(x % 4) + (c % 64)/4, and bit 4*((x % 32)/4) + (c % 4) of dword l is (activation[b][y][x][c] > 0).
+ * gate_out (forward, relu != 0): written for the output y; gate_bits (input gradient): the gate of the tensor dx belongs
+ * to, replaces `mask`. */
+size_t punet_gate_dwords(int B, int H, int W, int C);
+int punet_conv3x3_x6_gated(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
+                           int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out,
+                           const float* mask, const void* gate_bits, void* gate_out, int accumulate, int relu, int B,
+                           int H, int W, void* stream);
 
 /* ---- K3: autograd weight + bias gradient of K1 (convolution_backward, weight/bias), fp32 MFMA, deterministic split-K.
  *      x has cs channels and fills rows [ci_off, ci_off+cs) of dw[k][k][cin_total][cout]; dbias may be NULL.

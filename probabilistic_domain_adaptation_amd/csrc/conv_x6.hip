@@ -49,6 +49,8 @@ struct ConvX6Args {
     float* y;
     int n_total;
     const float* mask;
+    const unsigned* gate_bits;  // ReLU gate of the destination as bits (instead of `mask`), layout: punet_gate_dwords
+    unsigned* gate_out;         // forward with ReLU: (y > 0) bits of the output
     int accumulate, relu;
     int B, H, W, ntiles;
 };
@@ -72,7 +74,10 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
 
 // NP = number of bf16 planes per operand: 3 -> six products (fp32-accurate, the parity arithmetic); 2 -> hh + hm + mh
 // (16 significand bits, opt-in fast mode); 1 -> plain bf16 (opt-in).
-template <int NP>
+// DGRAD selects the epilogue: false = forward (bias, ReLU, optional gate bits of the output); true = input gradient
+// (ReLU gate of the destination as fp32 mask or bits, optional accumulate).  Two instantiations instead of run-time
+// flags: the kernel sits at the 256-VGPR limit and every live flag / pointer of the other mode costs registers.
+template <int NP, bool DGRAD>
 __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     constexpr int KS = 3, KK = 9, PAD = 1;
     constexpr int HTH = TH + KS - 1, HTW = TW + KS - 1;
@@ -202,36 +207,57 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
         const int prow = lane >> 4;                // pixel sub-row 0..3
         const bool nok = ti.n0 + co4 < N;          // N is a multiple of 4
         float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias && nok) bv4 = *reinterpret_cast<const float4*>(a.bias + (size_t)ti.b * a.bias_img_stride + ti.n0 + co4);
+        if (!DGRAD && a.bias && nok)
+            bv4 = *reinterpret_cast<const float4*>(a.bias + (size_t)ti.b * a.bias_img_stride + ti.n0 + co4);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
+            const int gy = ti.ty0 + 2 * wave + m;
+            // ReLU gates as bits (layout: punet_gate_dwords): per {row, 32-pixel tile, 64-channel block} one dword per
+            // lane of THIS epilogue mapping - lane l = 16 (x % 4) + (c % 64) / 4 holds bit 4 j + e for pixel 4 j + l / 16,
+            // channel 4 (l % 16) + e.  The forward ORs its own four comparisons per float4 into one register and stores
+            // 256 contiguous bytes per row; the input gradient loads its dword once per row, before the LDS transpose.
+            // (The fp32 gate loads - one load -> wait -> use chain per float4 - had made the dgrad epilogue of the
+            // 64-channel layers as long as their whole K loop.)
+            const bool row_in = gy < a.H;
+            const size_t gd_row = ((((size_t)(ti.b * a.H + gy) * tiles_x + (ti.tx0 / TW)) * ntn + (ti.n0 / TN)) << 6) + lane;
+            unsigned gin = 0u, gout = 0u;
+            if (DGRAD && a.gate_bits && row_in) gin = a.gate_bits[gd_row];
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sE[mfma32_row(r, half) * EPITCH + nb * 32 + l31] = acc[m][nb][r];
             __builtin_amdgcn_wave_barrier();  // same-wave LDS ops complete in order; keep the compiler from reordering
-            const int gy = ti.ty0 + 2 * wave + m;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int px = 4 * j + prow;
                 const float4 v4 = *reinterpret_cast<const float4*>(&sE[px * EPITCH + co4]);
                 const int gx = ti.tx0 + px;
-                if (gy < a.H && gx < a.W && nok) {
-                    const size_t idx = ((size_t)(ti.b * a.H + gy) * a.W + gx) * N + ti.n0 + co4;
-                    float4 v = make_float4(v4.x + bv4.x, v4.y + bv4.y, v4.z + bv4.z, v4.w + bv4.w);
-                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (a.mask) {
+                const bool ok = row_in && gx < a.W && nok;
+                const size_t idx = ((size_t)(ti.b * a.H + gy) * a.W + gx) * N + ti.n0 + co4;
+                float4 v = make_float4(v4.x + bv4.x, v4.y + bv4.y, v4.z + bv4.z, v4.w + bv4.w);
+                if (!DGRAD && a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (!DGRAD) {
+                } else if (a.gate_bits) {
+                    const unsigned g4 = gin >> (4 * j);
+                    v.x = g4 & 1u ? v.x : 0.f; v.y = g4 & 2u ? v.y : 0.f; v.z = g4 & 4u ? v.z : 0.f; v.w = g4 & 8u ? v.w : 0.f;
+                } else if (a.mask) {
+                    if (ok) {
                         const float4 g = *reinterpret_cast<const float4*>(a.mask + idx);
                         v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f;
                         v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
                     }
-                    if (a.accumulate) {
+                }
+                if (ok) {
+                    if (DGRAD && a.accumulate) {
                         const float4 o = *reinterpret_cast<const float4*>(a.y + idx);
                         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                     }
                     *reinterpret_cast<float4*>(a.y + idx) = v;
+                    if (!DGRAD)
+                        gout |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (4 * j);
                 }
             }
+            if (!DGRAD && a.gate_out && row_in) a.gate_out[gd_row] = gout;  // forward with ReLU: (y > 0), for the consumers' backward
             __builtin_amdgcn_wave_barrier();
         }
     };
@@ -426,9 +452,21 @@ extern "C" int punet_split_weights_x6_batch(const float* flat, void* planes, con
     return PUNET_OK;
 }
 
+extern "C" size_t punet_gate_dwords(int B, int H, int W, int C) {
+    return (size_t)B * H * ((W + TW - 1) / TW) * ((C + TN - 1) / TN) * 64;
+}
+
 extern "C" int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
                                 int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out,
                                 const float* mask, int accumulate, int relu, int B, int H, int W, void* stream) {
+    return punet_conv3x3_x6_gated(x0, c0, x1, c1, wplanes, plane_stride, n_row, n_off, bias, bias_img_stride, y, n_out, mask,
+                                  nullptr, nullptr, accumulate, relu, B, H, W, stream);
+}
+
+extern "C" int punet_conv3x3_x6_gated(const float* x0, int c0, const float* x1, int c1, const void* wplanes,
+                                      long plane_stride, int n_row, int n_off, const float* bias, int bias_img_stride,
+                                      float* y, int n_out, const float* mask, const void* gate_bits, void* gate_out,
+                                      int accumulate, int relu, int B, int H, int W, void* stream) {
     PUNET_CHECK_ARG(x0 && wplanes && y, "punet_conv3x3_x6: null pointer");
     PUNET_CHECK_ARG(c0 > 0 && c0 % CK == 0 && c1 >= 0 && c1 % CK == 0 && (c1 == 0 || x1),
                     "punet_conv3x3_x6: source channels must be multiples of %d (c0=%d c1=%d)", CK, c0, c1);
@@ -439,17 +477,26 @@ extern "C" int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1
     a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1;
     a.wp = (const __bf16*)wplanes; a.plane_stride = plane_stride; a.n_row = n_row; a.n_off = n_off;
     a.bias = bias; a.bias_img_stride = bias_img_stride;
+    PUNET_CHECK_ARG(!(mask && gate_bits), "punet_conv3x3_x6: give the ReLU gate either as fp32 mask or as bits, not both");
+    PUNET_CHECK_ARG(!gate_out || relu, "punet_conv3x3_x6: gate_out is the ReLU gate of the output and needs relu != 0");
     a.y = y; a.n_total = n_out; a.mask = mask; a.accumulate = accumulate; a.relu = relu;
+    a.gate_bits = (const unsigned*)gate_bits; a.gate_out = (unsigned*)gate_out;
     a.B = B; a.H = H; a.W = W;
     a.ntiles = B * ceil_div(H, TH) * ceil_div(W, TW) * ceil_div(n_out, TN);
     const int cap = g_x6_wg_per_cu * NUM_CU;
     const int grid = a.ntiles < cap ? a.ntiles : cap;
-    if (g_punet_x6_planes == 3)
-        conv3x3_x6_kernel<3><<<grid, 256, 0, (hipStream_t)stream>>>(a);
-    else if (g_punet_x6_planes == 2)
-        conv3x3_x6_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(a);
-    else
-        conv3x3_x6_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    // the input-gradient epilogue whenever one of its features is asked for; bias / ReLU / gate_out belong to the forward
+    const bool dgrad = mask || gate_bits || accumulate;
+    PUNET_CHECK_ARG(!(dgrad && (bias || relu || gate_out)),
+                    "punet_conv3x3_x6: bias/relu/gate_out (forward) cannot be combined with mask/gate_bits/accumulate (input gradient)");
+    hipStream_t st = (hipStream_t)stream;
+    if (g_punet_x6_planes == 3) {
+        if (dgrad) conv3x3_x6_kernel<3, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<3, false><<<grid, 256, 0, st>>>(a);
+    } else if (g_punet_x6_planes == 2) {
+        if (dgrad) conv3x3_x6_kernel<2, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<2, false><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (dgrad) conv3x3_x6_kernel<1, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<1, false><<<grid, 256, 0, st>>>(a);
+    }
     PUNET_LAUNCH_CHECK("conv3x3_x6");
     return PUNET_OK;
 }

@@ -169,11 +169,12 @@ class ParamLayout:
 # --------------------------------------------------------------------------------------------
 class Act:
     """An NHWC activation tensor with its geometry; relu_out marks tensors whose gradient must be gated by (t > 0)."""
-    __slots__ = ("t", "B", "H", "W", "C", "relu_out", "needs_grad")
+    __slots__ = ("t", "B", "H", "W", "C", "relu_out", "needs_grad", "bits")
 
     def __init__(self, t, B, H, W, C, relu_out=False, needs_grad=True):
         self.t, self.B, self.H, self.W, self.C = t, B, H, W, C
         self.relu_out, self.needs_grad = relu_out, needs_grad
+        self.bits = None  # (t > 0) as bits (layout: punet_gate_dwords) when the producing kernel published them
 
     @property
     def ptr(self):
@@ -279,10 +280,12 @@ class PUNetEngine:
                       B, H, W, int(relu), _stream())
         elif self.x6 and c.k == 3:
             planes = self._x6[(flat.data_ptr(), 0)]
-            self._timed("conv3x3_fwd", 2.0 * B * H * W * cin * c.cout * 9, "punet_conv3x3_x6", x0.ptr, x0.C,
+            if relu and tape is not None:  # a backward will follow: publish the ReLU gate of y as bits for it
+                y.bits = torch.empty(_lib.call("punet_gate_dwords", B, H, W, c.cout), dtype=torch.int32, device=self.device)
+            self._timed("conv3x3_fwd", 2.0 * B * H * W * cin * c.cout * 9, "punet_conv3x3_x6_gated", x0.ptr, x0.C,
                         x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0,
-                        planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cout, 0, self._bptr(flat, c), 0, y.ptr, c.cout, None, 0,
-                        int(relu), B, H, W, _stream())
+                        planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cout, 0, self._bptr(flat, c), 0, y.ptr, c.cout, None,
+                        None, y.bits.data_ptr() if y.bits is not None else None, 0, int(relu), B, H, W, _stream())
         else:
             self._timed(f"conv{c.k}x{c.k}_fwd", 2.0 * B * H * W * cin * c.cout * c.k * c.k, "punet_conv_fwd", x0.ptr, x0.C,
                         x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0, self._wptr(flat, c),
@@ -525,14 +528,16 @@ class PUNetEngine:
                 _lib.call("punet_flip_transpose_weights", self._wptr(flat, c), self.wT.data_ptr() + 4 * c.w_off, c.cin, c.cout,
                           c.k, _stream())
 
-    def _dgrad(self, flat, c: ConvP, dz, cin_off: int, cin: int, dx, mask_ptr, acc: int, B: int, H: int, W: int):
-        """dx[..., cin_off : cin_off + cin] of conv c given dz (epilogue: ReLU gate by `mask`, accumulate)."""
+    def _dgrad(self, flat, c: ConvP, dz, cin_off: int, cin: int, dx, mask_ptr, acc: int, B: int, H: int, W: int, bits=None):
+        """dx[..., cin_off : cin_off + cin] of conv c given dz (epilogue: ReLU gate by `mask` - or by its bit form `bits`
+        where the kernel takes it -, accumulate)."""
         flops = 2.0 * B * H * W * cin * c.cout * c.k * c.k
         if self.x6 and c.k == 3:
             planes = self._x6[(flat.data_ptr(), 1)]
-            self._timed("conv3x3_dgrad", flops, "punet_conv3x3_x6", dz.data_ptr(), c.cout, None, 0,
-                        planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cin, cin_off, None, 0, dx.data_ptr(), cin, mask_ptr, acc,
-                        0, B, H, W, _stream())
+            use_bits = bits is not None and mask_ptr is not None
+            self._timed("conv3x3_dgrad", flops, "punet_conv3x3_x6_gated", dz.data_ptr(), c.cout, None, 0,
+                        planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cin, cin_off, None, 0, dx.data_ptr(), cin,
+                        None if use_bits else mask_ptr, bits.data_ptr() if use_bits else None, None, acc, 0, B, H, W, _stream())
         elif c.cin % 4 == 0:
             self._timed(f"conv{c.k}x{c.k}_dgrad", flops, "punet_conv_dgrad_t", dz.data_ptr(), c.cout,
                         self.wT.data_ptr() + 4 * c.w_off, c.cin, cin_off, cin, dx.data_ptr(), mask_ptr, acc, B, H, W, c.k,
@@ -564,7 +569,8 @@ class PUNetEngine:
                         continue
                     if src.needs_grad:
                         g, acc = self._grad_into(gm, src)
-                        self._dgrad(flat, c, dz, off, src.C, g, src.ptr if src.relu_out else None, acc, src.B, src.H, src.W)
+                        self._dgrad(flat, c, dz, off, src.C, g, src.ptr if src.relu_out else None, acc, src.B, src.H, src.W,
+                                    bits=src.bits)
                     off += src.C
             elif op[0] == "pool":
                 _, x, y = op

@@ -100,3 +100,54 @@ def test_split_weights_batch_matches_per_slab(L, mode):
     L.call("punet_split_weights_x6_batch", flat.data_ptr(), bat.data_ptr(), table.data_ptr(), len(shapes), units, mode, S())
     torch.cuda.synchronize()
     assert torch.equal(one.view(torch.int16), bat.view(torch.int16))
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 64, 64, 64), (1, 24, 40, 32, 96), (1, 8, 8, 128, 32), (2, 40, 72, 64, 160)])
+def test_gate_bits_equal_fp32_gate(L, B, H, W, cin, cout):
+    """The forward publishes (y > 0) as bits; the input gradient gated by those bits is bit-identical to the one gated by
+    the fp32 tensor itself (ragged widths, channel counts that are not multiples of 64 included)."""
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, H, W, cin, generator=g).cuda()
+    w1 = (torch.randn(3, 3, cin, cout, generator=g) / np.sqrt(9 * cin)).cuda()
+    b1 = torch.randn(cout, generator=g).cuda()
+    nw = 9 * cin * cout
+    pf = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+    pd = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+    L.call("punet_split_weights_x6", w1.data_ptr(), pf.data_ptr(), nw, cin, cout, 3, 0, S())
+    L.call("punet_split_weights_x6", w1.data_ptr(), pd.data_ptr(), nw, cin, cout, 3, 1, S())
+    # y = relu(conv(x)) with its gate bits
+    y = torch.empty(B, H, W, cout, device="cuda")
+    nb = L.call("punet_gate_dwords", B, H, W, cout)
+    bits = torch.full((nb,), -1, dtype=torch.int32, device="cuda")
+    L.call("punet_conv3x3_x6_gated", x.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, b1.data_ptr(), 0, y.data_ptr(), cout,
+           None, None, bits.data_ptr(), 0, 1, B, H, W, S())
+    y_plain = torch.empty_like(y)
+    L.call("punet_conv3x3_x6", x.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, b1.data_ptr(), 0, y_plain.data_ptr(), cout,
+           None, 0, 1, B, H, W, S())
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_plain)
+    # decode the documented layout on the host and compare with (y > 0)
+    tiles, cbs = (W + 31) // 32, (cout + 63) // 64
+    d = bits.cpu().numpy().astype(np.uint32).reshape(B, H, tiles, cbs, 64)
+    yy = (y.cpu().numpy() > 0)
+    for (bb, hh, xx, cc) in [(0, 0, 0, 0), (B - 1, H - 1, W - 1, cout - 1), (0, H // 2, W // 3, cout // 2), (B - 1, 1, 5, 7)]:
+        lane = 16 * (xx % 4) + (cc % 64) // 4
+        bit = 4 * ((xx % 32) // 4) + (cc % 4)
+        assert bool((d[bb, hh, xx // 32, cc // 64, lane] >> bit) & 1) == bool(yy[bb, hh, xx, cc])
+    # now a second conv's input gradient w.r.t. y, gated either way (here: treat y as the source, its own grad as dz)
+    dz = torch.randn(B, H, W, cin, generator=g).cuda()  # gradient of a conv cout -> cin applied to y
+    w2 = (torch.randn(3, 3, cout, cin, generator=g) / np.sqrt(9 * cout)).cuda()
+    p2 = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+    L.call("punet_split_weights_x6", w2.data_ptr(), p2.data_ptr(), nw, cout, cin, 3, 1, S())
+    prev = torch.randn(B, H, W, cout, generator=g).cuda()
+    for acc in (0, 1):
+        d_mask, d_bits = prev.clone(), prev.clone()
+        L.call("punet_conv3x3_x6_gated", dz.data_ptr(), cin, None, 0, p2.data_ptr(), nw, cout, 0, None, 0, d_mask.data_ptr(), cout,
+               y.data_ptr(), None, None, acc, 0, B, H, W, S())
+        L.call("punet_conv3x3_x6_gated", dz.data_ptr(), cin, None, 0, p2.data_ptr(), nw, cout, 0, None, 0, d_bits.data_ptr(), cout,
+               None, bits.data_ptr(), None, acc, 0, B, H, W, S())
+        torch.cuda.synchronize()
+        assert torch.equal(d_mask, d_bits)
+    with pytest.raises(RuntimeError):
+        L.call("punet_conv3x3_x6_gated", dz.data_ptr(), cin, None, 0, p2.data_ptr(), nw, cout, 0, None, 0, d_bits.data_ptr(), cout,
+               y.data_ptr(), bits.data_ptr(), None, 0, 0, B, H, W, S())

@@ -35,6 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--bits", type=int, default=1, help="1: input gradient gated by bits; 0: by the fp32 activation")
     a = ap.parse_args()
     S = torch.cuda.current_stream().cuda_stream
     B = a.batch
@@ -64,9 +65,11 @@ def main():
             L.call("punet_conv3x3_x6", x0.data_ptr(), c0, x1.data_ptr() if c1 else None, c1, pf.data_ptr(), nw, cout, 0,
                    b.data_ptr(), 0, y.data_ptr(), cout, None, 0, 1, B, hw, hw, S)
 
-        def dgrad():  # gradient w.r.t. the first source, ReLU-gated
-            L.call("punet_conv3x3_x6", dz.data_ptr(), cout, None, 0, pd.data_ptr(), nw, cin, 0, None, 0, dx.data_ptr(), c0,
-                   x0.data_ptr(), 0, 0, B, hw, hw, S)
+        bits = torch.zeros(L.call("punet_gate_dwords", B, hw, hw, c0), dtype=torch.int32, device="cuda")
+
+        def dgrad():  # gradient w.r.t. the first source, ReLU-gated (bit form of the gate, as the engine does)
+            L.call("punet_conv3x3_x6_gated", dz.data_ptr(), cout, None, 0, pd.data_ptr(), nw, cin, 0, None, 0, dx.data_ptr(), c0,
+                   None if a.bits else x0.data_ptr(), bits.data_ptr() if a.bits else None, None, 0, 0, B, hw, hw, S)
 
         def wgrad():
             L.call("punet_conv_wgrad_x6", x0.data_ptr(), c0, dz.data_ptr(), cout, dw.data_ptr(), cin, 0, db.data_ptr(),
