@@ -79,7 +79,8 @@ int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1, const voi
 /* The same with the ReLU gate as BITS (1/32 of the fp32 gate's traffic and no per-lane load chain in the epilogue).
  * A [B,H,W,C] activation has punet_gate_dwords(B,H,W,C) = B*H*ceil(W/32)*ceil(C/64)*64 dwords: the block {row y,
  * pixels 32t..32t+31, channels 64cb..64cb+63} owns dwords ((((b*H + y)*ceil(W/32) + t)*ceil(C/64) + cb)*64 + l),
- * l = 16*(x % 4) + (c % 64)/4, and bit 4*((x % 32)/4) + (c % 4) of dword l is (activation[b][y][x][c] > 0).
+ * l = (x % 32) + 32*((c % 8)/4), and bit 16*((c % 64)/32) + 4*((c % 32)/8) + (c % 4) of dword l is
+ * (activation[b][y][x][c] > 0) - the lane / accumulator-register mapping of the kernels' epilogue.
  * gate_out (forward, relu != 0): written for the output y; gate_bits (input gradient): the gate of the tensor dx belongs
  * to, replaces `mask`. */
 size_t punet_gate_dwords(int B, int H, int W, int C);

@@ -131,8 +131,8 @@ def test_gate_bits_equal_fp32_gate(L, B, H, W, cin, cout):
     d = bits.cpu().numpy().astype(np.uint32).reshape(B, H, tiles, cbs, 64)
     yy = (y.cpu().numpy() > 0)
     for (bb, hh, xx, cc) in [(0, 0, 0, 0), (B - 1, H - 1, W - 1, cout - 1), (0, H // 2, W // 3, cout // 2), (B - 1, 1, 5, 7)]:
-        lane = 16 * (xx % 4) + (cc % 64) // 4
-        bit = 4 * ((xx % 32) // 4) + (cc % 4)
+        lane = (xx % 32) + 32 * ((cc % 8) // 4)
+        bit = 16 * ((cc % 64) // 32) + 4 * ((cc % 32) // 8) + (cc % 4)
         assert bool((d[bb, hh, xx // 32, cc // 64, lane] >> bit) & 1) == bool(yy[bb, hh, xx, cc])
     # now a second conv's input gradient w.r.t. y, gated either way (here: treat y as the source, its own grad as dz)
     dz = torch.randn(B, H, W, cin, generator=g).cuda()  # gradient of a conv cout -> cin applied to y
