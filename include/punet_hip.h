@@ -99,7 +99,9 @@ int punet_conv_wgrad(const float* x, int cs, const float* dz, int cout, float* d
                      float scale, void* stream);
 
 /* ---- K3x6: the 3x3 weight (+ bias) gradient with the same three-plane bf16 arithmetic as K1x6 (fp32-accurate); operands
- *      are fetched with the transposing LDS read ds_read_b64_tr_b16.  Arguments as punet_conv_wgrad (ksize = 3). */
+ *      are fetched with the transposing LDS read ds_read_b64_tr_b16.  Arguments as punet_conv_wgrad (ksize = 3); nslices
+ *      from punet_wgrad_x6_slices, workspace from punet_wgrad_workspace_floats(cs, cout, 3, nslices). */
+int punet_wgrad_x6_slices(int cs, int cout, int B, int H, int W); /* split-K slices (one resident workgroup per CU) */
 int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off,
                         float* dbias, float* workspace, int nslices, int B, int H, int W, int accumulate, float scale,
                         void* stream);

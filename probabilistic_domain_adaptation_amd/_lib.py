@@ -32,6 +32,7 @@ _SIGS = {
     "punet_conv3x3_x6_gated": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "punet_wgrad_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "punet_wgrad_slices": (_i, [_i, _i, _i, _i, _i]),
+    "punet_wgrad_x6_slices": (_i, [_i, _i, _i, _i, _i]),
     "punet_conv_wgrad": (_i, [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
     "punet_conv_wgrad_x6": (_i, [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "punet_conv3x3_small_fwd": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
@@ -69,7 +70,7 @@ _SIGS = {
 }
 
 _NO_WRAP = {"punet_last_error", "punet_build_info", "punet_device_ok", "punet_wgrad_workspace_floats", "punet_gate_dwords",
-            "punet_wgrad_slices", "punet_small_wgrad_workspace_floats", "punet_chan_sum_workspace_floats",
+            "punet_wgrad_slices", "punet_wgrad_x6_slices", "punet_small_wgrad_workspace_floats", "punet_chan_sum_workspace_floats",
             "punet_dot_bwd_workspace_floats", "punet_loss_workspace_floats", "punet_standardize_workspace_doubles"}
 
 _lib = None

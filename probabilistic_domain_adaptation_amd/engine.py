@@ -478,9 +478,10 @@ class PUNetEngine:
             _lib.call("punet_conv3x3_small_wgrad", x.ptr, c.cin, dz.data_ptr(), c.cout, dw, db, ws.data_ptr(), B, H, W,
                       int(accumulate), 1.0, _stream())
             return
-        ns = _lib.call("punet_wgrad_slices", x.C, c.cout, B, H, W)
+        x6 = self.x6 and c.k == 3
+        ns = _lib.call("punet_wgrad_x6_slices" if x6 else "punet_wgrad_slices", x.C, c.cout, B, H, W)
         ws = self.ws.get("wgrad", _lib.call("punet_wgrad_workspace_floats", x.C, c.cout, c.k, ns))
-        if self.x6 and c.k == 3:
+        if x6:
             self._timed("conv3x3_wgrad", 2.0 * B * H * W * x.C * c.cout * 9, "punet_conv_wgrad_x6", x.ptr, x.C, dz.data_ptr(),
                         c.cout, dw, c.cin, ci_off, db if with_bias else None, ws.data_ptr(), ns, B, H, W, int(accumulate), 1.0,
                         _stream())

@@ -54,7 +54,7 @@ def test_kernels_error_bands(L, products):
     DX = torch.zeros(B, H, W, cin, device="cuda")
     dw = torch.zeros(3, 3, cin, cout, device="cuda")
     db = torch.zeros(cout, device="cuda")
-    ns = L.call("punet_wgrad_slices", cin, cout, B, H, W)
+    ns = L.call("punet_wgrad_x6_slices", cin, cout, B, H, W)
     ws = torch.empty(L.call("punet_wgrad_workspace_floats", cin, cout, 3, ns), device="cuda")
     engine.set_x6_products(products)
     L.call("punet_conv3x3_x6", X.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, b.detach().cuda().data_ptr(), 0, Y.data_ptr(),

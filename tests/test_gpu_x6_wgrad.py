@@ -30,7 +30,7 @@ def test_wgrad_x6(B, H, W, cin, cout):
     tot, off = cin + 8, 8
     dw = torch.zeros(3, 3, tot, cout, device="cuda")
     db = torch.full((cout,), float("nan"), device="cuda")
-    ns = L.call("punet_wgrad_slices", cin, cout, B, H, W)
+    ns = L.call("punet_wgrad_x6_slices", cin, cout, B, H, W)
     ws = torch.empty(L.call("punet_wgrad_workspace_floats", cin, cout, 3, ns), device="cuda")
     L.call("punet_conv_wgrad_x6", X.data_ptr(), cin, DZ.data_ptr(), cout, dw.data_ptr(), tot, off, db.data_ptr(), ws.data_ptr(), ns,
            B, H, W, 0, 1.0, S)

@@ -35,6 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--slices-div", type=int, default=1, help="divide the split-K slice count of the weight gradient")
     ap.add_argument("--bits", type=int, default=1, help="1: input gradient gated by bits; 0: by the fp32 activation")
     a = ap.parse_args()
     S = torch.cuda.current_stream().cuda_stream
@@ -58,7 +59,7 @@ def main():
         dx = torch.zeros(B, hw, hw, c0, device="cuda")
         dw = torch.empty(3, 3, cin, cout, device="cuda")
         db = torch.empty(cout, device="cuda")
-        ns = L.call("punet_wgrad_slices", c0, cout, B, hw, hw)
+        ns = max(1, L.call("punet_wgrad_x6_slices", c0, cout, B, hw, hw) // a.slices_div)
         ws = torch.empty(L.call("punet_wgrad_workspace_floats", c0, cout, 3, ns), device="cuda")
 
         def fwd():
