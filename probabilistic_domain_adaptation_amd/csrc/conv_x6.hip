@@ -21,10 +21,9 @@
 // Weights arrive pre-split (punet_split_weights_x6, once per optimizer step) as planes[3][tap][K/8][N][8] bf16, so their
 // staging is a pure copy; activations are split while being staged (v_cvt_pk_bf16_f32, ~6 VALU ops per element,
 // amortised over 9 taps x 64 output channels).
-// Epilogue: the accumulator tiles are transposed through LDS (per-wave region, no cross-wave traffic) so that every
-// global access is a 16-byte one - 16 lanes cover the 64 channels of a pixel = 256 contiguous bytes: 16 stores (+ 16 gate
-// loads for the ReLU backward, + 16 loads when accumulating) per thread and tile instead of 64 of each.  With the main
-// loop 1.5x faster than the fp32 kernel the 4-byte epilogue had become 40 % of the dgrad time on the 64-channel layers.
+// Epilogue: the MFMAs run with the operands swapped (weights as A, pixels as B), so a lane ends up with one pixel and,
+// per accumulator register quad, four consecutive channels: 16-byte stores straight from the accumulators, no LDS
+// staging, no barrier (history and measurements at the epilogue lambda).  ReLU gates travel as bits (punet_gate_dwords).
 #include <type_traits>
 #include "common.h"
 #include "punet_hip.h"
@@ -53,6 +52,7 @@ struct ConvX6Args {
     unsigned* gate_out;         // forward with ReLU: (y > 0) bits of the output
     int accumulate, relu;
     int B, H, W, ntiles;
+    int xcd_remap;
 };
 
 struct TileInfo {
@@ -255,7 +255,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
         }
     };
 
+    // XCD-aware start tile: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), while consecutive tile
+    // indices share their input pixels (they differ in the output-channel block first, then in the neighbouring pixel
+    // block).  Give each XCD a CONTIGUOUS range of tiles so that those re-reads hit its own L2 instead of every XCD
+    // fetching the same activations from the fabric.
     int tile = blockIdx.x;
+    if (a.xcd_remap) tile = (tile & 7) * ((int)gridDim.x >> 3) + (tile >> 3);
     if (tile >= a.ntiles) return;
     int ch = 0;
     TileInfo ti = decode(tile);
@@ -482,6 +487,7 @@ extern "C" int punet_conv3x3_x6_gated(const float* x0, int c0, const float* x1, 
     PUNET_CHECK_ARG(!(dgrad && (bias || relu || gate_out)),
                     "punet_conv3x3_x6: bias/relu/gate_out (forward) cannot be combined with mask/gate_bits/accumulate (input gradient)");
     hipStream_t st = (hipStream_t)stream;
+    a.xcd_remap = grid % 8 == 0;  // same-process A/B: +0.5-0.8 % (the tensors of this workload fit the Infinity Cache)
     if (g_punet_x6_planes == 3) {
         if (dgrad) conv3x3_x6_kernel<3, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<3, false><<<grid, 256, 0, st>>>(a);
     } else if (g_punet_x6_planes == 2) {
