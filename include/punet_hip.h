@@ -124,6 +124,12 @@ int punet_pool2x2_bwd(const float* dy, const float* xmask, float* dx, int B, int
  *      dx = (xmask > 0) * ...). H, W are the INPUT sizes. */
 int punet_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
 int punet_upsample2x_bwd(const float* dy, const float* xmask, float* dx, int B, int H, int W, int C, void* stream);
+/* K4/K5 backward with the ReLU gate of x given as bits (punet_gate_dwords layout, as published by punet_conv3x3_x6_gated);
+ * xbits != NULL takes precedence over xmask. */
+int punet_pool2x2_bwd_gated(const float* dy, const float* xmask, const void* xbits, float* dx, int B, int H, int W, int C,
+                            int accumulate, void* stream);
+int punet_upsample2x_bwd_gated(const float* dy, const float* xmask, const void* xbits, float* dx, int B, int H, int W, int C,
+                               void* stream);
 
 /* ---- K6: latent head (probabilistic_unet.py:126-137): mean over H, W then 1x1 conv C -> J = 2*latent_dim.
  *      muls[b][:L] = mu, muls[b][L:] = log_sigma.  mean[b][C] is kept for the backward. */

@@ -42,6 +42,8 @@ _SIGS = {
     "punet_pool2x2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "punet_upsample2x_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "punet_upsample2x_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "punet_pool2x2_bwd_gated": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "punet_upsample2x_bwd_gated": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "punet_chan_sum_workspace_floats": (_sz, [_i, _i, _i]),
     "punet_chan_sum": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
     "punet_latent_head_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

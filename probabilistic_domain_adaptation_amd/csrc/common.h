@@ -39,3 +39,12 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // C/D fragment map of v_mfma_f32_32x32x2_f32 (dtype independent on gfx950):
 //   col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 __device__ __forceinline__ int mfma32_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// ReLU gate bits of a [B,H,W,C] activation (layout documented at punet_gate_dwords in punet_hip.h): the 4 gate bits of
+// channels c .. c+3 (c a multiple of 4) of pixel (b, y, x).
+__device__ __forceinline__ unsigned punet_gate_nibble(const unsigned* __restrict__ bits, size_t b, int H, int W, int C, int y,
+                                                      int x, int c) {
+    const int tiles = (W + 31) >> 5, cbs = (C + 63) >> 6;
+    const size_t idx = (((((size_t)b * H + y) * tiles + (x >> 5)) * cbs + (c >> 6)) << 6) + (x & 31) + 32 * ((c & 7) >> 2);
+    return (bits[idx] >> (16 * ((c & 63) >> 5) + 4 * ((c & 31) >> 3))) & 0xFu;
+}

@@ -72,8 +72,9 @@ __global__ void pool2x2_fwd_kernel(const float4* __restrict__ x, float4* __restr
 }
 
 // dx[b][iy][ix] (+)= (x > 0) * dy[b][iy/2][ix/2] / window
-__global__ void pool2x2_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ xmask, float4* __restrict__ dx,
-                                   int B, int H, int W, int C4, int accumulate) {
+__global__ void pool2x2_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ xmask,
+                                   const unsigned* __restrict__ xbits, float4* __restrict__ dx, int B, int H, int W, int C4,
+                                   int accumulate) {
     const int OH = (H + 1) / 2, OW = (W + 1) / 2;
     const size_t n = (size_t)B * H * W * C4;
     GRID_STRIDE(i, n) {
@@ -88,7 +89,10 @@ __global__ void pool2x2_bwd_kernel(const float4* __restrict__ dy, const float4* 
         const float inv = 1.f / (float)(wh * ww);
         const float4 g = dy[((b * OH + oy) * OW + ox) * C4 + c];
         float4 v = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
-        if (xmask) {
+        if (xbits) {
+            const unsigned g4 = punet_gate_nibble(xbits, b, H, W, 4 * C4, iy, ix, 4 * c);
+            v.x = g4 & 1u ? v.x : 0.f; v.y = g4 & 2u ? v.y : 0.f; v.z = g4 & 4u ? v.z : 0.f; v.w = g4 & 8u ? v.w : 0.f;
+        } else if (xmask) {
             const float4 m = xmask[i];
             v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
             v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
@@ -159,7 +163,8 @@ __device__ __forceinline__ float up_weight(int o, int i, float scale, int in_siz
 
 // dx[b][iy][ix] = (x > 0) * sum_{oy, ox} wy(oy, iy) * wx(ox, ix) * dy[b][oy][ox]
 __global__ void upsample2x_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ xmask,
-                                      float4* __restrict__ dx, int B, int H, int W, int C4) {
+                                      const unsigned* __restrict__ xbits, float4* __restrict__ dx, int B, int H, int W,
+                                      int C4) {
     const int OH = 2 * H, OW = 2 * W;
     const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
     const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
@@ -185,7 +190,10 @@ __global__ void upsample2x_bwd_kernel(const float4* __restrict__ dy, const float
                 s.x += wgt * g.x; s.y += wgt * g.y; s.z += wgt * g.z; s.w += wgt * g.w;
             }
         }
-        if (xmask) {
+        if (xbits) {
+            const unsigned g4 = punet_gate_nibble(xbits, b, H, W, 4 * C4, iy, ix, 4 * c);
+            s.x = g4 & 1u ? s.x : 0.f; s.y = g4 & 2u ? s.y : 0.f; s.z = g4 & 4u ? s.z : 0.f; s.w = g4 & 8u ? s.w : 0.f;
+        } else if (xmask) {
             const float4 m = xmask[i];
             s.x = m.x > 0.f ? s.x : 0.f; s.y = m.y > 0.f ? s.y : 0.f;
             s.z = m.z > 0.f ? s.z : 0.f; s.w = m.w > 0.f ? s.w : 0.f;
@@ -677,10 +685,15 @@ extern "C" int punet_pool2x2_fwd(const float* x, float* y, int B, int H, int W, 
 
 extern "C" int punet_pool2x2_bwd(const float* dy, const float* xmask, float* dx, int B, int H, int W, int C,
                                  int accumulate, void* stream) {
+    return punet_pool2x2_bwd_gated(dy, xmask, nullptr, dx, B, H, W, C, accumulate, stream);
+}
+
+extern "C" int punet_pool2x2_bwd_gated(const float* dy, const float* xmask, const void* xbits, float* dx, int B, int H, int W,
+                                       int C, int accumulate, void* stream) {
     PUNET_CHECK_ARG(dy && dx && C % 4 == 0 && B > 0 && H > 0 && W > 0, "punet_pool2x2_bwd: bad args (C=%d)", C);
     const size_t n = (size_t)B * H * W * (C / 4);
-    pool2x2_bwd_kernel<<<ew_grid(n), EW_BLOCK, 0, STREAM>>>((const float4*)dy, (const float4*)xmask, (float4*)dx, B, H, W,
-                                                            C / 4, accumulate);
+    pool2x2_bwd_kernel<<<ew_grid(n), EW_BLOCK, 0, STREAM>>>((const float4*)dy, (const float4*)xmask, (const unsigned*)xbits,
+                                                            (float4*)dx, B, H, W, C / 4, accumulate);
     PUNET_LAUNCH_CHECK("pool2x2_bwd");
     return PUNET_OK;
 }
@@ -695,10 +708,15 @@ extern "C" int punet_upsample2x_fwd(const float* x, float* y, int B, int H, int 
 
 extern "C" int punet_upsample2x_bwd(const float* dy, const float* xmask, float* dx, int B, int H, int W, int C,
                                     void* stream) {
+    return punet_upsample2x_bwd_gated(dy, xmask, nullptr, dx, B, H, W, C, stream);
+}
+
+extern "C" int punet_upsample2x_bwd_gated(const float* dy, const float* xmask, const void* xbits, float* dx, int B, int H,
+                                          int W, int C, void* stream) {
     PUNET_CHECK_ARG(dy && dx && C % 4 == 0 && B > 0 && H > 0 && W > 0, "punet_upsample2x_bwd: bad args (C=%d)", C);
     const size_t n = (size_t)B * H * W * (C / 4);
-    upsample2x_bwd_kernel<<<ew_grid(n), EW_BLOCK, 0, STREAM>>>((const float4*)dy, (const float4*)xmask, (float4*)dx, B, H, W,
-                                                               C / 4);
+    upsample2x_bwd_kernel<<<ew_grid(n), EW_BLOCK, 0, STREAM>>>((const float4*)dy, (const float4*)xmask, (const unsigned*)xbits,
+                                                               (float4*)dx, B, H, W, C / 4);
     PUNET_LAUNCH_CHECK("upsample2x_bwd");
     return PUNET_OK;
 }

@@ -577,15 +577,17 @@ class PUNetEngine:
                 _, x, y = op
                 dy = gm.pop(id(y))
                 g, acc = self._grad_into(gm, x)
-                _lib.call("punet_pool2x2_bwd", dy.data_ptr(), x.ptr if x.relu_out else None, g.data_ptr(), x.B, x.H, x.W, x.C,
-                          acc, _stream())
+                bits = x.bits.data_ptr() if (x.relu_out and x.bits is not None) else None
+                _lib.call("punet_pool2x2_bwd_gated", dy.data_ptr(), x.ptr if (x.relu_out and bits is None) else None, bits,
+                          g.data_ptr(), x.B, x.H, x.W, x.C, acc, _stream())
             else:
                 _, x, y = op
                 dy = gm.pop(id(y))
                 assert id(x) not in gm
                 g, _ = self._grad_into(gm, x)
-                _lib.call("punet_upsample2x_bwd", dy.data_ptr(), x.ptr if x.relu_out else None, g.data_ptr(), x.B, x.H, x.W,
-                          x.C, _stream())
+                bits = x.bits.data_ptr() if (x.relu_out and x.bits is not None) else None
+                _lib.call("punet_upsample2x_bwd_gated", dy.data_ptr(), x.ptr if (x.relu_out and bits is None) else None, bits,
+                          g.data_ptr(), x.B, x.H, x.W, x.C, _stream())
 
     def elbo_backward(self, flat, gflat, st, accumulate=False, after_unet=None):
         """Gradient of gscale * (reconstruction_loss + beta * kl) w.r.t. every parameter into gflat

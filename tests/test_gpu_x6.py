@@ -151,3 +151,33 @@ def test_gate_bits_equal_fp32_gate(L, B, H, W, cin, cout):
     with pytest.raises(RuntimeError):
         L.call("punet_conv3x3_x6_gated", dz.data_ptr(), cin, None, 0, p2.data_ptr(), nw, cout, 0, None, 0, d_bits.data_ptr(), cout,
                y.data_ptr(), bits.data_ptr(), None, 0, 0, B, H, W, S())
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 64, 32, 64), (1, 24, 40, 64, 96)])
+def test_pool_and_upsample_backward_take_the_gate_bits(L, B, H, W, cin, cout):
+    """K4/K5 backward gated by the bits the forward conv published == gated by the fp32 activation (bit-identical)."""
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(B, H, W, cin, generator=g).cuda()
+    w1 = (torch.randn(3, 3, cin, cout, generator=g) / np.sqrt(9 * cin)).cuda()
+    b1 = torch.randn(cout, generator=g).cuda()
+    nw = 9 * cin * cout
+    pf = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+    L.call("punet_split_weights_x6", w1.data_ptr(), pf.data_ptr(), nw, cin, cout, 3, 0, S())
+    y = torch.empty(B, H, W, cout, device="cuda")
+    bits = torch.zeros(L.call("punet_gate_dwords", B, H, W, cout), dtype=torch.int32, device="cuda")
+    L.call("punet_conv3x3_x6_gated", x.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, b1.data_ptr(), 0, y.data_ptr(), cout,
+           None, None, bits.data_ptr(), 0, 1, B, H, W, S())
+    dyp = torch.randn(B, (H + 1) // 2, (W + 1) // 2, cout, generator=g).cuda()
+    dyu = torch.randn(B, 2 * H, 2 * W, cout, generator=g).cuda()
+    prev = torch.randn(B, H, W, cout, generator=g).cuda()
+    for acc in (0, 1):
+        a_, b_ = prev.clone(), prev.clone()
+        L.call("punet_pool2x2_bwd_gated", dyp.data_ptr(), y.data_ptr(), None, a_.data_ptr(), B, H, W, cout, acc, S())
+        L.call("punet_pool2x2_bwd_gated", dyp.data_ptr(), None, bits.data_ptr(), b_.data_ptr(), B, H, W, cout, acc, S())
+        torch.cuda.synchronize()
+        assert torch.equal(a_, b_)
+    a_, b_ = torch.empty_like(prev), torch.empty_like(prev)
+    L.call("punet_upsample2x_bwd_gated", dyu.data_ptr(), y.data_ptr(), None, a_.data_ptr(), B, H, W, cout, S())
+    L.call("punet_upsample2x_bwd_gated", dyu.data_ptr(), None, bits.data_ptr(), b_.data_ptr(), B, H, W, cout, S())
+    torch.cuda.synchronize()
+    assert torch.equal(a_, b_) and (a_ == 0).float().mean().item() > 0.2
