@@ -27,22 +27,31 @@ __global__ __launch_bounds__(256) void conv3x3_small_fwd_kernel(const float* __r
     for (int it = 0; it < pix_per_block; it += ppb) {
         const size_t p = base + it + pl;
         if (p >= P) break;
-        const int px = (int)(p % W);
-        const int py = (int)((p / W) % H);
-        const size_t b = p / ((size_t)W * H);
+        // 32-bit index arithmetic (P < 2^31 is checked on the host): 64-bit divisions had made this HBM-bound kernel
+        // VALU-bound
+        const unsigned pu = (unsigned)p, row = pu / (unsigned)W;
+        const int px = (int)(pu - row * (unsigned)W);
+        const unsigned bu = row / (unsigned)H;
+        const int py = (int)(row - bu * (unsigned)H);
+        const size_t b = bu;
         float4 o = bv;
+        // branch-free taps: all 9 * CIN loads are issued together (clamped address, zero weight outside the image); a
+        // `continue` per tap had serialised them into nine load -> wait -> fma rounds
+        float xin[9 * CIN];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int gy = py + t / 3 - 1, gx = px + t % 3 - 1;
-            if (gy < 0 || gy >= H || gx < 0 || gx >= W) continue;
-            const float* xp = x + ((b * H + gy) * W + gx) * CIN;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const float* xp = x + ((b * H + (in ? gy : py)) * W + (in ? gx : px)) * CIN;
 #pragma unroll
-            for (int c = 0; c < CIN; ++c) {
-                const float xv = xp[c];
-                const float4 ww = wr[t * CIN + c];
-                o.x = fmaf(xv, ww.x, o.x); o.y = fmaf(xv, ww.y, o.y);
-                o.z = fmaf(xv, ww.z, o.z); o.w = fmaf(xv, ww.w, o.w);
-            }
+            for (int c = 0; c < CIN; ++c) xin[t * CIN + c] = in ? xp[c] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 9 * CIN; ++i) {
+            const float xv = xin[i];
+            const float4 ww = wr[i];
+            o.x = fmaf(xv, ww.x, o.x); o.y = fmaf(xv, ww.y, o.y);
+            o.z = fmaf(xv, ww.z, o.z); o.w = fmaf(xv, ww.w, o.w);
         }
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         *reinterpret_cast<float4*>(y + p * cout + g * 4) = o;
@@ -64,23 +73,28 @@ __global__ __launch_bounds__(256) void conv3x3_small_wgrad_kernel(const float* _
     const size_t P = (size_t)B * H * W;
     if (pl < ppb) {
         for (size_t p = (size_t)blockIdx.x * ppb + pl; p < P; p += (size_t)gridDim.x * ppb) {
-            const int px = (int)(p % W);
-            const int py = (int)((p / W) % H);
-            const size_t b = p / ((size_t)W * H);
+            const unsigned pu = (unsigned)p, row = pu / (unsigned)W;
+            const int px = (int)(pu - row * (unsigned)W);
+            const unsigned bu = row / (unsigned)H;
+            const int py = (int)(row - bu * (unsigned)H);
+            const size_t b = bu;
             const float4 d = *reinterpret_cast<const float4*>(dz + p * cout + g * 4);
             acc[ROWS - 1].x += d.x; acc[ROWS - 1].y += d.y; acc[ROWS - 1].z += d.z; acc[ROWS - 1].w += d.w;
+            float xin[9 * CIN];  // branch-free taps, as in the forward
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int gy = py + t / 3 - 1, gx = px + t % 3 - 1;
-                if (gy < 0 || gy >= H || gx < 0 || gx >= W) continue;
-                const float* xp = x + ((b * H + gy) * W + gx) * CIN;
+                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const float* xp = x + ((b * H + (in ? gy : py)) * W + (in ? gx : px)) * CIN;
 #pragma unroll
-                for (int c = 0; c < CIN; ++c) {
-                    const float xv = xp[c];
-                    float4& a = acc[t * CIN + c];
-                    a.x = fmaf(xv, d.x, a.x); a.y = fmaf(xv, d.y, a.y);
-                    a.z = fmaf(xv, d.z, a.z); a.w = fmaf(xv, d.w, a.w);
-                }
+                for (int c = 0; c < CIN; ++c) xin[t * CIN + c] = in ? xp[c] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 9 * CIN; ++i) {
+                const float xv = xin[i];
+                float4& a = acc[i];
+                a.x = fmaf(xv, d.x, a.x); a.y = fmaf(xv, d.y, a.y);
+                a.z = fmaf(xv, d.z, a.z); a.w = fmaf(xv, d.w, a.w);
             }
         }
     }
@@ -118,6 +132,7 @@ extern "C" int punet_conv3x3_small_fwd(const float* x, int cin, const float* w, 
     PUNET_CHECK_ARG(cout >= 4 && cout % 4 == 0 && 256 % (cout / 4) == 0 && cout <= 1024,
                     "punet_conv3x3_small_fwd: cout/4 must divide 256 (got cout=%d)", cout);
     const size_t P = (size_t)B * H * W;
+    PUNET_CHECK_ARG(P < (1ull << 31), "punet_conv3x3_small_fwd: more than 2^31 pixels");
     const int ppb = 256 / (cout / 4);
     const int pix_per_block = ppb * 16;
     const int grid = (int)((P + pix_per_block - 1) / pix_per_block);
@@ -144,6 +159,7 @@ extern "C" int punet_conv3x3_small_wgrad(const float* x, int cin, const float* d
     PUNET_CHECK_ARG(cout >= 4 && cout % 4 == 0 && 64 % (cout / 4) == 0,
                     "punet_conv3x3_small_wgrad: cout/4 must divide 64 (got cout=%d)", cout);
     const size_t P = (size_t)B * H * W;
+    PUNET_CHECK_ARG(P < (1ull << 31), "punet_conv3x3_small_wgrad: more than 2^31 pixels");
     const int groups = cout / 4, ppb = 256 / groups;
     int grid = (int)((P + ppb - 1) / ppb);
     if (grid > SMALL_WGRAD_BLOCKS) grid = SMALL_WGRAD_BLOCKS;

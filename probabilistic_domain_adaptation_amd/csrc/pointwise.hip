@@ -52,12 +52,13 @@ __global__ void pool2x2_fwd_kernel(const float4* __restrict__ x, float4* __restr
     const int OH = (H + 1) / 2, OW = (W + 1) / 2;
     const size_t n = (size_t)B * OH * OW * C4;
     GRID_STRIDE(i, n) {
-        const int c = (int)(i % C4);
-        size_t p = i / C4;
-        const int ox = (int)(p % OW);
-        p /= OW;
-        const int oy = (int)(p % OH);
-        const size_t b = p / OH;
+        unsigned p = (unsigned)i / (unsigned)C4;  // 32-bit index arithmetic (n < 2^31 checked on the host)
+        const int c = (int)((unsigned)i - p * (unsigned)C4);
+        unsigned q = p / (unsigned)OW;
+        const int ox = (int)(p - q * (unsigned)OW);
+        const unsigned bu = q / (unsigned)OH;
+        const int oy = (int)(q - bu * (unsigned)OH);
+        const size_t b = bu;
         const int y0 = oy * 2, x0 = ox * 2;
         const int y1 = min(y0 + 2, H), x1 = min(x0 + 2, W);
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -78,12 +79,13 @@ __global__ void pool2x2_bwd_kernel(const float4* __restrict__ dy, const float4* 
     const int OH = (H + 1) / 2, OW = (W + 1) / 2;
     const size_t n = (size_t)B * H * W * C4;
     GRID_STRIDE(i, n) {
-        const int c = (int)(i % C4);
-        size_t p = i / C4;
-        const int ix = (int)(p % W);
-        p /= W;
-        const int iy = (int)(p % H);
-        const size_t b = p / H;
+        unsigned p = (unsigned)i / (unsigned)C4;  // 32-bit index arithmetic (n < 2^31 checked on the host)
+        const int c = (int)((unsigned)i - p * (unsigned)C4);
+        unsigned q = p / (unsigned)W;
+        const int ix = (int)(p - q * (unsigned)W);
+        const unsigned bu = q / (unsigned)H;
+        const int iy = (int)(q - bu * (unsigned)H);
+        const size_t b = bu;
         const int oy = iy / 2, ox = ix / 2;
         const int wh = min(oy * 2 + 2, H) - oy * 2, ww = min(ox * 2 + 2, W) - ox * 2;
         const float inv = 1.f / (float)(wh * ww);
@@ -126,12 +128,13 @@ __global__ void upsample2x_fwd_kernel(const float4* __restrict__ x, float4* __re
     const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
     const size_t n = (size_t)B * OH * OW * C4;
     GRID_STRIDE(i, n) {
-        const int c = (int)(i % C4);
-        size_t p = i / C4;
-        const int ox = (int)(p % OW);
-        p /= OW;
-        const int oy = (int)(p % OH);
-        const size_t b = p / OH;
+        unsigned p = (unsigned)i / (unsigned)C4;  // 32-bit index arithmetic (n < 2^31 checked on the host)
+        const int c = (int)((unsigned)i - p * (unsigned)C4);
+        unsigned q = p / (unsigned)OW;
+        const int ox = (int)(p - q * (unsigned)OW);
+        const unsigned bu = q / (unsigned)OH;
+        const int oy = (int)(q - bu * (unsigned)OH);
+        const size_t b = bu;
         int h1, hp, w1, wp;
         float hl1, wl1;
         up_src(oy, sh, H, h1, hp, hl1);
@@ -170,12 +173,13 @@ __global__ void upsample2x_bwd_kernel(const float4* __restrict__ dy, const float
     const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
     const size_t n = (size_t)B * H * W * C4;
     GRID_STRIDE(i, n) {
-        const int c = (int)(i % C4);
-        size_t p = i / C4;
-        const int ix = (int)(p % W);
-        p /= W;
-        const int iy = (int)(p % H);
-        const size_t b = p / H;
+        unsigned p = (unsigned)i / (unsigned)C4;  // 32-bit index arithmetic (n < 2^31 checked on the host)
+        const int c = (int)((unsigned)i - p * (unsigned)C4);
+        unsigned q = p / (unsigned)W;
+        const int ix = (int)(p - q * (unsigned)W);
+        const unsigned bu = q / (unsigned)H;
+        const int iy = (int)(q - bu * (unsigned)H);
+        const size_t b = bu;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         const int oy0 = max(0, 2 * iy - 2), oy1 = min(OH - 1, 2 * iy + 4);
         const int ox0 = max(0, 2 * ix - 2), ox1 = min(OW - 1, 2 * ix + 4);
@@ -678,6 +682,7 @@ int punet_launch_reduce_slabs(const float* partial, int nslices, size_t slab_str
 extern "C" int punet_pool2x2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
     PUNET_CHECK_ARG(x && y && C % 4 == 0 && B > 0 && H > 0 && W > 0, "punet_pool2x2_fwd: bad args (C=%d)", C);
     const size_t n = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    PUNET_CHECK_ARG(n < (1ull << 31), "punet_pool2x2_fwd: more than 2^31 float4 elements");
     pool2x2_fwd_kernel<<<ew_grid(n), EW_BLOCK, 0, STREAM>>>((const float4*)x, (float4*)y, B, H, W, C / 4);
     PUNET_LAUNCH_CHECK("pool2x2_fwd");
     return PUNET_OK;
@@ -692,6 +697,7 @@ extern "C" int punet_pool2x2_bwd_gated(const float* dy, const float* xmask, cons
                                        int C, int accumulate, void* stream) {
     PUNET_CHECK_ARG(dy && dx && C % 4 == 0 && B > 0 && H > 0 && W > 0, "punet_pool2x2_bwd: bad args (C=%d)", C);
     const size_t n = (size_t)B * H * W * (C / 4);
+    PUNET_CHECK_ARG(n < (1ull << 31), "punet_pool2x2_bwd: more than 2^31 float4 elements");
     pool2x2_bwd_kernel<<<ew_grid(n), EW_BLOCK, 0, STREAM>>>((const float4*)dy, (const float4*)xmask, (const unsigned*)xbits,
                                                             (float4*)dx, B, H, W, C / 4, accumulate);
     PUNET_LAUNCH_CHECK("pool2x2_bwd");
@@ -701,6 +707,7 @@ extern "C" int punet_pool2x2_bwd_gated(const float* dy, const float* xmask, cons
 extern "C" int punet_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
     PUNET_CHECK_ARG(x && y && C % 4 == 0 && B > 0 && H > 0 && W > 0, "punet_upsample2x_fwd: bad args (C=%d)", C);
     const size_t n = (size_t)B * 4 * H * W * (C / 4);
+    PUNET_CHECK_ARG(n < (1ull << 31), "punet_upsample2x_fwd: more than 2^31 float4 elements");
     upsample2x_fwd_kernel<<<ew_grid(n), EW_BLOCK, 0, STREAM>>>((const float4*)x, (float4*)y, B, H, W, C / 4);
     PUNET_LAUNCH_CHECK("upsample2x_fwd");
     return PUNET_OK;
@@ -715,6 +722,7 @@ extern "C" int punet_upsample2x_bwd_gated(const float* dy, const float* xmask, c
                                           int W, int C, void* stream) {
     PUNET_CHECK_ARG(dy && dx && C % 4 == 0 && B > 0 && H > 0 && W > 0, "punet_upsample2x_bwd: bad args (C=%d)", C);
     const size_t n = (size_t)B * H * W * (C / 4);
+    PUNET_CHECK_ARG(n < (1ull << 31), "punet_upsample2x_bwd: more than 2^31 float4 elements");
     upsample2x_bwd_kernel<<<ew_grid(n), EW_BLOCK, 0, STREAM>>>((const float4*)dy, (const float4*)xmask, (const unsigned*)xbits,
                                                                (float4*)dx, B, H, W, C / 4);
     PUNET_LAUNCH_CHECK("upsample2x_bwd");
