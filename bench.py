@@ -236,16 +236,14 @@ def main():
             traffic, traffic_note = None, "not collected"
             try:  # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.py)
                 if a.workload == "mean_teacher" and (B, H, W, N) == (4, 512, 512, 8) and eng.conv_mode in ("x6", "f32"):
-                    fn, key = {"x6": ("pmc_hbm_traffic_x6.json", "conv3x3_x6_kernel<3>"),
+                    fn, key = {"x6": ("pmc_hbm_traffic_x6.json", "conv3x3_x6_kernel<3, false>"),
                                "f32": ("pmc_hbm_traffic.json", "conv_mfma_kernel<3, false>")}[eng.conv_mode]
                     pm = json.load(open(os.path.join(ROOT, "profiles", "r01", fn)))
                     traffic = round(pm["kernels"][key]["hbm_bytes_per_launch"])
                     traffic_note = ("bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE in separate "
-                                    f"passes of this same workload (profiles/r01/{fn}); the kernel also serves the input-gradient "
-                                    "launches, so this is the mean over forward and input-gradient launches (algorithmic mean "
-                                    "over the same launches: 312 MB = activations in + out (+ ReLU gate) + weight planes); "
-                                    "FETCH_SIZE includes halo re-reads (1.33x) and Infinity-Cache refills of tiles shared by "
-                                    "the output-channel blocks")
+                                    f"passes of this same workload (profiles/r01/{fn}), mean over the launches of the forward "
+                                    "instantiation (algorithmic mean over the forward launches: 265 MB = 144 MB activations in + "
+                                    "weight planes, 121 MB out); FETCH_SIZE includes the 1.33x halo re-reads of the 8x32-pixel tiles")
             except Exception:
                 pass
             if k3:

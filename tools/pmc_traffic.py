@@ -26,7 +26,8 @@ def load(path, counter):
 
 
 def short(name):
-    for key in ("conv3x3_x6_kernel<3>", "conv3x3_x6_kernel<2>", "conv3x3_x6_kernel<1>", "wgrad3x3_x6_kernel<3>",
+    for key in ("conv3x3_x6_kernel<3, false>", "conv3x3_x6_kernel<3, true>", "conv3x3_x6_kernel<2, false>",
+                "conv3x3_x6_kernel<2, true>", "conv3x3_x6_kernel<1, false>", "conv3x3_x6_kernel<1, true>", "wgrad3x3_x6_kernel<3>",
                 "wgrad3x3_x6_kernel<2>", "wgrad3x3_x6_kernel<1>", "conv_mfma_kernel<3, false>", "conv_mfma_kernel<3, true>", "conv_mfma_kernel<1, false>",
                 "conv_mfma_kernel<1, true>", "wgrad_mfma_kernel<3>", "wgrad_mfma_kernel<1>", "fcomb_sampler_kernel<2>"):
         if key in name:
