@@ -88,6 +88,12 @@ int punet_conv3x3_x6_gated(const float* x0, int c0, const float* x1, int c1, con
                            int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out,
                            const float* mask, const void* gate_bits, void* gate_out, int accumulate, int relu, int B,
                            int H, int W, void* stream);
+/* The same kernel for 1x1 convolutions (the Fcomb layers, probabilistic_unet.py:168-173): planes from
+ * punet_split_weights_x6(..., ksize = 1, ...), c0/c1 multiples of 8; always the six-product parity arithmetic. */
+int punet_conv1x1_x6_gated(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
+                           int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out,
+                           const float* mask, const void* gate_bits, void* gate_out, int accumulate, int relu, int B,
+                           int H, int W, void* stream);
 
 /* ---- K3: autograd weight + bias gradient of K1 (convolution_backward, weight/bias), fp32 MFMA, deterministic split-K.
  *      x has cs channels and fills rows [ci_off, ci_off+cs) of dw[k][k][cin_total][cout]; dbias may be NULL.

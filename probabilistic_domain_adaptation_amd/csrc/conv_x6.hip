@@ -77,9 +77,10 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
 // DGRAD selects the epilogue: false = forward (bias, ReLU, optional gate bits of the output); true = input gradient
 // (ReLU gate of the destination as fp32 mask or bits, optional accumulate).  Two instantiations instead of run-time
 // flags: the kernel sits at the 256-VGPR limit and every live flag / pointer of the other mode costs registers.
-template <int NP, bool DGRAD>
+// KS = 3 or 1 (the Fcomb layers): with one tap the "last tap, two chunks per K-step" pairing is the whole K loop.
+template <int NP, bool DGRAD, int KS = 3>
 __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
-    constexpr int KS = 3, KK = 9, PAD = 1;
+    constexpr int KK = KS * KS, PAD = KS / 2;
     constexpr int HTH = TH + KS - 1, HTW = TW + KS - 1;
     constexpr int NPIX = HTH * HTW;
     constexpr int XUNITS = NPIX * (CK / 4);
@@ -426,14 +427,15 @@ extern "C" int punet_set_x6_products(int n) {
 
 extern "C" int punet_split_weights_x6(const float* w, void* planes, long plane_stride, int cin, int cout, int ksize, int mode,
                                       void* stream) {
-    PUNET_CHECK_ARG(w && planes && cin > 0 && cout > 0 && ksize == 3 && (mode == 0 || mode == 1),
+    PUNET_CHECK_ARG(w && planes && cin > 0 && cout > 0 && (ksize == 3 || ksize == 1) && (mode == 0 || mode == 1),
                     "punet_split_weights_x6: bad args");
     PUNET_CHECK_ARG((mode == 0 ? cin : cout) % 8 == 0, "punet_split_weights_x6: the contracted channel count must be a multiple of 8");
-    PUNET_CHECK_ARG(plane_stride >= (long)9 * cin * cout, "punet_split_weights_x6: plane_stride too small");
-    const size_t total = (size_t)9 * cin * cout / 8;
+    const int kk = ksize * ksize;
+    PUNET_CHECK_ARG(plane_stride >= (long)kk * cin * cout, "punet_split_weights_x6: plane_stride too small");
+    const size_t total = (size_t)kk * cin * cout / 8;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    split_weights_x6_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(w, (__bf16*)planes, plane_stride, cin, cout, 9, mode);
+    split_weights_x6_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(w, (__bf16*)planes, plane_stride, cin, cout, kk, mode);
     PUNET_LAUNCH_CHECK("split_weights_x6");
     return PUNET_OK;
 }
@@ -460,10 +462,29 @@ extern "C" int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1
                                   nullptr, nullptr, accumulate, relu, B, H, W, stream);
 }
 
+static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
+                          int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
+                          const void* gate_bits, void* gate_out, int accumulate, int relu, int B, int H, int W, void* stream);
+
 extern "C" int punet_conv3x3_x6_gated(const float* x0, int c0, const float* x1, int c1, const void* wplanes,
                                       long plane_stride, int n_row, int n_off, const float* bias, int bias_img_stride,
                                       float* y, int n_out, const float* mask, const void* gate_bits, void* gate_out,
                                       int accumulate, int relu, int B, int H, int W, void* stream) {
+    return conv_x6_launch(3, x0, c0, x1, c1, wplanes, plane_stride, n_row, n_off, bias, bias_img_stride, y, n_out, mask, gate_bits,
+                          gate_out, accumulate, relu, B, H, W, stream);
+}
+
+extern "C" int punet_conv1x1_x6_gated(const float* x0, int c0, const float* x1, int c1, const void* wplanes,
+                                      long plane_stride, int n_row, int n_off, const float* bias, int bias_img_stride,
+                                      float* y, int n_out, const float* mask, const void* gate_bits, void* gate_out,
+                                      int accumulate, int relu, int B, int H, int W, void* stream) {
+    return conv_x6_launch(1, x0, c0, x1, c1, wplanes, plane_stride, n_row, n_off, bias, bias_img_stride, y, n_out, mask, gate_bits,
+                          gate_out, accumulate, relu, B, H, W, stream);
+}
+
+static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
+                          int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
+                          const void* gate_bits, void* gate_out, int accumulate, int relu, int B, int H, int W, void* stream) {
     PUNET_CHECK_ARG(x0 && wplanes && y, "punet_conv3x3_x6: null pointer");
     PUNET_CHECK_ARG(c0 > 0 && c0 % CK == 0 && c1 >= 0 && c1 % CK == 0 && (c1 == 0 || x1),
                     "punet_conv3x3_x6: source channels must be multiples of %d (c0=%d c1=%d)", CK, c0, c1);
@@ -488,7 +509,9 @@ extern "C" int punet_conv3x3_x6_gated(const float* x0, int c0, const float* x1, 
                     "punet_conv3x3_x6: bias/relu/gate_out (forward) cannot be combined with mask/gate_bits/accumulate (input gradient)");
     hipStream_t st = (hipStream_t)stream;
     a.xcd_remap = grid % 8 == 0;  // same-process A/B: +0.5-0.8 % (the tensors of this workload fit the Infinity Cache)
-    if (g_punet_x6_planes == 3) {
+    if (ksize == 1) {  // the two Fcomb layers: always the parity arithmetic (they are a rounding error of the step time)
+        if (dgrad) conv3x3_x6_kernel<3, true, 1><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<3, false, 1><<<grid, 256, 0, st>>>(a);
+    } else if (g_punet_x6_planes == 3) {
         if (dgrad) conv3x3_x6_kernel<3, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<3, false><<<grid, 256, 0, st>>>(a);
     } else if (g_punet_x6_planes == 2) {
         if (dgrad) conv3x3_x6_kernel<2, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<2, false><<<grid, 256, 0, st>>>(a);

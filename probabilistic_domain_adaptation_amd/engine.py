@@ -235,6 +235,7 @@ class PUNetEngine:
         self.x6 = self.conv_mode in _X6_PRODUCTS  # the split-plane kernel family
         self._x6 = {}  # (flat.data_ptr(), mode) -> bf16 planes buffer [3 * numel]
         self._x6_table = None  # (device int64 [nconv+1, 4], nconv, total_units) for punet_split_weights_x6_batch
+        self._x6_1x1 = {}  # (flat.data_ptr(), mode) -> {conv name: bf16 planes} for the Fcomb 1x1 layers
         tab, self.l2_ntensors = layout.l2_chunk_table()
         self.l2_chunks = tab.to(self.device)
         self.l2_nchunks = tab.shape[0]
@@ -268,7 +269,9 @@ class PUNetEngine:
         return x.permute(0, 2, 3, 1).contiguous()
 
     # ---------------------------------------------------------------- forward ops
-    def conv(self, flat, name: str, x0: Act, x1: Optional[Act] = None, relu=True, tape=None, taps=None) -> Act:
+    def conv(self, flat, name: str, x0: Act, x1: Optional[Act] = None, relu=True, tape=None, taps=None, tape_bits=False) -> Act:
+        """tape_bits: publish the ReLU gate bits of the output even without a tape (Fcomb layers, whose backward is
+        written out by hand in elbo_backward)."""
         c = self.L.convs[name]
         B, H, W = x0.B, x0.H, x0.W
         y = Act(self._empty(B, H, W, c.cout), B, H, W, c.cout, relu_out=relu)
@@ -280,12 +283,19 @@ class PUNetEngine:
                       B, H, W, int(relu), _stream())
         elif self.x6 and c.k == 3:
             planes = self._x6[(flat.data_ptr(), 0)]
-            if relu and tape is not None:  # a backward will follow: publish the ReLU gate of y as bits for it
+            if relu and (tape is not None or tape_bits):  # a backward will follow: publish the ReLU gate of y as bits
                 y.bits = torch.empty(_lib.call("punet_gate_dwords", B, H, W, c.cout), dtype=torch.int32, device=self.device)
             self._timed("conv3x3_fwd", 2.0 * B * H * W * cin * c.cout * 9, "punet_conv3x3_x6_gated", x0.ptr, x0.C,
                         x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0,
                         planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cout, 0, self._bptr(flat, c), 0, y.ptr, c.cout, None,
                         None, y.bits.data_ptr() if y.bits is not None else None, 0, int(relu), B, H, W, _stream())
+        elif self.x6 and c.k == 1 and x1 is None and name in self._x6_1x1.get((flat.data_ptr(), 0), {}):
+            planes = self._x6_1x1[(flat.data_ptr(), 0)][name]
+            if relu and tape_bits:
+                y.bits = torch.empty(_lib.call("punet_gate_dwords", B, H, W, c.cout), dtype=torch.int32, device=self.device)
+            self._timed("conv1x1_fwd", 2.0 * B * H * W * cin * c.cout, "punet_conv1x1_x6_gated", x0.ptr, cin, None, 0,
+                        planes.data_ptr(), cin * c.cout, c.cout, 0, self._bptr(flat, c), 0, y.ptr, c.cout, None, None,
+                        y.bits.data_ptr() if y.bits is not None else None, 0, int(relu), B, H, W, _stream())
         else:
             self._timed(f"conv{c.k}x{c.k}_fwd", 2.0 * B * H * W * cin * c.cout * c.k * c.k, "punet_conv_fwd", x0.ptr, x0.C,
                         x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0, self._wptr(flat, c),
@@ -440,13 +450,21 @@ class PUNetEngine:
         _lib.call("punet_fcomb_zbias", z.data_ptr(), self._wptr(flat, c1), self._bptr(flat, c1), zb.data_ptr(), B, Ld, CH,
                   _stream())
         h = Act(self._empty(B, H, W, CH), B, H, W, CH, relu_out=True)
-        _lib.call("punet_conv_fwd", feat.ptr, CH, None, 0, self._wptr(flat, c1), zb.data_ptr(), CH, h.ptr, CH, B, H, W, 1, 1,
-                  _stream())
+        p1 = self._x6_1x1.get((flat.data_ptr(), 0), {}).get(c1.name) if self.x6 else None
+        if p1 is not None:
+            if record:
+                h.bits = torch.empty(_lib.call("punet_gate_dwords", B, H, W, CH), dtype=torch.int32, device=self.device)
+            self._timed("conv1x1_fwd", 2.0 * B * H * W * CH * CH, "punet_conv1x1_x6_gated", feat.ptr, CH, None, 0, p1.data_ptr(),
+                        CH * CH, CH, 0, zb.data_ptr(), CH, h.ptr, CH, None, None,
+                        h.bits.data_ptr() if h.bits is not None else None, 0, 1, B, H, W, _stream())
+        else:
+            _lib.call("punet_conv_fwd", feat.ptr, CH, None, 0, self._wptr(flat, c1), zb.data_ptr(), CH, h.ptr, CH, B, H, W, 1, 1,
+                      _stream())
         hs = [h]
         if taps is not None:
             taps["conv:fcomb.layers.0"] = h
         for nm in L.fcomb_mid:
-            h = self.conv(flat, nm, h, None, True, None, taps)
+            h = self.conv(flat, nm, h, None, True, None, taps, tape_bits=record)
             hs.append(h)
         P = B * H * W
         logits = self._empty(B, 1, H, W)
@@ -511,19 +529,41 @@ class PUNetEngine:
                   _stream())
         return planes
 
+    def _fcomb_1x1(self):
+        """(conv, rows) of the Fcomb 1x1 layers the split-plane kernel serves: the feature rows of layers.0 (its last
+        latent_dim rows are the z term, folded into a per-image bias) and the middle layers."""
+        L = self.L
+        if L.kind != "punet" or L.nf[0] % 8:
+            return []
+        return [(L.convs["fcomb.layers.0"], L.nf[0])] + [(L.convs[nm], L.nf[0]) for nm in L.fcomb_mid]
+
+    def _split_x6_1x1(self, flat, mode: int):
+        key = (flat.data_ptr(), mode)
+        d = self._x6_1x1.get(key)
+        if d is None:
+            d = {c.name: torch.empty(3 * rows * c.cout, dtype=torch.bfloat16, device=self.device) for c, rows in self._fcomb_1x1()}
+            self._x6_1x1[key] = d
+        for c, rows in self._fcomb_1x1():
+            _lib.call("punet_split_weights_x6", self._wptr(flat, c), d[c.name].data_ptr(), rows * c.cout, rows, c.cout, 1, mode,
+                      _stream())
+        return d
+
     def prepare_forward_weights(self, flat):
         if self.x6:
             self._split_x6(flat, 0)
+            self._split_x6_1x1(flat, 0)
 
     def prepare_dgrad_weights(self, flat):
         """Bring every conv weight slab into forward-kernel orientation for the input-gradient pass
         (wt[k*k-1-t][cout][cin] = w[t][cin][cout]); ~0.1 ms per step, after which dgrad IS the forward kernel."""
         if self.x6:
             self._split_x6(flat, 1)
+            self._split_x6_1x1(flat, 1)
         if self.wT is None or self.wT.numel() != flat.numel():
             self.wT = torch.empty_like(flat)
+        served = {c.name for c, _ in self._fcomb_1x1()} if self.x6 else set()
         for c in self.L.convs.values():
-            if self.x6 and c.k == 3:
+            if (self.x6 and c.k == 3) or c.name in served:
                 continue  # served by the x6 planes
             if c.cin > 4 and c.cin % 4 == 0 and c.cout % 8 == 0:
                 _lib.call("punet_flip_transpose_weights", self._wptr(flat, c), self.wT.data_ptr() + 4 * c.w_off, c.cin, c.cout,
@@ -539,6 +579,12 @@ class PUNetEngine:
             self._timed("conv3x3_dgrad", flops, "punet_conv3x3_x6_gated", dz.data_ptr(), c.cout, None, 0,
                         planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cin, cin_off, None, 0, dx.data_ptr(), cin,
                         None if use_bits else mask_ptr, bits.data_ptr() if use_bits else None, None, acc, 0, B, H, W, _stream())
+        elif self.x6 and c.k == 1 and c.name in self._x6_1x1.get((flat.data_ptr(), 1), {}) and cin_off == 0:
+            planes = self._x6_1x1[(flat.data_ptr(), 1)][c.name]  # built for the first `cin` rows of the slab
+            use_bits = bits is not None and mask_ptr is not None
+            self._timed("conv1x1_dgrad", flops, "punet_conv1x1_x6_gated", dz.data_ptr(), c.cout, None, 0, planes.data_ptr(),
+                        cin * c.cout, cin, 0, None, 0, dx.data_ptr(), cin, None if use_bits else mask_ptr,
+                        bits.data_ptr() if use_bits else None, None, acc, 0, B, H, W, _stream())
         elif c.cin % 4 == 0:
             self._timed(f"conv{c.k}x{c.k}_dgrad", flops, "punet_conv_dgrad_t", dz.data_ptr(), c.cout,
                         self.wT.data_ptr() + 4 * c.w_off, c.cin, cin_off, cin, dx.data_ptr(), mask_ptr, acc, B, H, W, c.k,
@@ -614,7 +660,7 @@ class PUNetEngine:
             xin = hs[k]
             self._wgrad(gflat, c, xin, 0, dz_h, True, accumulate)
             dprev = torch.empty_like(xin.t)
-            self._dgrad(flat, c, dz_h, 0, xin.C, dprev, xin.ptr, 0, B, H, W)
+            self._dgrad(flat, c, dz_h, 0, xin.C, dprev, xin.ptr, 0, B, H, W, bits=xin.bits)
             dz_h = dprev
         # first layer: feature rows by wgrad (+ bias), z rows and dz from the per-image column sums
         self._wgrad(gflat, c1, feat, 0, dz_h, True, accumulate)
@@ -626,7 +672,7 @@ class PUNetEngine:
                   dz.data_ptr(), B, Ld, CH, acc, _stream())
         gm_u = {}
         dfeat, _ = self._grad_into(gm_u, feat)
-        self._dgrad(flat, c1, dz_h, 0, CH, dfeat, feat.ptr, 0, B, H, W)
+        self._dgrad(flat, c1, dz_h, 0, CH, dfeat, feat.ptr, 0, B, H, W, bits=feat.bits)
         del dz_h
         tq, tp, tu = st["tapes"]
         self._backward_tape(flat, gflat, tu, gm_u, accumulate)

@@ -181,3 +181,38 @@ def test_pool_and_upsample_backward_take_the_gate_bits(L, B, H, W, cin, cout):
     L.call("punet_upsample2x_bwd_gated", dyu.data_ptr(), None, bits.data_ptr(), b_.data_ptr(), B, H, W, cout, S())
     torch.cuda.synchronize()
     assert torch.equal(a_, b_) and (a_ == 0).float().mean().item() > 0.2
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,rows", [(2, 16, 64, 64, 64, 70), (1, 24, 40, 32, 96, 32), (1, 8, 8, 72, 64, 72)])
+def test_conv1x1_x6_fwd_and_dgrad(L, B, H, W, cin, cout, rows):
+    """The Fcomb 1x1 layers through the split-plane kernel: forward with a per-image bias (the folded z term) and the
+    input gradient w.r.t. a channel window of a wider weight (Fcomb's first layer has C + latent_dim input rows)."""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, cin, H, W, generator=g).requires_grad_(True)
+    wfull = (torch.randn(cout, rows, 1, 1, generator=g) / np.sqrt(rows))
+    w = wfull[:, :cin].clone().requires_grad_(True)
+    bimg = torch.randn(B, cout, generator=g)
+    y = F.conv2d(x, w) + bimg[:, :, None, None]
+    dz = torch.randn(B, cout, H, W, generator=g)
+    F.relu(y).backward(dz)
+    Wp = wfull.permute(2, 3, 1, 0).contiguous().cuda()  # [1][1][rows][cout]
+    nw = cin * cout
+    pf = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+    pd = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+    L.call("punet_split_weights_x6", Wp.data_ptr(), pf.data_ptr(), nw, cin, cout, 1, 0, S())
+    L.call("punet_split_weights_x6", Wp.data_ptr(), pd.data_ptr(), nw, cin, cout, 1, 1, S())
+    X = nhwc(x.detach())
+    Y = torch.full((B, H, W, cout), float("nan"), device="cuda")
+    bits = torch.zeros(L.call("punet_gate_dwords", B, H, W, cout), dtype=torch.int32, device="cuda")
+    Bd = bimg.cuda()
+    L.call("punet_conv1x1_x6_gated", X.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, Bd.data_ptr(), cout, Y.data_ptr(), cout,
+           None, None, bits.data_ptr(), 0, 1, B, H, W, S())
+    torch.cuda.synchronize()
+    assert rel_err(nchw(Y), F.relu(y.detach())) < 2e-6
+    # input gradient of relu(y) w.r.t. x: dz gated by (y > 0) first, then contracted with W^T; gate of x itself: none
+    DZ = nhwc(dz * (y.detach() > 0))
+    DX = torch.full((B, H, W, cin), float("nan"), device="cuda")
+    L.call("punet_conv1x1_x6_gated", DZ.data_ptr(), cout, None, 0, pd.data_ptr(), nw, cin, 0, None, 0, DX.data_ptr(), cin,
+           None, None, None, 0, 0, B, H, W, S())
+    torch.cuda.synchronize()
+    assert rel_err(nchw(DX), x.grad) < 3e-6
