@@ -103,8 +103,8 @@ def cpu_baseline(workload, n_samples, H, W, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="mean_teacher", choices=["mean_teacher", "punet_source", "inference", "fixmatch", "adamt", "adamatch"])
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4)
@@ -114,6 +114,9 @@ def main():
                     help="3x3 conv arithmetic (default: $PUNET_CONV_MODE or x6); x3/bf16 are reduced-precision fast modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--kernel-timing", default="roofline", choices=["roofline", "all"],
+                    help="HIP-event brackets inside the timed region: only the roofline kernel's launches (default; 73 per "
+                         "step) or every MFMA launch (adds ~1 ms of bubbles per step)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI; the default) or gloo (rehearsal on one GPU)")
     a = ap.parse_args()
 
@@ -184,9 +187,14 @@ def main():
     prof = None if a.no_kernel_timing else []
     for e in engines:
         e.prof = prof
+        e.prof_kinds = {"conv3x3_fwd"} if a.kernel_timing == "roofline" else None
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]  # per-step GPU timeline (diagnostic)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         step()
+        marks[i + 1].record()
+    t_enq = time.perf_counter() - t0  # host time to enqueue the K steps (the GPU runs behind; must stay below dt)
     sync()
     dt = time.perf_counter() - t0
     for e in engines:
@@ -213,7 +221,9 @@ def main():
                                    f"{H}x{W}x{a.channels} patches, batch {B}/GPU, N={N} MC samples, Adam lr 1e-5, EMA 0.999",
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "algorithmic_gflop_per_patch": gf,
-                       "model_tflops_per_gpu": round(gf * patches / dt / world / 1e3, 2)},
+                       "model_tflops_per_gpu": round(gf * patches / dt / world / 1e3, 2),
+                       "host_enqueue_ms_per_step": round(1e3 * t_enq / a.steps, 2),
+                       "ms_each_step": [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(a.steps)]},
         }
         out["config"]["conv_arithmetic"] = {
             "x6": "3x3 convs fwd+dgrad+wgrad: fp32 operands split into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 "

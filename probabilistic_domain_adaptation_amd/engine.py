@@ -224,6 +224,7 @@ class PUNetEngine:
         _lib.load()
         self.ws = Workspace(self.device)
         self.prof = None  # when a list: (kind, algorithmic FLOPs, start event, end event) per 3x3 MFMA launch
+        self.prof_kinds = None  # optional set of kinds to bracket (every event pair costs ~1 us of GPU idle time)
         self.wT = None  # flipped + transposed weight slabs for the dgrad pass (prepare_dgrad_weights)
         # 3x3 conv arithmetic.  Parity modes (same tolerances): "x6" = three-plane bf16 split on the BF16 matrix cores
         # (fp32-accurate, default), "f32" = fp32-input MFMA.  Opt-in fast modes (the analogue of the reference scripts'
@@ -244,7 +245,7 @@ class PUNetEngine:
         """Launch through the C ABI; with self.prof set, bracket the launch with HIP events on the launch stream."""
         if self.x6:
             set_x6_products(_X6_PRODUCTS[self.conv_mode])
-        if self.prof is None:
+        if self.prof is None or (self.prof_kinds is not None and kind not in self.prof_kinds):
             return _lib.call(name, *args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -3,7 +3,7 @@
 set -e
 out=${1:-gpurun_out/configs.log}
 : > $out
-run() { echo "== $*" >> $out; timeout -k 10 400 python bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 >> $out; }
+run() { echo "== $*" >> $out; timeout -k 10 400 python bench.py --no-cpu-baseline --kernel-timing all "$@" 2>/dev/null | tail -1 >> $out; }
 run --steps 5 --warmup 2
 run --workload punet_source --steps 5 --warmup 2
 run --workload fixmatch --steps 5 --warmup 2
