@@ -1,0 +1,128 @@
+"""GPU: the BASELINE.json sizes (512x512 patches, nf = [64, 128, 256, 512], N = 8).  Direct parity with the CPU oracle
+where it finishes in seconds (one patch, inference path), size-independent properties where it does not (the full
+batch-4 training step): exact power-of-two linearity of the convolution kernels, bit-reproducibility of the whole
+Mean-Teacher step, gate-bit / fp32-gate equivalence at full size."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import punet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+NF = [64, 128, 256, 512]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _model(dev, seed=1, **kw):
+    """The oracle's synthetic weights (scaled so that the MC samples are confident on part of the image - with a plain
+    Kaiming init every sigmoid sits near 0.5 and the consensus mask is empty, which would make the mask checks vacuous)."""
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    m = ProbabilisticUnet(1, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=0, **kw)
+    cfg = O.PUNetConfig(1, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in O.synth_params(cfg.spec(), seed).items()})
+    return m
+
+
+def test_inference_512_against_oracle(dev):
+    """One 512x512 patch through U-Net + prior + 8 MC samples: logits within the 1e-3 bar, consensus masks identical
+    wherever no sigmoid sits within 1e-5 of a threshold."""
+    m = _model(dev)
+    cfg = O.PUNetConfig(1, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    P = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    x, x1, x2, y = O.synth_batch(1, 1, 512, 512, 0)
+    n = 8
+    eps = torch.randn(n, 1, 6, generator=torch.Generator().manual_seed(2))
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        st = O.punet_forward(P, cfg, x1, None, False)
+        logits = torch.stack([O.punet_sample(P, cfg, st, eps[i]) for i in range(n)])
+    eng = m.engine
+    with torch.no_grad():
+        out = eng.forward_features(m.flat_params, eng.to_nhwc(x1))
+        z = eng.reparam(out["prior_muls"], eps.to(dev))
+        ym, cz, lg = eng.sample(m.flat_params, out["features"], z, 0.9, 0.1, True, want_logits=True)
+    torch.cuda.synchronize()
+    err = (lg.cpu() - logits).abs().max().item()
+    print(f"\n512x512 logits max abs err vs oracle: {err:.3e}")
+    assert err < 1e-3
+    probs = torch.sigmoid(logits)
+    ref = (((probs >= 0.9) | (probs <= 0.1)).float().sum(0) == n).float()
+    safe = ((probs - 0.9).abs().min(0).values > 1e-5) & ((probs - 0.1).abs().min(0).values > 1e-5)
+    assert safe.float().mean().item() > 0.999
+    assert torch.equal(cz.cpu()[safe], ref[safe])
+    assert 0.01 < ref.mean().item() < 0.99  # a non-trivial mask
+    assert (ym.cpu() - probs.mean(0)).abs().max().item() < 1e-4
+
+
+def test_mean_teacher_step_batch4_512_is_bit_reproducible(dev):
+    """The whole fused step (teacher MC pass, consensus, ELBO forward/backward, L2, Adam, EMA) at the bench shape, twice
+    from the same state: identical bits (no atomics, fixed reduction orders, fixed split-K order)."""
+    import copy
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    x, x1, x2, y = [t.to(dev) for t in O.synth_batch(4, 1, 512, 512, 0)]
+    g = torch.Generator().manual_seed(3)
+    eps_t, eps_s = torch.randn(8, 4, 6, generator=g).to(dev), torch.randn(4, 6, generator=g).to(dev)
+    outs = []
+    for _ in range(2):
+        m = _model(dev)
+        t = copy.deepcopy(m)
+        opt = FusedAdam(m, lr=1e-4)
+        loss, ys, zs, _ = FU.fused_self_training_step(m, t, opt, x1, x2, 8, True, eps_pl=eps_t, eps_s=eps_s)
+        torch.cuda.synchronize()
+        outs.append((float(loss), m.flat_params.clone(), t.flat_params.clone(), zs.clone()))
+        del m, t, opt
+    assert np.isfinite(outs[0][0]) and outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+    frac = outs[0][3].mean().item()
+    assert 0.0 < frac < 1.0  # a non-trivial consensus mask
+
+
+def test_conv_kernels_are_exactly_linear_in_powers_of_two(dev):
+    """Scaling an operand by 2^k scales every bf16 plane exactly, hence the output exactly: conv(4 x) == 4 conv(x) and
+    wgrad(x, 0.5 dz) == 0.5 wgrad(x, dz) bit for bit at a full-size layer (64 -> 64 @ 512^2, batch 4)."""
+    from probabilistic_domain_adaptation_amd import _lib as L, engine
+    engine.set_x6_products(6)
+    S = torch.cuda.current_stream().cuda_stream
+    B, H, W, C = 4, 512, 512, 64
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, H, W, C, generator=g).to(dev)
+    w = (torch.randn(3, 3, C, C, generator=g) / 24.0).to(dev)
+    nw = 9 * C * C
+    pf = torch.empty(3 * nw, dtype=torch.bfloat16, device=dev)
+    L.call("punet_split_weights_x6", w.data_ptr(), pf.data_ptr(), nw, C, C, 3, 0, S)
+    y1, y4 = torch.empty(B, H, W, C, device=dev), torch.empty(B, H, W, C, device=dev)
+    x4 = x * 4.0
+    for src, dst in ((x, y1), (x4, y4)):
+        L.call("punet_conv3x3_x6", src.data_ptr(), C, None, 0, pf.data_ptr(), nw, C, 0, None, 0, dst.data_ptr(), C, None, 0, 0, B, H,
+               W, S)
+    torch.cuda.synchronize()
+    assert torch.equal(y4, y1 * 4.0)
+    dz = torch.randn(B, H, W, C, generator=g).to(dev)
+    ns = L.call("punet_wgrad_x6_slices", C, C, B, H, W)
+    ws = torch.empty(L.call("punet_wgrad_workspace_floats", C, C, 3, ns), device=dev)
+    dw1, dw2 = torch.empty(3, 3, C, C, device=dev), torch.empty(3, 3, C, C, device=dev)
+    db1, db2 = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    dzh = dz * 0.5
+    L.call("punet_conv_wgrad_x6", x.data_ptr(), C, dz.data_ptr(), C, dw1.data_ptr(), C, 0, db1.data_ptr(), ws.data_ptr(), ns, B, H, W,
+           0, 1.0, S)
+    L.call("punet_conv_wgrad_x6", x.data_ptr(), C, dzh.data_ptr(), C, dw2.data_ptr(), C, 0, db2.data_ptr(), ws.data_ptr(), ns, B, H,
+           W, 0, 1.0, S)
+    torch.cuda.synchronize()
+    assert torch.equal(dw2, dw1 * 0.5) and torch.equal(db2, db1 * 0.5)
+    # and against an fp64 evaluation of a few output entries (a checksum of the full-size contraction)
+    xs, ds = x.double(), dz.double()
+    for (ky, kx, ci, co) in [(0, 0, 0, 0), (1, 1, 17, 40), (2, 0, 63, 63)]:
+        xsh = torch.zeros(B, H, W, dtype=torch.float64, device=dev)
+        y0, y1_ = max(0, 1 - ky), min(H, H + 1 - ky)
+        x0, x1_ = max(0, 1 - kx), min(W, W + 1 - kx)
+        xsh[:, y0:y1_, x0:x1_] = xs[:, y0 + ky - 1:y1_ + ky - 1, x0 + kx - 1:x1_ + kx - 1, ci]
+        ref = (xsh * ds[..., co]).sum().item()
+        assert abs(dw1[ky, kx, ci, co].item() - ref) < 2e-5 * (xsh.abs() * ds[..., co].abs()).sum().item() ** 0.5 + 1e-3 * abs(ref)
