@@ -132,48 +132,53 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     float4 rx[XITER];
     uint4 rw[WITER];
 
-    auto prefetch = [&](const TileInfo& ti, int ch) __attribute__((always_inline)) {
+    // one staging unit of the operand images of chunk `ch` of tile `ti` (global -> register).  All offsets are 32-bit
+    // (uniform 64-bit base + per-lane 32-bit element offset; sizes are checked on the host): 64-bit multiply-add chains
+    // per address had made the staging phase - one wave per SIMD, no instruction-level parallelism to speak of - longer
+    // than the K-steps it feeds.
+    // BRANCH-FREE on purpose: out-of-range units load from a clamped (valid) address and are zeroed / deduplicated by
+    // selects.  With the loads inside divergent branches the compiler's waitcnt insertion loses track of the vmcnt order
+    // across the joins and falls back to s_waitcnt vmcnt(0) - i.e. it waited for the loads it had just issued for the
+    // NEXT chunk, three exposed memory latencies per commit.
+    auto load_x = [&](const TileInfo& ti, int ch, int it) __attribute__((always_inline)) -> float4 {
         const int kbase = ch * CK;
-        const float* src;
-        int cs, coff;
-        if (kbase < a.c0) {
-            src = a.x0; cs = a.c0; coff = kbase;
-        } else {
-            src = a.x1; cs = a.c1; coff = kbase - a.c0;
-        }
+        const float* src = kbase < a.c0 ? a.x0 : a.x1;
+        const int cs = kbase < a.c0 ? a.c0 : a.c1, coff = kbase < a.c0 ? kbase : kbase - a.c0;
+        const int u = min(tid + it * 256, XUNITS - 1);  // a clamped duplicate re-stages the last unit (same data, same slot)
+        const int q = u % (CK / 4), pix = u / (CK / 4);
+        const int py = pix / HTW, px = pix % HTW;
+        const int gy = ti.ty0 + py - PAD, gx = ti.tx0 + px - PAD;
+        const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+        float4 v = *reinterpret_cast<const float4*>(src + (unsigned)(((ti.b * a.H + cy) * a.W + cx) * cs + coff + q * 4));
+        if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        return v;
+    };
+    auto load_w = [&](const TileInfo& ti, int ch, int it) __attribute__((always_inline)) -> uint4 {
+        const int u = min(tid + it * 256, WUNITS - 1);
+        const int n = u % TN, t = (u / TN) % KK, p = u / (TN * KK);
+        const int nc = min(ti.n0 + n, N - 1);  // columns beyond N copy column N - 1: their outputs are never stored
+        return *reinterpret_cast<const uint4*>(a.wp + (unsigned)(p * (int)a.plane_stride +
+                                                                 ((t * nchunks + ch) * a.n_row + a.n_off + nc) * 8));
+    };
+    auto prefetch = [&](const TileInfo& ti, int ch) __attribute__((always_inline)) {
 #pragma unroll
-        for (int it = 0; it < XITER; ++it) {
-            const int u = tid + it * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < XUNITS) {
-                const int q = u % (CK / 4), pix = u / (CK / 4);
-                const int py = pix / HTW, px = pix % HTW;
-                const int gy = ti.ty0 + py - PAD, gx = ti.tx0 + px - PAD;
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                    v = *reinterpret_cast<const float4*>(src + ((size_t)(ti.b * a.H + gy) * a.W + gx) * cs + coff + q * 4);
-            }
-            rx[it] = v;
-        }
+        for (int it = 0; it < XITER; ++it) rx[it] = load_x(ti, ch, it);
 #pragma unroll
-        for (int it = 0; it < WITER; ++it) {
-            const int u = tid + it * 256;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (u < WUNITS) {
-                const int n = u % TN, t = (u / TN) % KK, p = u / (TN * KK);
-                if (ti.n0 + n < N)
-                    v = *reinterpret_cast<const uint4*>(a.wp + (size_t)p * a.plane_stride +
-                                                        (((size_t)t * nchunks + ch) * a.n_row + a.n_off + ti.n0 + n) * 8);
-            }
-            rw[it] = v;
-        }
+        for (int it = 0; it < WITER; ++it) rw[it] = load_w(ti, ch, it);
     };
 
-    auto commit = [&](int par) __attribute__((always_inline)) {
+    // Registers -> LDS images of the current chunk, and - interleaved, each staging register is re-loaded as soon as it has
+    // been consumed - the global loads of the NEXT chunk (a per-phase timeline of one wave showed 3.9k cycles in a commit
+    // that waits for loads issued only ~4k cycles earlier, then 1.6k cycles in a separate load-issue phase, against 4.0k
+    // cycles of K-steps: issuing the loads here, under the split arithmetic, buys them ~2k cycles of extra flight time and
+    // removes the separate phase)
+    auto commit = [&](int par, const TileInfo& nti, int nch) __attribute__((always_inline)) {
         uint4* sXc = sX + par * XBUF;
 #pragma unroll
         for (int it = 0; it < XITER; ++it) {
-            const int u = tid + it * 256;
-            if (u < XUNITS) {
+            const int u = min(tid + it * 256, XUNITS - 1);
+            {
                 const int q = u % (CK / 4), pix = u / (CK / 4);
                 const float xv[4] = {rx[it].x, rx[it].y, rx[it].z, rx[it].w};
                 bf16x4 ph, pm, pl;
@@ -187,15 +192,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                 if (NP > 1) *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[(NP > 1) * NPIX + pix]) + q * 8) = pm;
                 if (NP > 2) *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[(NP > 2) * 2 * NPIX + pix]) + q * 8) = pl;
             }
+            rx[it] = load_x(nti, nch, it);  // the register is free again: reload it for the next chunk
         }
 #pragma unroll
         for (int it = 0; it < WITER; ++it) {
-            const int u = tid + it * 256;
-            if (u < WUNITS) {
+            const int u = min(tid + it * 256, WUNITS - 1);
+            {
                 const int n = u % TN, t = (u / TN) % KK, p = u / (TN * KK);
                 const int slot = t < KK - 1 ? t : KK - par;  // tap 8: slot 8 (odd chunk) or 9 (even chunk)
                 sW[p * WSLAB + slot * TN + n] = rw[it];
             }
+            rw[it] = load_w(nti, nch, it);
         }
     };
 
@@ -210,12 +217,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     // comparisons into one register per row; the input gradient loads its dword once per row.
     auto epilogue = [&](const TileInfo& ti) __attribute__((always_inline)) {
         const int gx = ti.tx0 + l31;
+        // all eight bias quads first (one latency; per-quad loads inside the store loop had been a chain of 16 dependent L2
+        // round trips per tile - 16k cycles, 17 % of a 64-channel layer's tile)
+        float4 bq4[2][4];
+        if (!DGRAD) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int c = ti.n0 + nb * 32 + rg * 8 + 4 * half;
+                    bq4[nb][rg] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.bias && c < N) bq4[nb][rg] = *reinterpret_cast<const float4*>(a.bias + (size_t)ti.b * a.bias_img_stride + c);
+                }
+        }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int gy = ti.ty0 + 2 * wave + m;
             const bool pix_in = gy < a.H && gx < a.W;
-            const size_t gd = ((((size_t)(ti.b * a.H + gy) * tiles_x + (ti.tx0 / TW)) * ntn + (ti.n0 / TN)) << 6) + lane;
-            const size_t pbase = ((size_t)(ti.b * a.H + gy) * a.W + gx) * N + ti.n0 + 4 * half;
+            const unsigned gd = (unsigned)(((((ti.b * a.H + gy) * tiles_x + (ti.tx0 / TW)) * ntn + (ti.n0 / TN)) << 6) + lane);
+            const unsigned pbase = (unsigned)(((ti.b * a.H + gy) * a.W + gx) * N + ti.n0 + 4 * half);
             unsigned gin = 0u, gout = 0u;
             if (DGRAD && a.gate_bits && pix_in) gin = a.gate_bits[gd];
 #pragma unroll
@@ -226,10 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                     const bool ok = pix_in && ti.n0 + ch + 4 * half < N;  // N is a multiple of 4
                     float4 v = make_float4(acc[m][nb][4 * rg + 0], acc[m][nb][4 * rg + 1], acc[m][nb][4 * rg + 2], acc[m][nb][4 * rg + 3]);
                     if (!DGRAD) {
-                        if (a.bias && ok) {
-                            const float4 bv4 = *reinterpret_cast<const float4*>(a.bias + (size_t)ti.b * a.bias_img_stride + ti.n0 + ch + 4 * half);
-                            v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
-                        }
+                        v.x += bq4[nb][rg].x; v.y += bq4[nb][rg].y; v.z += bq4[nb][rg].z; v.w += bq4[nb][rg].w;
                         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     } else if (a.gate_bits) {
                         const unsigned g4 = gin >> (16 * nb + 4 * rg);
@@ -305,9 +322,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     // below is an instruction immediate.  Returns true when this workgroup has no further work.
     auto phase = [&](auto par_c) __attribute__((always_inline)) -> bool {
         constexpr int par = decltype(par_c)::value;
-        __syncthreads();
-        commit(par);
-        __syncthreads();
         int nch = ch + 1, ntile = tile;
         TileInfo nti = ti;
         if (nch == nchunks) {
@@ -316,7 +330,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
             if (ntile < a.ntiles) nti = decode(ntile);
         }
         const bool has_next = ntile < a.ntiles;
-        if (has_next) prefetch(nti, nch);
+        if (!has_next) nch = ch;  // nothing follows: the (unconditional, branch-free) reloads re-fetch this chunk and are dropped
+        __syncthreads();
+        // the staging phase is a few hundred dependent VALU / LDS / VMEM instructions of ONE wave per SIMD; the other
+        // resident wave (the other workgroup) is usually inside its K-steps and only needs one issue slot per 32 cycles:
+        // give this wave priority so that it is not queued behind MFMAs it does not depend on
+        __builtin_amdgcn_s_setprio(3);
+        commit(par, nti, nch);
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
 
         // taps 0-7 of this chunk, two per K-step: lanes 0-31 tap 2j, lanes 32-63 tap 2j+1
 #pragma unroll
@@ -491,6 +513,12 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
     PUNET_CHECK_ARG(n_out > 0 && n_out % 4 == 0 && n_off >= 0 && n_off + n_out <= n_row,
                     "punet_conv3x3_x6: bad output-channel window (n_out must be a multiple of 4)");
     PUNET_CHECK_ARG(B > 0 && H > 0 && W > 0, "punet_conv3x3_x6: bad shape");
+    {   // the kernel does its index arithmetic in 32 bits
+        const unsigned long long px = (unsigned long long)B * H * W;
+        const int cmax = c0 > c1 ? (c0 > n_out ? c0 : n_out) : (c1 > n_out ? c1 : n_out);
+        PUNET_CHECK_ARG(px * cmax < (1ull << 31) && 3ull * (unsigned long long)plane_stride < (1ull << 31),
+                        "punet_conv3x3_x6: tensor too large for 32-bit indexing (%llu pixels x %d channels)", px, cmax);
+    }
     ConvX6Args a{};
     a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1;
     a.wp = (const __bf16*)wplanes; a.plane_stride = plane_stride; a.n_row = n_row; a.n_off = n_off;
