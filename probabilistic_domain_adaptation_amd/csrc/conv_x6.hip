@@ -132,40 +132,54 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     float4 rx[XITER];
     uint4 rw[WITER];
 
-    // one staging unit of the operand images of chunk `ch` of tile `ti` (global -> register).  All offsets are 32-bit
-    // (uniform 64-bit base + per-lane 32-bit element offset; sizes are checked on the host): 64-bit multiply-add chains
-    // per address had made the staging phase - one wave per SIMD, no instruction-level parallelism to speak of - longer
-    // than the K-steps it feeds.
+    // Staging addresses.  Everything that depends only on the thread and on the TILE is computed once per tile
+    // (`retarget`): the clamped pixel index / in-image flag of each activation unit and the element offset of each weight
+    // unit; per chunk a load then costs one multiply-add (activations) or one add (weights).  The staging phase is a few
+    // hundred dependent instructions of ONE wave per SIMD and makes little progress while the other resident wave issues
+    // MFMAs (measured: 1.6k cycles alone, 4.1k next to a wave in its K-steps), so every instruction removed from it counts.
+    // All offsets are 32-bit (uniform 64-bit base + per-lane element offset; sizes are checked on the host).
     // BRANCH-FREE on purpose: out-of-range units load from a clamped (valid) address and are zeroed / deduplicated by
     // selects.  With the loads inside divergent branches the compiler's waitcnt insertion loses track of the vmcnt order
     // across the joins and falls back to s_waitcnt vmcnt(0) - i.e. it waited for the loads it had just issued for the
     // NEXT chunk, three exposed memory latencies per commit.
-    auto load_x = [&](const TileInfo& ti, int ch, int it) __attribute__((always_inline)) -> float4 {
+    int xpix[XITER];       // (b * H + clamped y) * W + clamped x of the unit's pixel
+    bool xin[XITER];       // pixel inside the image
+    unsigned wbase[WITER];  // plane, tap and output-channel part of the weight offset (chunk part added per chunk)
+    auto retarget = [&](const TileInfo& ti) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < XITER; ++it) {
+            const int u = min(tid + it * 256, XUNITS - 1);  // a clamped duplicate re-stages the last unit (same data, same slot)
+            const int pix = u / (CK / 4);
+            const int py = pix / HTW, px = pix % HTW;
+            const int gy = ti.ty0 + py - PAD, gx = ti.tx0 + px - PAD;
+            xin[it] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            xpix[it] = (ti.b * a.H + min(max(gy, 0), a.H - 1)) * a.W + min(max(gx, 0), a.W - 1);
+        }
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) {
+            const int u = min(tid + it * 256, WUNITS - 1);
+            const int n = u % TN, t = (u / TN) % KK, p = u / (TN * KK);
+            const int nc = min(ti.n0 + n, N - 1);  // columns beyond N copy column N - 1: their outputs are never stored
+            wbase[it] = (unsigned)(p * (int)a.plane_stride + (t * nchunks * a.n_row + a.n_off + nc) * 8);
+        }
+    };
+    auto load_x = [&](int ch, int it) __attribute__((always_inline)) -> float4 {
         const int kbase = ch * CK;
         const float* src = kbase < a.c0 ? a.x0 : a.x1;
         const int cs = kbase < a.c0 ? a.c0 : a.c1, coff = kbase < a.c0 ? kbase : kbase - a.c0;
-        const int u = min(tid + it * 256, XUNITS - 1);  // a clamped duplicate re-stages the last unit (same data, same slot)
-        const int q = u % (CK / 4), pix = u / (CK / 4);
-        const int py = pix / HTW, px = pix % HTW;
-        const int gy = ti.ty0 + py - PAD, gx = ti.tx0 + px - PAD;
-        const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
-        float4 v = *reinterpret_cast<const float4*>(src + (unsigned)(((ti.b * a.H + cy) * a.W + cx) * cs + coff + q * 4));
-        if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int q = min(tid + it * 256, XUNITS - 1) % (CK / 4);  // the same clamped unit index as in retarget / commit
+        float4 v = *reinterpret_cast<const float4*>(src + (unsigned)(xpix[it] * cs + coff + q * 4));
+        if (!xin[it]) v = make_float4(0.f, 0.f, 0.f, 0.f);
         return v;
     };
-    auto load_w = [&](const TileInfo& ti, int ch, int it) __attribute__((always_inline)) -> uint4 {
-        const int u = min(tid + it * 256, WUNITS - 1);
-        const int n = u % TN, t = (u / TN) % KK, p = u / (TN * KK);
-        const int nc = min(ti.n0 + n, N - 1);  // columns beyond N copy column N - 1: their outputs are never stored
-        return *reinterpret_cast<const uint4*>(a.wp + (unsigned)(p * (int)a.plane_stride +
-                                                                 ((t * nchunks + ch) * a.n_row + a.n_off + nc) * 8));
+    auto load_w = [&](int ch, int it) __attribute__((always_inline)) -> uint4 {
+        return *reinterpret_cast<const uint4*>(a.wp + (wbase[it] + (unsigned)(ch * a.n_row * 8)));
     };
-    auto prefetch = [&](const TileInfo& ti, int ch) __attribute__((always_inline)) {
+    auto prefetch = [&](int ch) __attribute__((always_inline)) {
 #pragma unroll
-        for (int it = 0; it < XITER; ++it) rx[it] = load_x(ti, ch, it);
+        for (int it = 0; it < XITER; ++it) rx[it] = load_x(ch, it);
 #pragma unroll
-        for (int it = 0; it < WITER; ++it) rw[it] = load_w(ti, ch, it);
+        for (int it = 0; it < WITER; ++it) rw[it] = load_w(ch, it);
     };
 
     // Registers -> LDS images of the current chunk, and - interleaved, each staging register is re-loaded as soon as it has
@@ -173,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     // that waits for loads issued only ~4k cycles earlier, then 1.6k cycles in a separate load-issue phase, against 4.0k
     // cycles of K-steps: issuing the loads here, under the split arithmetic, buys them ~2k cycles of extra flight time and
     // removes the separate phase)
-    auto commit = [&](int par, const TileInfo& nti, int nch) __attribute__((always_inline)) {
+    auto commit = [&](int par, int nch) __attribute__((always_inline)) {
         uint4* sXc = sX + par * XBUF;
 #pragma unroll
         for (int it = 0; it < XITER; ++it) {
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                 if (NP > 1) *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[(NP > 1) * NPIX + pix]) + q * 8) = pm;
                 if (NP > 2) *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[(NP > 2) * 2 * NPIX + pix]) + q * 8) = pl;
             }
-            rx[it] = load_x(nti, nch, it);  // the register is free again: reload it for the next chunk
+            rx[it] = load_x(nch, it);  // the register is free again: reload it for the next chunk
         }
 #pragma unroll
         for (int it = 0; it < WITER; ++it) {
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                 const int slot = t < KK - 1 ? t : KK - par;  // tap 8: slot 8 (odd chunk) or 9 (even chunk)
                 sW[p * WSLAB + slot * TN + n] = rw[it];
             }
-            rw[it] = load_w(nti, nch, it);
+            rw[it] = load_w(nch, it);
         }
     };
 
@@ -282,7 +296,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     if (tile >= a.ntiles) return;
     int ch = 0;
     TileInfo ti = decode(tile);
-    prefetch(ti, 0);
+    retarget(ti);
+    prefetch(0);
     // one K-step: 24 MFMAs on the fragments at sX[offA + ...] (offset incl. the image base) and weight slot slotB; both
     // arguments are per-half-wave values (lanes 0-31 and 32-63 contract different {tap, chunk} blocks of 8 channels)
     auto kstep = [&](int offA, int slotB, bool zero_a) __attribute__((always_inline)) {
@@ -331,12 +346,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
         }
         const bool has_next = ntile < a.ntiles;
         if (!has_next) nch = ch;  // nothing follows: the (unconditional, branch-free) reloads re-fetch this chunk and are dropped
+        if (has_next && nch == 0) retarget(nti);  // the reloads of this phase already belong to the next tile
         __syncthreads();
         // the staging phase is a few hundred dependent VALU / LDS / VMEM instructions of ONE wave per SIMD; the other
         // resident wave (the other workgroup) is usually inside its K-steps and only needs one issue slot per 32 cycles:
         // give this wave priority so that it is not queued behind MFMAs it does not depend on
         __builtin_amdgcn_s_setprio(3);
-        commit(par, nti, nch);
+        commit(par, nch);
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
 
