@@ -187,26 +187,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     // that waits for loads issued only ~4k cycles earlier, then 1.6k cycles in a separate load-issue phase, against 4.0k
     // cycles of K-steps: issuing the loads here, under the split arithmetic, buys them ~2k cycles of extra flight time and
     // removes the separate phase)
+    // fp32 -> bf16 planes of one staged activation unit, kept PACKED in registers until the commit writes them to LDS.
+    // It is called from inside the K-step sequence (same instruction stream as the MFMAs): a wave's own VALU work issues in
+    // the shadow of its own MFMAs, whereas VALU work of the OTHER resident wave is held up behind them.
+    bf16x4 px[XITER][NP];
+    auto split_unit = [&](int it) __attribute__((always_inline)) {
+        const float xv[4] = {rx[it].x, rx[it].y, rx[it].z, rx[it].w};
+        bf16x4 ph, pm, pl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __bf16 h_, m_, l_;
+            split3(xv[e], h_, m_, l_);
+            ph[e] = h_; pm[e] = m_; pl[e] = l_;
+        }
+        px[it][0] = ph;
+        if (NP > 1) px[it][NP > 1 ? 1 : 0] = pm;
+        if (NP > 2) px[it][NP > 2 ? 2 : 0] = pl;
+    };
     auto commit = [&](int par, int nch) __attribute__((always_inline)) {
         uint4* sXc = sX + par * XBUF;
 #pragma unroll
         for (int it = 0; it < XITER; ++it) {
             const int u = min(tid + it * 256, XUNITS - 1);
-            {
-                const int q = u % (CK / 4), pix = u / (CK / 4);
-                const float xv[4] = {rx[it].x, rx[it].y, rx[it].z, rx[it].w};
-                bf16x4 ph, pm, pl;
+            const int q = u % (CK / 4), pix = u / (CK / 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    __bf16 h_, m_, l_;
-                    split3(xv[e], h_, m_, l_);
-                    ph[e] = h_; pm[e] = m_; pl[e] = l_;
-                }
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[0 * NPIX + pix]) + q * 8) = ph;
-                if (NP > 1) *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[(NP > 1) * NPIX + pix]) + q * 8) = pm;
-                if (NP > 2) *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[(NP > 2) * 2 * NPIX + pix]) + q * 8) = pl;
-            }
-            rx[it] = load_x(nch, it);  // the register is free again: reload it for the next chunk
+            for (int p = 0; p < NP; ++p)
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[p * NPIX + pix]) + q * 8) = px[it][p];
+            rx[it] = load_x(nch, it);  // reload the staging register for the next chunk (split during this phase's K-steps)
         }
 #pragma unroll
         for (int it = 0; it < WITER; ++it) {
@@ -298,6 +305,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     TileInfo ti = decode(tile);
     retarget(ti);
     prefetch(0);
+#pragma unroll
+    for (int it = 0; it < XITER; ++it) split_unit(it);
     // one K-step: 24 MFMAs on the fragments at sX[offA + ...] (offset incl. the image base) and weight slot slotB; both
     // arguments are per-half-wave values (lanes 0-31 and 32-63 contract different {tap, chunk} blocks of 8 channels)
     auto kstep = [&](int offA, int slotB, bool zero_a) __attribute__((always_inline)) {
@@ -362,6 +371,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
             const int t0 = 2 * j, t1 = 2 * j + 1;
             const int offA0 = (t0 / KS) * HTW + t0 % KS, offA1 = (t1 / KS) * HTW + t1 % KS;
             kstep(par * XBUF + (half ? offA1 : offA0), half ? t1 : t0, false);
+            // the next chunk's activations (loaded during this phase's commit) are split in the shadow of the MFMAs
+            if (KS == 3 && j >= 1 && j - 1 < XITER) split_unit(j - 1);
+        }
+        if (KS != 3) {
+#pragma unroll
+            for (int it = 0; it < XITER; ++it) split_unit(it);
         }
         // tap 8 is contracted for two chunks at once (the even chunk's image is still resident in the other buffer), so 16
         // channels cost 9 K-steps, not 10; a trailing unpaired chunk (odd chunk count) pairs its tap 8 with a zero A
