@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpunet_hip.so")
+LIB_PATH = os.environ.get("PUNET_HIP_LIB", os.path.join(_HERE, "libpunet_hip.so"))  # override: A/B of two builds
 
 _p = C.c_void_p
 _i = C.c_int

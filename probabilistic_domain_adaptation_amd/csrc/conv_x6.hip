@@ -168,9 +168,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
         const float* src = kbase < a.c0 ? a.x0 : a.x1;
         const int cs = kbase < a.c0 ? a.c0 : a.c1, coff = kbase < a.c0 ? kbase : kbase - a.c0;
         const int q = min(tid + it * 256, XUNITS - 1) % (CK / 4);  // the same clamped unit index as in retarget / commit
-        float4 v = *reinterpret_cast<const float4*>(src + (unsigned)(xpix[it] * cs + coff + q * 4));
-        if (!xin[it]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        return v;
+        // raw value: the out-of-image zeroing happens where the register is consumed (split_unit) - a select right here
+        // would make the wave wait for the load it has just issued
+        return *reinterpret_cast<const float4*>(src + (unsigned)(xpix[it] * cs + coff + q * 4));
     };
     auto load_w = [&](int ch, int it) __attribute__((always_inline)) -> uint4 {
         return *reinterpret_cast<const uint4*>(a.wp + (wbase[it] + (unsigned)(ch * a.n_row * 8)));
@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     // the shadow of its own MFMAs, whereas VALU work of the OTHER resident wave is held up behind them.
     bf16x4 px[XITER][NP];
     auto split_unit = [&](int it) __attribute__((always_inline)) {
-        const float xv[4] = {rx[it].x, rx[it].y, rx[it].z, rx[it].w};
+        const float4 r = xin[it] ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding outside the image
+        const float xv[4] = {r.x, r.y, r.z, r.w};
         bf16x4 ph, pm, pl;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

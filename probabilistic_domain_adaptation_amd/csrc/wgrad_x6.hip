@@ -58,10 +58,14 @@ __device__ __forceinline__ s16x4 tr_read(const char* lds_base, int byte_off) {
 }
 
 // taps [T0, T0 + NT) of one staged tile.  aoff/boff: this lane's byte offset inside an image (see kernel body).
-template <int NP, int T0, int NT>
-__device__ __forceinline__ void tile_mfma(f32x16 (&acc)[5], const char* sX, const char* sD, int cib, int cob, int aoff, int boff) {
+// `between(s)` is called after the MFMAs of pixel group s have been issued: the kernel stages the NEXT tile there (split +
+// LDS writes into the other image set), i.e. in the same instruction stream as the MFMAs - a wave's own VALU / LDS work
+// issues in the shadow of its own MFMAs, whereas a separate staging phase leaves the matrix pipe idle.
+template <int NP, int T0, int NT, typename F>
+__device__ __forceinline__ void tile_mfma(f32x16 (&acc)[5], const char* sX, const char* sD, int cib, int cob, int aoff, int boff,
+                                          F&& between) {
     constexpr int P1 = NP > 1 ? 1 : 0, P2 = NP > 2 ? 2 : 0;  // plane indices that exist for this NP
-#pragma unroll 1
+#pragma unroll
     for (int s = 0; s < NPD / 16; ++s) {
         const int row = (16 * s) / WTW, col0 = (16 * s) % WTW;
         Frag b[NP];
@@ -92,6 +96,8 @@ __device__ __forceinline__ void tile_mfma(f32x16 (&acc)[5], const char* sX, cons
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[0].v, c, 0, 0, 0);  // hh
             acc[tt] = c;
         }
+        between(s);
+        __builtin_amdgcn_sched_barrier(0);  // keep the four unrolled pixel groups apart (hoisted fragment reads cost registers)
     }
 }
 
@@ -144,6 +150,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
     const int lane_off = (8 * half + q) * ROWB + (16 * cb + 4 * p4) * 2;
 
     float4 rx[XIT], rd[DIT];
+    unsigned inmask = 0u;  // bit per staging register: its unit lies inside the image / channel range
     auto prefetch = [&](int tile) __attribute__((always_inline)) {
         int sid = tile;
         const int txi = sid % tiles_x;
@@ -151,17 +158,19 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
         const int tyi = sid % tiles_y;
         const int b = sid / tiles_y;
         const int ty0 = tyi * WTH, tx0 = txi * WTW;
+        // branch-free (clamped address + select) with 32-bit offsets: one basic block, exact vmcnt waits
+        inmask = 0u;
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
-            const int u = tid + it * 512;
+            const int u = min(tid + it * 512, XUNITS - 1);
             const int c4 = u % (WC / 4), pix = u / (WC / 4);
             const int py = pix / HTW, px = pix % HTW;
             const int gy = ty0 + py - 1, gx = tx0 + px - 1;
             const int c = ci0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < XUNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.cs)
-                v = *reinterpret_cast<const float4*>(a.x + ((size_t)(b * a.H + gy) * a.W + gx) * a.cs + c);
-            rx[it] = v;
+            const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.cs;
+            const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1), cc = min(c, a.cs - 4);
+            rx[it] = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * a.H + cy) * a.W + cx) * a.cs + cc));
+            inmask = in ? inmask | (1u << it) : inmask;  // zeroing happens at the consumer: no wait on the load just issued
         }
 #pragma unroll
         for (int it = 0; it < DIT; ++it) {
@@ -170,55 +179,55 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
             const int py = pix / WTW, px = pix % WTW;
             const int gy = ty0 + py, gx = tx0 + px;
             const int c = co0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < DUNITS && gy < a.H && gx < a.W && c < a.cout)
-                v = *reinterpret_cast<const float4*>(a.dz + ((size_t)(b * a.H + gy) * a.W + gx) * a.cout + c);
-            rd[it] = v;
+            const bool in = gy < a.H && gx < a.W && c < a.cout;
+            const int cy = min(gy, a.H - 1), cx = min(gx, a.W - 1), cc = min(c, a.cout - 4);
+            rd[it] = *reinterpret_cast<const float4*>(a.dz + (unsigned)(((b * a.H + cy) * a.W + cx) * a.cout + cc));
+            inmask = in ? inmask | (1u << (XIT + it)) : inmask;
         }
     };
-    auto commit = [&](int buf) __attribute__((always_inline)) {
+    static_assert(DUNITS % 512 == 0, "every dZ unit is owned by exactly one thread (the bias sums rely on it)");
+    auto commit_x = [&](int buf, int it) __attribute__((always_inline)) {
         char* sX = smem + buf * BUF;
-        char* sD = sX + NP * 2 * XIMG;
+        const int u = min(tid + it * 512, XUNITS - 1);  // a clamped duplicate re-writes the last unit with the same data
+        const int c4 = u % (WC / 4), pix = u / (WC / 4);
+        const float4 r = (inmask >> it) & 1u ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float xv[4] = {r.x, r.y, r.z, r.w};
+        bf16x4 ph, pm, pl;
 #pragma unroll
-        for (int it = 0; it < XIT; ++it) {
-            const int u = tid + it * 512;
-            if (u < XUNITS) {
-                const int c4 = u % (WC / 4), pix = u / (WC / 4);
-                const float xv[4] = {rx[it].x, rx[it].y, rx[it].z, rx[it].w};
-                bf16x4 ph, pm, pl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    __bf16 h_, m_, l_;
-                    split3(xv[e], h_, m_, l_);
-                    ph[e] = h_; pm[e] = m_; pl[e] = l_;
-                }
-                const int off = (c4 >> 3) * XIMG + pix * ROWB + (c4 & 7) * 8;
-                *reinterpret_cast<bf16x4*>(sX + 0 * 2 * XIMG + off) = ph;
-                if (NP > 1) *reinterpret_cast<bf16x4*>(sX + (NP > 1) * 2 * XIMG + off) = pm;
-                if (NP > 2) *reinterpret_cast<bf16x4*>(sX + (NP > 2) * 4 * XIMG + off) = pl;
-            }
+        for (int e = 0; e < 4; ++e) {
+            __bf16 h_, m_, l_;
+            split3(xv[e], h_, m_, l_);
+            ph[e] = h_; pm[e] = m_; pl[e] = l_;
         }
+        const int off = (c4 >> 3) * XIMG + pix * ROWB + (c4 & 7) * 8;
+        *reinterpret_cast<bf16x4*>(sX + 0 * 2 * XIMG + off) = ph;
+        if (NP > 1) *reinterpret_cast<bf16x4*>(sX + (NP > 1) * 2 * XIMG + off) = pm;
+        if (NP > 2) *reinterpret_cast<bf16x4*>(sX + (NP > 2) * 4 * XIMG + off) = pl;
+    };
+    auto commit_d = [&](int buf, int it) __attribute__((always_inline)) {
+        char* sD = smem + buf * BUF + NP * 2 * XIMG;
+        const int u = tid + it * 512;
+        const int c4 = u % (WC / 4), pix = u / (WC / 4);
+        const float4 v = (inmask >> (XIT + it)) & 1u ? rd[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+        const float xv[4] = {v.x, v.y, v.z, v.w};
+        bf16x4 ph, pm, pl;
 #pragma unroll
-        for (int it = 0; it < DIT; ++it) {
-            const int u = tid + it * 512;
-            if (u < DUNITS) {
-                const int c4 = u % (WC / 4), pix = u / (WC / 4);
-                const float4 v = rd[it];
-                bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
-                const float xv[4] = {v.x, v.y, v.z, v.w};
-                bf16x4 ph, pm, pl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    __bf16 h_, m_, l_;
-                    split3(xv[e], h_, m_, l_);
-                    ph[e] = h_; pm[e] = m_; pl[e] = l_;
-                }
-                const int off = (c4 >> 3) * DIMG + pix * ROWB + (c4 & 7) * 8;
-                *reinterpret_cast<bf16x4*>(sD + 0 * 2 * DIMG + off) = ph;
-                if (NP > 1) *reinterpret_cast<bf16x4*>(sD + (NP > 1) * 2 * DIMG + off) = pm;
-                if (NP > 2) *reinterpret_cast<bf16x4*>(sD + (NP > 2) * 4 * DIMG + off) = pl;
-            }
+        for (int e = 0; e < 4; ++e) {
+            __bf16 h_, m_, l_;
+            split3(xv[e], h_, m_, l_);
+            ph[e] = h_; pm[e] = m_; pl[e] = l_;
         }
+        const int off = (c4 >> 3) * DIMG + pix * ROWB + (c4 & 7) * 8;
+        *reinterpret_cast<bf16x4*>(sD + 0 * 2 * DIMG + off) = ph;
+        if (NP > 1) *reinterpret_cast<bf16x4*>(sD + (NP > 1) * 2 * DIMG + off) = pm;
+        if (NP > 2) *reinterpret_cast<bf16x4*>(sD + (NP > 2) * 4 * DIMG + off) = pl;
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) commit_x(buf, it);
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) commit_d(buf, it);
     };
 
     int cur = 0;
@@ -230,14 +239,34 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
     for (int tile = slice; tile < ntiles; tile += a.nslices) {
         const int next = tile + a.nslices;
         const bool has_next = next < ntiles;  // block-uniform
-        if (has_next) prefetch(next);         // in flight during the MFMA phase
+        prefetch(has_next ? next : tile);     // unconditional (the loop body stays one basic block); a re-fetch is dropped
         const char* sX = smem + cur * BUF;
         const char* sD = sX + NP * 2 * XIMG;
-        if (group == 0)
-            tile_mfma<NP, 0, 5>(acc, sX, sD, cib, cob, lane_off, lane_off);
-        else
-            tile_mfma<NP, 5, 4>(acc, sX, sD, cib, cob, lane_off, lane_off);
-        if (has_next) commit(cur ^ 1);  // the other image set: its last readers passed the previous barrier
+        const int nbuf = cur ^ 1;  // the other image set: its last readers passed the previous barrier
+        // the next tile is staged between the four pixel groups of this tile's MFMAs, late enough for its loads to land
+        auto between = [&](int s) __attribute__((always_inline)) {
+            if (s == 1) { commit_x(nbuf, 0); commit_x(nbuf, 1); }
+            if (s == 2) { commit_x(nbuf, 2); commit_x(nbuf, 3); }
+            if (s == 3) {
+#pragma unroll
+                for (int it = 4; it < XIT; ++it) commit_x(nbuf, it);
+#pragma unroll
+                for (int it = 0; it < DIT; ++it) commit_d(nbuf, it);
+            }
+        };
+        static_assert(XIT >= 4 && NPD / 16 == 4, "staging schedule assumes four pixel groups and at least four X units");
+        if (has_next) {
+            if (group == 0)
+                tile_mfma<NP, 0, 5>(acc, sX, sD, cib, cob, lane_off, lane_off, between);
+            else
+                tile_mfma<NP, 5, 4>(acc, sX, sD, cib, cob, lane_off, lane_off, between);
+        } else {  // last tile of this slice: nothing to stage (and the dZ column sums must not count a tile twice)
+            auto nothing = [](int) {};
+            if (group == 0)
+                tile_mfma<NP, 0, 5>(acc, sX, sD, cib, cob, lane_off, lane_off, nothing);
+            else
+                tile_mfma<NP, 5, 4>(acc, sX, sD, cib, cob, lane_off, lane_off, nothing);
+        }
         __syncthreads();
         cur ^= 1;
     }
@@ -302,6 +331,8 @@ extern "C" int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int 
                     "punet_conv_wgrad_x6: channels must be multiples of 4 (cs=%d cout=%d)", cs, cout);
     PUNET_CHECK_ARG(ci_off >= 0 && ci_off + cs <= cin_total, "punet_conv_wgrad_x6: bad channel window");
     PUNET_CHECK_ARG(nslices >= 1, "punet_conv_wgrad_x6: nslices must be >= 1");
+    PUNET_CHECK_ARG((unsigned long long)B * H * W * (cs > cout ? cs : cout) < (1ull << 31),
+                    "punet_conv_wgrad_x6: tensor too large for 32-bit indexing");
     WgradX6Args a{};
     a.x = x; a.cs = cs; a.dz = dz; a.cout = cout;
     a.partial = workspace;
