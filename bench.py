@@ -179,15 +179,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    sync()
     eng = model.engine
     engines = [eng] + ([teacher.engine] if teacher is not None else [])
     prof = None if a.no_kernel_timing else []
-    for e in engines:
-        e.prof = prof
+    for e in engines:  # the warm-up runs with the same HIP-event brackets as the timed steps: the first use of ~1000 events
+        e.prof = prof  # in a process costs tens of ms (seen as one 124 ms step in an otherwise flat 59 ms series)
         e.prof_kinds = {"conv3x3_fwd"} if a.kernel_timing == "roofline" else None
+    for _ in range(a.warmup):
+        step()
+    sync()
+    if prof is not None:
+        prof.clear()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]  # per-step GPU timeline (diagnostic)
     t0 = time.perf_counter()
     marks[0].record()
