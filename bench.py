@@ -248,7 +248,7 @@ def main():
             traffic, traffic_note = None, "not collected"
             try:  # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.py)
                 if a.workload == "mean_teacher" and (B, H, W, N) == (4, 512, 512, 8) and eng.conv_mode in ("x6", "f32"):
-                    fn, key = {"x6": ("pmc_hbm_traffic_x6.json", "conv3x3_x6_kernel<3, false>"),
+                    fn, key = {"x6": ("pmc_hbm_traffic_x6.json", "conv3x3_x6_kernel<3, false, 3>"),
                                "f32": ("pmc_hbm_traffic.json", "conv_mfma_kernel<3, false>")}[eng.conv_mode]
                     pm = json.load(open(os.path.join(ROOT, "profiles", "r01", fn)))
                     traffic = round(pm["kernels"][key]["hbm_bytes_per_launch"])

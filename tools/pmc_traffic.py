@@ -26,13 +26,11 @@ def load(path, counter):
 
 
 def short(name):
-    for key in ("conv3x3_x6_kernel<3, false>", "conv3x3_x6_kernel<3, true>", "conv3x3_x6_kernel<2, false>",
-                "conv3x3_x6_kernel<2, true>", "conv3x3_x6_kernel<1, false>", "conv3x3_x6_kernel<1, true>", "wgrad3x3_x6_kernel<3>",
-                "wgrad3x3_x6_kernel<2>", "wgrad3x3_x6_kernel<1>", "conv_mfma_kernel<3, false>", "conv_mfma_kernel<3, true>", "conv_mfma_kernel<1, false>",
-                "conv_mfma_kernel<1, true>", "wgrad_mfma_kernel<3>", "wgrad_mfma_kernel<1>", "fcomb_sampler_kernel<2>"):
-        if key in name:
-            return key
-    return name.split("(")[0].split("::")[-1][:60]
+    """Kernel name without the namespace and argument list, template arguments kept:
+    'void (anonymous namespace)::conv3x3_x6_kernel<3, false, 3>(...)' -> 'conv3x3_x6_kernel<3, false, 3>'."""
+    import re
+    m = re.search(r"([A-Za-z_][A-Za-z0-9_]*(?:<[^()]*>)?)\(", name.replace("(anonymous namespace)::", ""))
+    return (m.group(1) if m else name)[:60]
 
 
 def main():
