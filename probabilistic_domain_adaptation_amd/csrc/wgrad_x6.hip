@@ -16,6 +16,20 @@
 #include "common.h"
 #include "punet_hip.h"
 
+// -DPUNET_WGRAD_TRACE: s_memtime stamps of one workgroup's tile (tools/trace_wgrad.sh); compiled out otherwise.  Only at
+// the region boundaries (loop top 0, barrier reached 10 / passed 11): a stamp inside the MFMA stream pins the schedule and
+// no longer measures the product kernel (the compiler interleaves the staging with the MFMAs of a pixel group).
+#ifdef PUNET_WGRAD_TRACE
+__device__ unsigned long long punet_wgrad_trace[8 * 32];
+#define WGT(id)                                                                                          \
+    do {                                                                                                 \
+        if (blockIdx.x == 7 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && trace_iter == 5)            \
+            punet_wgrad_trace[(threadIdx.x >> 6) * 32 + (id)] = __builtin_amdgcn_s_memtime();            \
+    } while (0)
+#else
+#define WGT(id)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -231,6 +245,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
     };
 
     int cur = 0;
+#ifdef PUNET_WGRAD_TRACE
+    int trace_iter = 0;
+#endif
     if (slice < ntiles) {
         prefetch(slice);
         commit(0);
@@ -239,6 +256,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
     for (int tile = slice; tile < ntiles; tile += a.nslices) {
         const int next = tile + a.nslices;
         const bool has_next = next < ntiles;  // block-uniform
+        WGT(0);
         prefetch(has_next ? next : tile);     // unconditional (the loop body stays one basic block); a re-fetch is dropped
         const char* sX = smem + cur * BUF;
         const char* sD = sX + NP * 2 * XIMG;
@@ -267,8 +285,13 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
             else
                 tile_mfma<NP, 5, 4>(acc, sX, sD, cib, cob, lane_off, lane_off, nothing);
         }
+        WGT(10);
         __syncthreads();
+        WGT(11);
         cur ^= 1;
+#ifdef PUNET_WGRAD_TRACE
+        ++trace_iter;
+#endif
     }
 
     const int co = co0 + cob * 32 + l31;
@@ -350,3 +373,35 @@ extern "C" int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int 
         rc = punet_launch_reduce_slabs(a.bias_partial, nslices, (size_t)cout, 1, cout, 1, 1, 0, dbias, accumulate, scale, stream);
     return rc;
 }
+
+#ifdef PUNET_WGRAD_TRACE_MAIN  // standalone trace driver: 64 -> 64 channels at 512 x 512, batch 4 (tools/trace_wgrad.sh)
+#include <cstdio>
+#include <vector>
+int main() {
+    const int B = 4, H = 512, W = 512, C = 64;
+    const size_t n = (size_t)B * H * W * C;
+    std::vector<float> h(n);
+    unsigned s = 1;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.f - (s & 1 ? 0.5f : 1.5f); }
+    float *x, *dz, *dw, *db, *ws;
+    const int ns = punet_wgrad_x6_slices(C, C, B, H, W);
+    hipMalloc(&x, n * 4); hipMalloc(&dz, n * 4); hipMalloc(&dw, 9 * C * C * 4); hipMalloc(&db, C * 4);
+    hipMalloc(&ws, ((size_t)ns * 9 * C * C + (size_t)ns * C) * 4);
+    hipMemcpy(x, h.data(), n * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dz, h.data(), n * 4, hipMemcpyHostToDevice);
+    for (int r = 0; r < 3; ++r) {
+        const int rc = punet_conv_wgrad_x6(x, C, dz, C, dw, C, 0, db, ws, ns, B, H, W, 0, 1.f, nullptr);
+        if (rc) { printf("error %d\n", rc); return 1; }
+    }
+    hipDeviceSynchronize();
+    unsigned long long t[8 * 32];
+    hipMemcpyFromSymbol(t, HIP_SYMBOL(punet_wgrad_trace), sizeof(t));
+    printf("slices %d; stamps relative to wave 0's loop top (id 0), shader cycles (s_memtime)\n", ns);
+    for (int w = 0; w < 8; ++w) {
+        printf("wave %d:", w);
+        for (int i : {0, 10, 11}) printf("  id %2d: %6lld", i, (long long)(t[w * 32 + i] - t[0]));
+        printf("\n");
+    }
+    return 0;
+}
+#endif

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Build wgrad_x6.hip with its s_memtime stamps and standalone driver (-DPUNET_WGRAD_TRACE[_MAIN]) against the other
+# objects of the library, into tools/trace_wgrad (untracked).  Run the binary on the GPU box: one workgroup's tile, per wave:
+# ids 0 loop top, 10 barrier reached, 11 barrier passed (stamps only at the region boundaries: they do not change the schedule).
+set -e
+cd "$(dirname "$0")/.."
+C=probabilistic_domain_adaptation_amd/csrc
+objs=$(ls $C/build/*.o | grep -v wgrad_x6.o)
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DPUNET_WGRAD_TRACE -DPUNET_WGRAD_TRACE_MAIN -I $C -I include \
+    -c $C/wgrad_x6.hip -o /tmp/trace_wgrad.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 /tmp/trace_wgrad.o $objs -o tools/trace_wgrad
