@@ -43,9 +43,12 @@ def _tiles(shape, block_shape, halo):
 
 @torch.no_grad()
 def predict_image(model, image: np.ndarray, prior_samples: int = 8, block_shape=(384, 384), halo=(64, 64),
-                  tile_batch: int = 4, multiple_of: int = 8) -> np.ndarray:
+                  tile_batch: int = 4, multiple_of: int = 8, shard_over_ranks: bool = True) -> np.ndarray:
     """Tiled MC prediction of one 2-D image -> float32 mean-probability map (punet_predictions.py:35-50).
-    Tiles of equal outer shape are batched (`tile_batch` per launch); every tile gets its own latent draws."""
+    Tiles of equal outer shape are batched (`tile_batch` per launch); every tile gets its own latent draws.
+    Under an initialised `torch.distributed` group (one process per GPU) the tile batches are dealt round-robin to the
+    ranks - tiles are independent, so this is replicas-only - and the disjoint partial maps are joined by
+    ONE all_reduce(sum) of the output; every rank returns the full map."""
     assert image.ndim == 2, "2-D single-channel images (every reference script uses input_channels=1)"
     H, W = image.shape
     out = np.zeros((H, W), dtype="float32")
@@ -59,13 +62,24 @@ def predict_image(model, image: np.ndarray, prior_samples: int = 8, block_shape=
         tile = standardize(padded[y0:y0 + oh, x0:x0 + ow])  # padded origin is (-halo, -halo)
         groups.setdefault((oh, ow), []).append(((y0, y1, x0, x1), tile))
     dev = model.device
+    import torch.distributed as dist
+    world = dist.get_world_size() if shard_over_ranks and dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    n_chunk = 0
     for (oh, ow), items in groups.items():
         for i in range(0, len(items), tile_batch):
+            n_chunk += 1
+            if (n_chunk - 1) % world != rank:
+                continue
             chunk = items[i:i + tile_batch]
             raw = torch.from_numpy(np.stack([t for _, t in chunk])[:, None]).to(dev)
             pred = mc_prediction(model, raw, prior_samples).cpu().numpy()[:, 0]
             for k, ((y0, y1, x0, x1), _) in enumerate(chunk):
                 out[y0:y1, x0:x1] = pred[k, halo[0]:halo[0] + (y1 - y0), halo[1]:halo[1] + (x1 - x0)]
+    if world > 1:  # every pixel was written by exactly one rank, the others hold 0 there
+        joined = torch.from_numpy(out).to(dev)
+        dist.all_reduce(joined, op=dist.ReduceOp.SUM)
+        out = joined.cpu().numpy()
     return out
 
 

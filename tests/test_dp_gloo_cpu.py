@@ -93,3 +93,65 @@ def test_unet_slice_of_the_flat_layout():
     assert L.unet_numel == 11690688 and all(nm.startswith("unet.") for nm in names)
     assert all(not nm.startswith("unet.") for nm, off, n, _ in L.entries if off >= L.unet_numel)
     assert L.unet_numel % 4 == 0
+
+
+class _PointwiseModel:
+    """Stand-in with the two calls mc_prediction makes; 'prediction' = sigmoid of the (standardised) tile, on the CPU."""
+    device = torch.device("cpu")
+
+    def forward(self, raw, segm, training=False):
+        self._raw = raw
+
+    def sample_consensus(self, n, eps=None):
+        return torch.sigmoid(self._raw), None
+
+
+def _tiled_reference(img, block, halo):
+    import numpy as np
+    from probabilistic_domain_adaptation_amd.my_predictions.punet_predictions import standardize
+    H, W = img.shape
+    out = np.zeros_like(img)
+    pad = np.pad(img, ((halo, halo + block), (halo, halo + block)), mode="reflect")
+    for y0 in range(0, H, block):
+        for x0 in range(0, W, block):
+            y1, x1 = min(y0 + block, H), min(x0 + block, W)
+            oh, ow = -(-(y1 - y0 + 2 * halo) // 8) * 8, -(-(x1 - x0 + 2 * halo) // 8) * 8
+            t = standardize(pad[y0:y0 + oh, x0:x0 + ow])
+            out[y0:y1, x0:x1] = (1.0 / (1.0 + np.exp(-t.astype("float64"))))[halo:halo + y1 - y0, halo:halo + x1 - x0]
+    return out
+
+
+def _worker_tiles(rank, world, port, q):
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from probabilistic_domain_adaptation_amd.my_predictions import predict_image
+    img = np.random.default_rng(3).normal(size=(200, 168)).astype("float32")
+    out = predict_image(_PointwiseModel(), img, prior_samples=2, block_shape=(64, 64), halo=(8, 8), tile_batch=2)
+    q.put((rank, float(np.abs(out - _tiled_reference(img, 64, 8)).max()), float(out.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tiled_prediction_sharded_over_ranks_world2():
+    """predict_image deals its tile batches to the ranks and joins the disjoint maps with one all_reduce: every rank ends
+    with the full map, equal to the single-process tiling (halo read with reflect padding, per-tile standardisation, halo
+    cropped) of a pointwise stand-in model."""
+    import numpy as np
+    from probabilistic_domain_adaptation_amd.my_predictions import predict_image
+    img = np.random.default_rng(3).normal(size=(200, 168)).astype("float32")
+    single = predict_image(_PointwiseModel(), img, prior_samples=2, block_shape=(64, 64), halo=(8, 8), tile_batch=2)
+    assert np.abs(single - _tiled_reference(img, 64, 8)).max() < 1e-6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_tiles, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, tot in res:
+        assert err < 1e-6
+        assert abs(tot - float(single.sum())) < 1e-2
