@@ -79,6 +79,85 @@ __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ src, 
     if (s == 12345.678f) out[0] = s;  // keep the chains alive
 }
 
+
+// the same operand registers through v_mfma_f32_16x16x32_bf16 (half the accumulator traffic per MAC, twice the operand
+// traffic): 48 MFMAs of 16 cycles = the 24 x 32 cycles of the K-step above
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+template <int WITH_LDS>
+__global__ __launch_bounds__(256) void mfma_loop_16(const uint4* __restrict__ src, float* __restrict__ out, int iters) {
+    __shared__ uint4 sm[WITH_LDS ? 2048 : 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (WITH_LDS) {
+        for (int i = tid; i < 2048; i += 256) sm[i] = src[i];
+        __syncthreads();
+    }
+    union U { uint4 u; bf16x8 v; };
+    U a[6], b[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        a[i].u = src[(lane + 64 * i) & 2047];
+        b[i].u = src[(lane + 64 * (i + 6)) & 2047];
+    }
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        if (WITH_LDS) {  // the same 12 x 16-byte fragment reads per 768 MFMA cycles as the 32x32 variant
+            const int base = (it * 7) & 1023;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                a[i].u = sm[(base + lane + 64 * i) & 2047];
+                b[i].u = sm[(base + lane + 64 * (i + 6)) & 2047];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            // eight DIFFERENT operand combinations: tiles 4-7 swap the roles of the a and b registers
+            const int mb = (t >> 1) & 1, nb = t & 1;
+            const bf16x8 *A = t < 4 ? &a[0].v : &b[0].v, *B = t < 4 ? &b[0].v : &a[0].v;
+            f32x4 c = acc[t];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2 + mb], B[2 + nb], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[4 + mb], B[0 + nb], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0 + mb], B[4 + nb], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2 + mb], B[0 + nb], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0 + mb], B[2 + nb], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0 + mb], B[0 + nb], c, 0, 0, 0);
+            acc[t] = c;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[t][r];
+    if (s == 12345.678f) out[0] = s;
+}
+
+template <int WITH_LDS>
+static void run16(const char* label, const uint4* src, float* out, int wg_per_cu, int iters, int reps) {
+    hipDeviceProp_t p;
+    CK(hipGetDeviceProperties(&p, 0));
+    const int grid = p.multiProcessorCount * wg_per_cu;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    mfma_loop_16<WITH_LDS><<<grid, 256>>>(src, out, iters);
+    CK(hipDeviceSynchronize());
+    for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(e0));
+        mfma_loop_16<WITH_LDS><<<grid, 256>>>(src, out, iters);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double flops = (double)grid * 4 * iters * 48 * 2.0 * 16 * 16 * 32;
+        printf("%-34s waves/SIMD=%d rep=%d  %.3f ms  %.1f TFLOP/s bf16  (x6-equivalent %.1f)\n", label, wg_per_cu, r, ms,
+               flops / ms * 1e-9, flops / ms * 1e-9 / 6);
+    }
+}
+
 template <int WITH_LDS, int ORDER = 0>
 static void run(const char* label, const uint4* src, float* out, int wg_per_cu, int iters, int reps) {
     hipDeviceProp_t p;
@@ -137,6 +216,10 @@ int main() {
             snprintf(label, sizeof label, "+12 ds_read_b128/24 mfma, %s", d);
             run<1>(label, src, out, w, iters, 3);
         }
+        snprintf(label, sizeof label, "16x16x32 MFMAs, %s", d);
+        run16<0>(label, src, out, 2, iters, 3);
+        snprintf(label, sizeof label, "16x16x32 + 12 ds_read_b128, %s", d);
+        run16<1>(label, src, out, 2, iters, 3);
         snprintf(label, sizeof label, "operand-sharing order, %s", d);
         run<0, 1>(label, src, out, 2, iters, 3);
         snprintf(label, sizeof label, "sharing order + LDS, %s", d);
