@@ -34,6 +34,11 @@ void punet_set_error(const char* fmt, ...);
 int punet_launch_reduce_slabs(const float* partial, int nslices, size_t slab_stride, int rows, int cols, int cs,
                               int cin_total, int ci_off, float* out, int accumulate, float scale, hipStream_t stream);
 
+// weight slabs (layout as above) and bias slabs (1 x cols per slice) of one layer in ONE launch; bit-identical to two calls
+int punet_launch_reduce_slabs_pair(const float* partial_w, size_t stride_w, int rows, int cols, int cs, int cin_total, int ci_off,
+                                   float* out_w, const float* partial_b, size_t stride_b, float* out_b, int nslices,
+                                   int accumulate, float scale, hipStream_t stream);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // C/D fragment map of v_mfma_f32_32x32x2_f32 (dtype independent on gfx950):

@@ -173,8 +173,6 @@ extern "C" int punet_conv3x3_small_wgrad(const float* x, int cin, const float* d
     }
     PUNET_LAUNCH_CHECK("conv3x3_small_wgrad");
     const size_t slab = (size_t)rows * cout;
-    int rc = punet_launch_reduce_slabs(workspace, grid, slab, 9 * cin, cout, cin, cin, 0, dw, accumulate, scale, stream);
-    if (rc != PUNET_OK) return rc;
-    return punet_launch_reduce_slabs(workspace + (size_t)9 * cin * cout, grid, slab, 1, cout, 1, 1, 0, dbias, accumulate,
-                                     scale, stream);
+    return punet_launch_reduce_slabs_pair(workspace, slab, 9 * cin, cout, cin, cin, 0, dw, workspace + (size_t)9 * cin * cout, slab,
+                                          dbias, grid, accumulate, scale, stream);
 }

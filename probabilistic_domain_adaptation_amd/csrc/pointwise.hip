@@ -712,6 +712,72 @@ int punet_launch_reduce_slabs(const float* partial, int nslices, size_t slab_str
     return PUNET_OK;
 }
 
+// Two reductions in ONE launch (a layer's weight slabs and its bias slabs): the first nb0 blocks work on job 0, the rest
+// on job 1.  Per output the summation is exactly reduce_slabs_kernel's (lane sl sums slices sl, sl + 8, ... in order, lanes
+// combined in order), so results are bit-identical to two separate launches.
+struct SlabJob {
+    const float* partial;
+    size_t slab_stride;
+    int rows, cols, cs, cin_total, ci_off;
+    float* out;
+};
+
+__global__ __launch_bounds__(256) void reduce_slabs_pair_kernel(SlabJob j0, SlabJob j1, unsigned nb0, int vec0, int nslices,
+                                                                int accumulate, float scale) {
+    __shared__ float4 sh[8][32];
+    const bool first = blockIdx.x < nb0;
+    const SlabJob& j = first ? j0 : j1;
+    const int vec = first ? vec0 : 1;  // job 0 may run 4 outputs per thread, job 1 (the short one) is scalar
+    const unsigned blk = first ? blockIdx.x : blockIdx.x - nb0;
+    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const size_t n = (size_t)j.rows * j.cols / vec;
+    const size_t i = (size_t)blk * 32 + o;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+        if (vec == 4) {
+            const float4* p4 = reinterpret_cast<const float4*>(j.partial);
+            const size_t st4 = j.slab_stride / 4;
+            for (int k = sl; k < nslices; k += 8) {
+                const float4 v = p4[(size_t)k * st4 + i];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        } else {
+            for (int k = sl; k < nslices; k += 8) s.x += j.partial[(size_t)k * j.slab_stride + i];
+        }
+    }
+    sh[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float4 t = sh[0][o];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { t.x += sh[k][o].x; t.y += sh[k][o].y; t.z += sh[k][o].z; t.w += sh[k][o].w; }
+        const size_t e = i * vec;
+        const int row = (int)(e / j.cols), col = (int)(e % j.cols);
+        float* dst = j.out + ((size_t)(row / j.cs) * j.cin_total + j.ci_off + row % j.cs) * j.cols + col;
+        if (vec == 4) {
+            float4 v = make_float4(t.x * scale, t.y * scale, t.z * scale, t.w * scale);
+            if (accumulate) { const float4 q = *reinterpret_cast<float4*>(dst); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            *reinterpret_cast<float4*>(dst) = v;
+        } else {
+            const float v = t.x * scale;
+            *dst = accumulate ? *dst + v : v;
+        }
+    }
+}
+
+int punet_launch_reduce_slabs_pair(const float* partial_w, size_t stride_w, int rows, int cols, int cs, int cin_total, int ci_off,
+                                   float* out_w, const float* partial_b, size_t stride_b, float* out_b, int nslices,
+                                   int accumulate, float scale, hipStream_t stream) {
+    const size_t n = (size_t)rows * cols;
+    const int vec0 = (cols % 4 == 0 && stride_w % 4 == 0 && ((uintptr_t)partial_w & 15) == 0 && ((uintptr_t)out_w & 15) == 0) ? 4 : 1;
+    const unsigned nb0 = (unsigned)((n / vec0 + 31) / 32), nb1 = (unsigned)((cols + 31) / 32);
+    SlabJob j0{partial_w, stride_w, rows, cols, cs, cin_total, ci_off, out_w};
+    SlabJob j1{partial_b, stride_b, 1, cols, 1, 1, 0, out_b};
+    reduce_slabs_pair_kernel<<<nb0 + nb1, 256, 0, stream>>>(j0, j1, nb0, vec0, nslices, accumulate, scale);
+    PUNET_LAUNCH_CHECK("reduce_slabs_pair");
+    return PUNET_OK;
+}
+
 #define STREAM ((hipStream_t)stream)
 
 extern "C" int punet_pool2x2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {

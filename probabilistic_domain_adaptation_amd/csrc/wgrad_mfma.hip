@@ -189,11 +189,8 @@ extern "C" int punet_conv_wgrad(const float* x, int cs, const float* dz, int cou
         wgrad_mfma_kernel<1><<<grid, 256, 0, stream>>>(a);
     PUNET_LAUNCH_CHECK("wgrad_mfma");
     const size_t n = (size_t)KK * cs * cout;
-    int rc = punet_launch_reduce_slabs(a.partial, nslices, n, KK * cs, cout, cs, cin_total, ci_off, dw, accumulate,
-                                       scale, stream);
-    if (rc != PUNET_OK) return rc;
     if (dbias)
-        rc = punet_launch_reduce_slabs(a.bias_partial, nslices, (size_t)cout, 1, cout, 1, 1, 0, dbias, accumulate,
-                                       scale, stream);
-    return rc;
+        return punet_launch_reduce_slabs_pair(a.partial, n, KK * cs, cout, cs, cin_total, ci_off, dw, a.bias_partial, (size_t)cout,
+                                              dbias, nslices, accumulate, scale, stream);
+    return punet_launch_reduce_slabs(a.partial, nslices, n, KK * cs, cout, cs, cin_total, ci_off, dw, accumulate, scale, stream);
 }

@@ -367,10 +367,10 @@ extern "C" int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int 
     if (rc0 != PUNET_OK) return rc0;
     PUNET_LAUNCH_CHECK("wgrad3x3_x6");
     const size_t n = (size_t)9 * cs * cout;
-    int rc = punet_launch_reduce_slabs(a.partial, nslices, n, 9 * cs, cout, cs, cin_total, ci_off, dw, accumulate, scale, stream);
-    if (rc != PUNET_OK) return rc;
     if (dbias)
-        rc = punet_launch_reduce_slabs(a.bias_partial, nslices, (size_t)cout, 1, cout, 1, 1, 0, dbias, accumulate, scale, stream);
+        return punet_launch_reduce_slabs_pair(a.partial, n, 9 * cs, cout, cs, cin_total, ci_off, dw, a.bias_partial, (size_t)cout,
+                                              dbias, nslices, accumulate, scale, stream);
+    const int rc = punet_launch_reduce_slabs(a.partial, nslices, n, 9 * cs, cout, cs, cin_total, ci_off, dw, accumulate, scale, stream);
     return rc;
 }
 
