@@ -88,6 +88,12 @@ int punet_conv3x3_x6_gated(const float* x0, int c0, const float* x1, int c1, con
                            int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out,
                            const float* mask, const void* gate_bits, void* gate_out, int accumulate, int relu, int B,
                            int H, int W, void* stream);
+/* Forward 3x3 convolution that ALSO writes AvgPool2d(2, 2) of its output (DownConvBlock = pool + 3 convs,
+ * unet_blocks.py:17-24 / probabilistic_unet.py:54: the last conv of a block feeds the next block's pool): pool_out is
+ * [B, H/2, W/2, n_out]; H and W must be even (ceil_mode never engages); bit-identical to punet_pool2x2_fwd of y. */
+int punet_conv3x3_x6_pooled(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
+                            int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out,
+                            void* gate_out, float* pool_out, int relu, int B, int H, int W, void* stream);
 /* The same kernel for 1x1 convolutions (the Fcomb layers, probabilistic_unet.py:168-173): planes from
  * punet_split_weights_x6(..., ksize = 1, ...), c0/c1 multiples of 8; always the six-product parity arithmetic. */
 int punet_conv1x1_x6_gated(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,

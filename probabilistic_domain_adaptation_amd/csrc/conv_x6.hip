@@ -50,6 +50,7 @@ struct ConvX6Args {
     const float* mask;
     const unsigned* gate_bits;  // ReLU gate of the destination as bits (instead of `mask`), layout: punet_gate_dwords
     unsigned* gate_out;         // forward with ReLU: (y > 0) bits of the output
+    float* pool_out;            // forward: AvgPool2d(2, 2) of the output as well (H, W even), nullptr = off
     int accumulate, relu;
     int B, H, W, ntiles;
     int xcd_remap;
@@ -251,6 +252,61 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                     bq4[nb][rg] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (a.bias && c < N) bq4[nb][rg] = *reinterpret_cast<const float4*>(a.bias + (size_t)ti.b * a.bias_img_stride + c);
                 }
+        }
+        if constexpr (!DGRAD) {
+            // forward: both rows of a channel quad together - the wave's two rows are a vertical pooling pair (the tile origin
+            // is even) and the horizontal partner of pixel x is lane x ^ 1, so AvgPool2d(2, 2) of the output costs one DPP
+            // add per row and value.  Summation order of pool2x2_fwd_kernel: ((y00 + y01) + y10) + y11, then * 0.25.
+            const int gy0 = ti.ty0 + 2 * wave;
+            const bool in0 = gy0 < a.H && gx < a.W, in1 = gy0 + 1 < a.H && gx < a.W;
+            const unsigned gd0 = (unsigned)(((((ti.b * a.H + gy0) * tiles_x + (ti.tx0 / TW)) * ntn + (ti.n0 / TN)) << 6) + lane);
+            const unsigned gd1 = gd0 + (unsigned)((tiles_x * ntn) << 6);
+            const unsigned pbase0 = (unsigned)(((ti.b * a.H + gy0) * a.W + gx) * N + ti.n0 + 4 * half);
+            const unsigned pbase1 = pbase0 + (unsigned)(a.W * N);
+            const unsigned qbase = (unsigned)(((ti.b * (a.H >> 1) + (gy0 >> 1)) * (a.W >> 1) + (gx >> 1)) * N + ti.n0 + 4 * half);
+            unsigned gout0 = 0u, gout1 = 0u;
+            auto partner = [](float v) __attribute__((always_inline)) {  // value of lane ^ 1 (quad_perm [1, 0, 3, 2])
+                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+            };
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int ch = nb * 32 + rg * 8;  // + 4 * half + e
+                    const bool okc = ti.n0 + ch + 4 * half < N;  // N is a multiple of 4
+                    float4 v0 = make_float4(acc[0][nb][4 * rg + 0], acc[0][nb][4 * rg + 1], acc[0][nb][4 * rg + 2], acc[0][nb][4 * rg + 3]);
+                    float4 v1 = make_float4(acc[1][nb][4 * rg + 0], acc[1][nb][4 * rg + 1], acc[1][nb][4 * rg + 2], acc[1][nb][4 * rg + 3]);
+                    const float4 bq = bq4[nb][rg];
+                    v0.x += bq.x; v0.y += bq.y; v0.z += bq.z; v0.w += bq.w;
+                    v1.x += bq.x; v1.y += bq.y; v1.z += bq.z; v1.w += bq.w;
+                    if (a.relu) {
+                        v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+                        v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+                    }
+                    if (in0 && okc) {
+                        *reinterpret_cast<float4*>(a.y + pbase0 + ch) = v0;
+                        gout0 |= ((v0.x > 0.f ? 1u : 0u) | (v0.y > 0.f ? 2u : 0u) | (v0.z > 0.f ? 4u : 0u) | (v0.w > 0.f ? 8u : 0u))
+                                 << (16 * nb + 4 * rg);
+                    }
+                    if (in1 && okc) {
+                        *reinterpret_cast<float4*>(a.y + pbase1 + ch) = v1;
+                        gout1 |= ((v1.x > 0.f ? 1u : 0u) | (v1.y > 0.f ? 2u : 0u) | (v1.z > 0.f ? 4u : 0u) | (v1.w > 0.f ? 8u : 0u))
+                                 << (16 * nb + 4 * rg);
+                    }
+                    if (a.pool_out) {  // uniform
+                        float4 q;
+                        q.x = (((v0.x + partner(v0.x)) + v1.x) + partner(v1.x)) * 0.25f;
+                        q.y = (((v0.y + partner(v0.y)) + v1.y) + partner(v1.y)) * 0.25f;
+                        q.z = (((v0.z + partner(v0.z)) + v1.z) + partner(v1.z)) * 0.25f;
+                        q.w = (((v0.w + partner(v0.w)) + v1.w) + partner(v1.w)) * 0.25f;
+                        if (!(lane & 1) && in0 && okc) *reinterpret_cast<float4*>(a.pool_out + qbase + ch) = q;
+                    }
+                }
+            if (a.gate_out) {  // forward with ReLU: (y > 0), for the consumers' backward
+                if (in0) a.gate_out[gd0] = gout0;
+                if (in1) a.gate_out[gd1] = gout1;
+            }
+            return;
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -518,7 +574,8 @@ extern "C" int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1
 
 static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
                           int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
-                          const void* gate_bits, void* gate_out, int accumulate, int relu, int B, int H, int W, void* stream);
+                          const void* gate_bits, void* gate_out, int accumulate, int relu, int B, int H, int W, void* stream,
+                          float* pool_out = nullptr);
 
 extern "C" int punet_conv3x3_x6_gated(const float* x0, int c0, const float* x1, int c1, const void* wplanes,
                                       long plane_stride, int n_row, int n_off, const float* bias, int bias_img_stride,
@@ -526,6 +583,15 @@ extern "C" int punet_conv3x3_x6_gated(const float* x0, int c0, const float* x1, 
                                       int accumulate, int relu, int B, int H, int W, void* stream) {
     return conv_x6_launch(3, x0, c0, x1, c1, wplanes, plane_stride, n_row, n_off, bias, bias_img_stride, y, n_out, mask, gate_bits,
                           gate_out, accumulate, relu, B, H, W, stream);
+}
+
+extern "C" int punet_conv3x3_x6_pooled(const float* x0, int c0, const float* x1, int c1, const void* wplanes,
+                                       long plane_stride, int n_row, int n_off, const float* bias, int bias_img_stride,
+                                       float* y, int n_out, void* gate_out, float* pool_out, int relu, int B, int H, int W,
+                                       void* stream) {
+    PUNET_CHECK_ARG(pool_out, "punet_conv3x3_x6_pooled: null pool_out");
+    return conv_x6_launch(3, x0, c0, x1, c1, wplanes, plane_stride, n_row, n_off, bias, bias_img_stride, y, n_out, nullptr, nullptr,
+                          gate_out, 0, relu, B, H, W, stream, pool_out);
 }
 
 extern "C" int punet_conv1x1_x6_gated(const float* x0, int c0, const float* x1, int c1, const void* wplanes,
@@ -538,8 +604,11 @@ extern "C" int punet_conv1x1_x6_gated(const float* x0, int c0, const float* x1, 
 
 static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
                           int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
-                          const void* gate_bits, void* gate_out, int accumulate, int relu, int B, int H, int W, void* stream) {
+                          const void* gate_bits, void* gate_out, int accumulate, int relu, int B, int H, int W, void* stream,
+                          float* pool_out) {
     PUNET_CHECK_ARG(x0 && wplanes && y, "punet_conv3x3_x6: null pointer");
+    PUNET_CHECK_ARG(!pool_out || (H % 2 == 0 && W % 2 == 0 && !mask && !gate_bits && !accumulate),
+                    "punet_conv3x3_x6_pooled: the fused 2x2 average needs even H and W (%dx%d) and the forward epilogue", H, W);
     PUNET_CHECK_ARG(c0 > 0 && c0 % CK == 0 && c1 >= 0 && c1 % CK == 0 && (c1 == 0 || x1),
                     "punet_conv3x3_x6: source channels must be multiples of %d (c0=%d c1=%d)", CK, c0, c1);
     PUNET_CHECK_ARG(n_out > 0 && n_out % 4 == 0 && n_off >= 0 && n_off + n_out <= n_row,
@@ -558,7 +627,7 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
     PUNET_CHECK_ARG(!(mask && gate_bits), "punet_conv3x3_x6: give the ReLU gate either as fp32 mask or as bits, not both");
     PUNET_CHECK_ARG(!gate_out || relu, "punet_conv3x3_x6: gate_out is the ReLU gate of the output and needs relu != 0");
     a.y = y; a.n_total = n_out; a.mask = mask; a.accumulate = accumulate; a.relu = relu;
-    a.gate_bits = (const unsigned*)gate_bits; a.gate_out = (unsigned*)gate_out;
+    a.gate_bits = (const unsigned*)gate_bits; a.gate_out = (unsigned*)gate_out; a.pool_out = pool_out;
     a.B = B; a.H = H; a.W = W;
     a.ntiles = B * ceil_div(H, TH) * ceil_div(W, TW) * ceil_div(n_out, TN);
     const int cap = g_x6_wg_per_cu * NUM_CU;

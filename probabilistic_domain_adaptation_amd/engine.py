@@ -234,6 +234,8 @@ class PUNetEngine:
         if self.conv_mode not in _X6_PRODUCTS and self.conv_mode != "f32":
             raise ValueError("PUNET_CONV_MODE must be one of 'x6', 'f32', 'x3', 'bf16'")
         self.x6 = self.conv_mode in _X6_PRODUCTS  # the split-plane kernel family
+        # the last conv of a contracting block also writes the next block's 2x2 average (PUNET_FUSE_POOL=0: separate kernel)
+        self.fuse_pool = os.environ.get("PUNET_FUSE_POOL", "1") != "0"
         self._x6 = {}  # (flat.data_ptr(), mode) -> bf16 planes buffer [3 * numel]
         self._x6_table = None  # (device int64 [nconv+1, 4], nconv, total_units) for punet_split_weights_x6_batch
         self._x6_1x1 = {}  # (flat.data_ptr(), mode) -> {conv name: bf16 planes} for the Fcomb 1x1 layers
@@ -270,9 +272,11 @@ class PUNetEngine:
         return x.permute(0, 2, 3, 1).contiguous()
 
     # ---------------------------------------------------------------- forward ops
-    def conv(self, flat, name: str, x0: Act, x1: Optional[Act] = None, relu=True, tape=None, taps=None, tape_bits=False) -> Act:
+    def conv(self, flat, name: str, x0: Act, x1: Optional[Act] = None, relu=True, tape=None, taps=None, tape_bits=False,
+             pooled: Optional[list] = None) -> Act:
         """tape_bits: publish the ReLU gate bits of the output even without a tape (Fcomb layers, whose backward is
-        written out by hand in elbo_backward)."""
+        written out by hand in elbo_backward).  pooled: a list that receives the 2x2 average of the output when the kernel
+        can produce it in its epilogue (split-plane 3x3 kernel, even H and W); left empty otherwise."""
         c = self.L.convs[name]
         B, H, W = x0.B, x0.H, x0.W
         y = Act(self._empty(B, H, W, c.cout), B, H, W, c.cout, relu_out=relu)
@@ -286,10 +290,18 @@ class PUNetEngine:
             planes = self._x6[(flat.data_ptr(), 0)]
             if relu and (tape is not None or tape_bits):  # a backward will follow: publish the ReLU gate of y as bits
                 y.bits = torch.empty(_lib.call("punet_gate_dwords", B, H, W, c.cout), dtype=torch.int32, device=self.device)
-            self._timed("conv3x3_fwd", 2.0 * B * H * W * cin * c.cout * 9, "punet_conv3x3_x6_gated", x0.ptr, x0.C,
-                        x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0,
-                        planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cout, 0, self._bptr(flat, c), 0, y.ptr, c.cout, None,
-                        None, y.bits.data_ptr() if y.bits is not None else None, 0, int(relu), B, H, W, _stream())
+            if pooled is not None and H % 2 == 0 and W % 2 == 0:
+                q = Act(self._empty(B, H // 2, W // 2, c.cout), B, H // 2, W // 2, c.cout)
+                pooled.append(q)
+                self._timed("conv3x3_fwd", 2.0 * B * H * W * cin * c.cout * 9, "punet_conv3x3_x6_pooled", x0.ptr, x0.C,
+                            x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0,
+                            planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cout, 0, self._bptr(flat, c), 0, y.ptr, c.cout,
+                            y.bits.data_ptr() if y.bits is not None else None, q.ptr, int(relu), B, H, W, _stream())
+            else:
+                self._timed("conv3x3_fwd", 2.0 * B * H * W * cin * c.cout * 9, "punet_conv3x3_x6_gated", x0.ptr, x0.C,
+                            x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0,
+                            planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cout, 0, self._bptr(flat, c), 0, y.ptr, c.cout,
+                            None, None, y.bits.data_ptr() if y.bits is not None else None, 0, int(relu), B, H, W, _stream())
         elif self.x6 and c.k == 1 and x1 is None and name in self._x6_1x1.get((flat.data_ptr(), 0), {}):
             planes = self._x6_1x1[(flat.data_ptr(), 0)][name]
             if relu and tape_bits:
@@ -325,11 +337,19 @@ class PUNetEngine:
     def encoder_stack(self, flat, blocks: Sequence[Sequence[str]], x: Act, tape=None, taps=None, tag="") -> Tuple[Act, List[Act]]:
         """The 4-block contracting stack shared by Unet (unet.py:50-55) and Encoder (probabilistic_unet.py:67-69)."""
         outs = []
+        pooled: list = []
         for i, names in enumerate(blocks):
             if i != 0:
-                x = self.pool(x, tape)
-            for nm in names:
-                x = self.conv(flat, nm, x, None, True, tape, taps)
+                if pooled:  # the previous block's last conv has written its 2x2 average already
+                    y = pooled.pop()
+                    if tape is not None:
+                        tape.append(("pool", x, y))
+                    x = y
+                else:
+                    x = self.pool(x, tape)
+            for k, nm in enumerate(names):
+                last = k == len(names) - 1 and i + 1 < len(blocks) and self.fuse_pool
+                x = self.conv(flat, nm, x, None, True, tape, taps, pooled=pooled if last else None)
             outs.append(x)
             if taps is not None:
                 taps[f"{tag}{i}"] = x

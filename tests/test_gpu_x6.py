@@ -216,3 +216,44 @@ def test_conv1x1_x6_fwd_and_dgrad(L, B, H, W, cin, cout, rows):
            None, None, None, 0, 0, B, H, W, S())
     torch.cuda.synchronize()
     assert rel_err(nchw(DX), x.grad) < 3e-6
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,cout", [(2, 16, 32, 64, 0, 64), (1, 24, 40, 32, 0, 96), (1, 8, 8, 128, 64, 128),
+                                              (3, 2, 2, 16, 0, 8), (1, 64, 96, 64, 0, 200)])
+def test_conv_x6_pooled_epilogue_is_bit_identical(L, B, H, W, c0, c1, cout):
+    """punet_conv3x3_x6_pooled = punet_conv3x3_x6_gated + punet_pool2x2_fwd of its output, bit for bit (output, gate bits
+    and the 2x2 average), including partial tiles in x, y and the channel block."""
+    g = torch.Generator().manual_seed(21)
+    cin = c0 + c1
+    X = torch.randn(B, H, W, cin, generator=g).cuda()
+    X0 = X[..., :c0].contiguous()
+    X1 = X[..., c0:].contiguous() if c1 else None
+    Wp = (torch.randn(3, 3, cin, cout, generator=g) / np.sqrt(cin * 9)).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    nw = 9 * cin * cout
+    pf = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+    L.call("punet_split_weights_x6", Wp.data_ptr(), pf.data_ptr(), nw, cin, cout, 3, 0, S())
+    nd = L.call("punet_gate_dwords", B, H, W, cout)
+    y1, y2 = torch.empty(B, H, W, cout, device="cuda"), torch.empty(B, H, W, cout, device="cuda")
+    g1 = torch.zeros(nd, dtype=torch.int32, device="cuda")
+    g2 = torch.zeros(nd, dtype=torch.int32, device="cuda")
+    q1 = torch.empty(B, H // 2, W // 2, cout, device="cuda")
+    q2 = torch.full((B, H // 2, W // 2, cout), float("nan"), device="cuda")
+    L.call("punet_conv3x3_x6_gated", X0.data_ptr(), c0, X1.data_ptr() if c1 else None, c1, pf.data_ptr(), nw, cout, 0, b.data_ptr(), 0,
+           y1.data_ptr(), cout, None, None, g1.data_ptr(), 0, 1, B, H, W, S())
+    L.call("punet_pool2x2_fwd", y1.data_ptr(), q1.data_ptr(), B, H, W, cout, S())
+    L.call("punet_conv3x3_x6_pooled", X0.data_ptr(), c0, X1.data_ptr() if c1 else None, c1, pf.data_ptr(), nw, cout, 0, b.data_ptr(), 0,
+           y2.data_ptr(), cout, g2.data_ptr(), q2.data_ptr(), 1, B, H, W, S())
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2) and torch.equal(g1, g2)
+    assert torch.equal(q1, q2)
+    assert (q1 > 0).any()
+
+
+def test_conv_x6_pooled_rejects_odd_sizes(L):
+    X = torch.zeros(1, 5, 8, 8, device="cuda")
+    pf = torch.zeros(3 * 9 * 8 * 8, dtype=torch.bfloat16, device="cuda")
+    y, q = torch.empty(1, 5, 8, 8, device="cuda"), torch.empty(1, 2, 4, 8, device="cuda")
+    with pytest.raises(RuntimeError, match="even H and W"):
+        L.call("punet_conv3x3_x6_pooled", X.data_ptr(), 8, None, 0, pf.data_ptr(), 9 * 8 * 8, 8, 0, None, 0, y.data_ptr(), 8, None,
+               q.data_ptr(), 1, 1, 5, 8, S())
