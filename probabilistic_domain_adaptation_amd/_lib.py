@@ -30,6 +30,7 @@ _SIGS = {
     "punet_conv3x3_x6": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "punet_gate_dwords": (_sz, [_i, _i, _i, _i]),
     "punet_conv3x3_x6_gated": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "punet_set_x6_mfma_shape": (_i, [_i]),
     "punet_conv3x3_x6_pooled": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "punet_conv1x1_x6_gated": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "punet_wgrad_workspace_floats": (_sz, [_i, _i, _i, _i]),

@@ -25,6 +25,8 @@
 // per accumulator register quad, four consecutive channels: 16-byte stores straight from the accumulators, no LDS
 // staging, no barrier (history and measurements at the epilogue lambda).  ReLU gates travel as bits (punet_gate_dwords).
 #include <type_traits>
+#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "punet_hip.h"
 
@@ -457,6 +459,350 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The same convolution through v_mfma_f32_16x16x32_bf16 (input channels a multiple of 32).  The 16 x 16 x 32 shape moves
+// half the accumulator data per MAC of 32 x 32 x 16 and the matrix cores are power-limited: the same
+// six-product chain sustains 2.07 PF against 1.80 PF in a register-only loop, +10 % in this kernel with unchanged reads.
+// One MFMA contracts FOUR {tap, 8 channels} blocks (lane group g = lane / 16 takes block g).  A chunk of 8 channels has
+// 9 blocks, so 4 chunks = 36 blocks = 9 K-steps; chunks are still staged one at a time, and the blocks a chunk leaves
+// over are contracted together with the next chunk's (the previous chunk's image is the other image buffer anyway):
+//   phase 0: {t0 .. t7}                          leaves t8
+//   phase 1: {t8', t0 .. t6}                     leaves t7 t8         (' = of the previous chunk)
+//   phase 2: {t7' t8', t0 .. t5}                 leaves t6 t7 t8
+//   phase 3: {t6' t7' t8', t0 .. t8}
+// Left-over weight rows stay where they are: the slab has 12 slots and a chunk's rows go to the slots its predecessor's
+// left-overs do not occupy (x6b_slot).  A wave's 64 pixel x 64 channel tile is 4 x 4 sub-tiles; to stay inside the register
+// budget the weight fragments of two channel blocks are resident and the pixel fragments are streamed, i.e. read twice
+// per K-step (36 fragment reads per 96 MFMAs of 16 cycles instead of 24: measured cost about half of the shape's gain).
+// Output mapping: lane (l16 = lane % 16, g) holds pixel l16 of a 16-pixel block and channels 16 cb + 4 g .. + 3 - again a
+// 16-byte store per sub-tile straight from the accumulators.  Gate bits keep the punet_gate_dwords layout: a dword's 32
+// bits are held half by lane (l16, g) and half by lane (l16, g ^ 2) = lane ^ 32 (v_permlane32_swap joins them).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int x6b_slot(int ph, int t) {
+    return ph == 0 ? t : ph == 1 ? (t < 8 ? t : 9) : ph == 2 ? (t < 7 ? t : t == 7 ? 8 : 10) : (t < 6 ? t : 2 * t - 5);
+}
+
+template <int NP, bool DGRAD>
+__global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
+    constexpr int KS = 3, KK = 9, PAD = 1;
+    constexpr int HTH = TH + KS - 1, HTW = TW + KS - 1;
+    constexpr int NPIX = HTH * HTW;
+    // LDS image: rows 48 pixels apart.  ds_read_b128 is served in groups that mix lanes of lane groups (0, 1) and (2, 3);
+    // two lane groups of one instruction are conflict-free iff their pixel offsets agree mod 16 (256 bytes = all 64 banks).
+    // With a pitch of 48 the taps of one column kx are 0 mod 16 apart, and so are the two image buffers.
+    constexpr int HTWP = 48;
+    constexpr int NPIXA = (HTH - 1) * HTWP + HTW;  // 466 units per plane
+    constexpr int XUNITS = NPIX * (CK / 4);
+    constexpr int XITER = (XUNITS + 255) / 256;
+    constexpr int WUNITS = NP * KK * TN;
+    constexpr int WITER = (WUNITS + 255) / 256;
+    constexpr int WSLAB = 12 * TN;   // per plane: 12 slots of one {tap, 8 channels} row (64 output channels x 16 bytes)
+    constexpr int XBUF = (NP * NPIXA + 15) / 16 * 16;  // one activation image (NP planes); two of them, by chunk parity
+    constexpr int OPERANDS = 2 * XBUF + NP * WSLAB;
+
+    __shared__ uint4 smem[OPERANDS];  // 81,920 B at NP = 3: exactly two workgroups per CU
+    uint4* sX = smem;
+    uint4* sW = smem + 2 * XBUF;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, l16 = lane & 15, g = lane >> 4;
+
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int ntn = (a.n_total + TN - 1) / TN;
+    const int N = a.n_total;
+    const int K = a.c0 + a.c1;
+    const int nchunks = K / CK;  // a multiple of 4 (host check)
+
+    auto decode = [&](int tile) {
+        TileInfo t;
+        t.n0 = (tile % ntn) * TN;
+        int sid = tile / ntn;
+        t.tx0 = (sid % tiles_x) * TW;
+        sid /= tiles_x;
+        t.ty0 = (sid % tiles_y) * TH;
+        t.b = sid / tiles_y;
+        return t;
+    };
+
+    f32x4 acc[4][4];  // [pixel block pb = 2 * row + half][channel block cb]
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+
+    // staging: identical to conv3x3_x6_kernel (see the comments there)
+    float4 rx[XITER];
+    uint4 rw[WITER];
+    int xpix[XITER];
+    bool xin[XITER];
+    unsigned wbase[WITER];
+    auto retarget = [&](const TileInfo& ti) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < XITER; ++it) {
+            const int u = min(tid + it * 256, XUNITS - 1);
+            const int pix = u / (CK / 4);
+            const int py = pix / HTW, px = pix % HTW;
+            const int gy = ti.ty0 + py - PAD, gx = ti.tx0 + px - PAD;
+            xin[it] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            xpix[it] = (ti.b * a.H + min(max(gy, 0), a.H - 1)) * a.W + min(max(gx, 0), a.W - 1);
+        }
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) {
+            const int u = min(tid + it * 256, WUNITS - 1);
+            const int n = u % TN, t = (u / TN) % KK, p = u / (TN * KK);
+            const int nc = min(ti.n0 + n, N - 1);
+            wbase[it] = (unsigned)(p * (int)a.plane_stride + (t * nchunks * a.n_row + a.n_off + nc) * 8);
+        }
+    };
+    auto load_x = [&](int ch, int it) __attribute__((always_inline)) -> float4 {
+        const int kbase = ch * CK;
+        const float* src = kbase < a.c0 ? a.x0 : a.x1;
+        const int cs = kbase < a.c0 ? a.c0 : a.c1, coff = kbase < a.c0 ? kbase : kbase - a.c0;
+        const int q = min(tid + it * 256, XUNITS - 1) % (CK / 4);
+        return *reinterpret_cast<const float4*>(src + (unsigned)(xpix[it] * cs + coff + q * 4));
+    };
+    auto load_w = [&](int ch, int it) __attribute__((always_inline)) -> uint4 {
+        return *reinterpret_cast<const uint4*>(a.wp + (wbase[it] + (unsigned)(ch * a.n_row * 8)));
+    };
+    auto prefetch = [&](int ch) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < XITER; ++it) rx[it] = load_x(ch, it);
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) rw[it] = load_w(ch, it);
+    };
+    bf16x4 px[XITER][NP];
+    auto split_unit = [&](int it) __attribute__((always_inline)) {
+        const float4 r = xin[it] ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float xv[4] = {r.x, r.y, r.z, r.w};
+        bf16x4 ph_, pm, pl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __bf16 h_, m_, l_;
+            split3(xv[e], h_, m_, l_);
+            ph_[e] = h_; pm[e] = m_; pl[e] = l_;
+        }
+        px[it][0] = ph_;
+        if (NP > 1) px[it][NP > 1 ? 1 : 0] = pm;
+        if (NP > 2) px[it][NP > 2 ? 2 : 0] = pl;
+    };
+    // registers -> LDS image (ph & 1) and weight slots x6b_slot(ph, tap); each register is re-loaded for chunk nch at once
+    auto commit = [&](auto ph_c, int nch) __attribute__((always_inline)) {
+        constexpr int ph = decltype(ph_c)::value;
+        uint4* sXc = sX + (ph & 1) * XBUF;
+#pragma unroll
+        for (int it = 0; it < XITER; ++it) {
+            const int u = min(tid + it * 256, XUNITS - 1);
+            const int q = u % (CK / 4), pix = u / (CK / 4);
+            const int lpix = (pix / HTW) * HTWP + pix % HTW;
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[p * NPIXA + lpix]) + q * 8) = px[it][p];
+            rx[it] = load_x(nch, it);
+        }
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) {
+            const int u = min(tid + it * 256, WUNITS - 1);
+            const int n = u % TN, t = (u / TN) % KK, p = u / (TN * KK);
+            // x6b_slot(ph, t) without a table: t below the first displaced tap keeps its slot, the others move up
+            const int slot = ph == 0 ? t : ph == 1 ? (t < 8 ? t : 9) : ph == 2 ? (t < 7 ? t : (t == 7 ? 8 : 10)) : (t < 6 ? t : 2 * t - 5);
+            sW[p * WSLAB + slot * TN + n] = rw[it];
+            rw[it] = load_w(nch, it);
+        }
+    };
+
+    // One K-step: lane group g contracts block g = {image buffer, tap, weight slot} (compile-time per group).
+    auto kstep = [&](auto b0, auto b1, auto b2, auto b3, auto&& mid) __attribute__((always_inline)) {
+        constexpr int P1 = NP > 1 ? 1 : 0, P2 = NP > 2 ? 2 : 0;
+        // block code = buffer * 4096 + tap * 16 + slot
+        constexpr int c0 = decltype(b0)::value, c1 = decltype(b1)::value, c2 = decltype(b2)::value, c3 = decltype(b3)::value;
+        auto offA_of = [](int c) { return (c >> 12) * XBUF + (((c >> 4) & 15) / KS) * HTWP + ((c >> 4) & 15) % KS; };
+        auto offB_of = [](int c) { return (c & 15) * TN; };
+        const int offA = (g == 0 ? offA_of(c0) : g == 1 ? offA_of(c1) : g == 2 ? offA_of(c2) : offA_of(c3)) + l16;
+        const int offB = (g == 0 ? offB_of(c0) : g == 1 ? offB_of(c1) : g == 2 ? offB_of(c2) : offB_of(c3)) + l16;
+#pragma unroll
+        for (int chh = 0; chh < 2; ++chh) {
+            U4 bw[NP][2];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bw[p][j].u = sW[p * WSLAB + offB + 16 * (2 * chh + j)];
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                U4 ax[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) ax[p].u = sX[offA + p * NPIXA + (2 * wave + (pb >> 1)) * HTWP + 16 * (pb & 1)];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {  // (alternating the two chains instead: -1.6 %, same-box)
+                    f32x4 c = acc[pb][2 * chh + j];
+                    if (NP > 2) {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[P1][j].v, ax[P1].v, c, 0, 0, 0);  // mm
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0][j].v, ax[P2].v, c, 0, 0, 0);   // lh
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[P2][j].v, ax[0].v, c, 0, 0, 0);   // hl
+                    }
+                    if (NP > 1) {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0][j].v, ax[P1].v, c, 0, 0, 0);  // mh
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[P1][j].v, ax[0].v, c, 0, 0, 0);  // hm
+                    }
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0][j].v, ax[0].v, c, 0, 0, 0);  // hh
+                    acc[pb][2 * chh + j] = c;
+                }
+            }
+            if (chh == 0) mid();  // staging work of the next chunk, in the shadow of this K-step's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    auto nibble = [](const f32x4& v) -> unsigned {
+        return (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+    };
+    auto epilogue = [&](const TileInfo& ti) __attribute__((always_inline)) {
+        const int cq = ti.n0 + 4 * g;  // + 16 cb: first of this lane's four consecutive channels
+        f32x4 bq[4];
+        if (!DGRAD) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                bq[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.bias && cq + 16 * cb < N)
+                    bq[cb] = *reinterpret_cast<const f32x4*>(a.bias + (size_t)ti.b * a.bias_img_stride + cq + 16 * cb);
+            }
+        }
+        auto partner = [](float v) __attribute__((always_inline)) {  // value of lane ^ 1 (quad_perm [1, 0, 3, 2])
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+        };
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // 16-pixel half of the row; rows m = 0, 1 are pixel blocks h and 2 + h
+            const int gx = ti.tx0 + 16 * h + l16;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int gy = ti.ty0 + 2 * wave + m;
+                const bool pix_in = gy < a.H && gx < a.W;
+                // dword of (pixel, channel) in the punet_gate_dwords layout: (x % 32) + 32 * ((c % 8) / 4) = 16 h + l16 + 32 (g & 1)
+                const unsigned gd = (unsigned)(((((ti.b * a.H + gy) * tiles_x + (ti.tx0 / TW)) * ntn + (ti.n0 / TN)) << 6) +
+                                               16 * h + l16 + 32 * (g & 1));
+                const unsigned pbase = (unsigned)(((ti.b * a.H + gy) * a.W + gx) * N + cq);
+                unsigned gin = 0u, gout = 0u;
+                if (DGRAD && a.gate_bits && pix_in) gin = a.gate_bits[gd];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    const bool ok = pix_in && cq + 16 * cb < N;
+                    const int sh = 16 * (cb >> 1) + 8 * (cb & 1) + 4 * (g >> 1);  // this quad's nibble in its dword
+                    f32x4 v = acc[2 * m + h][cb];
+                    if (!DGRAD) {
+                        v += bq[cb];
+                        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    } else if (a.gate_bits) {
+                        const unsigned g4 = gin >> sh;
+                        v[0] = g4 & 1u ? v[0] : 0.f; v[1] = g4 & 2u ? v[1] : 0.f; v[2] = g4 & 4u ? v[2] : 0.f; v[3] = g4 & 8u ? v[3] : 0.f;
+                    } else if (a.mask) {
+                        if (ok) {
+                            const f32x4 gm = *reinterpret_cast<const f32x4*>(a.mask + pbase + 16 * cb);
+                            v[0] = gm[0] > 0.f ? v[0] : 0.f; v[1] = gm[1] > 0.f ? v[1] : 0.f;
+                            v[2] = gm[2] > 0.f ? v[2] : 0.f; v[3] = gm[3] > 0.f ? v[3] : 0.f;
+                        }
+                    }
+                    if (ok) {
+                        if (DGRAD && a.accumulate) v += *reinterpret_cast<const f32x4*>(a.y + pbase + 16 * cb);
+                        *reinterpret_cast<f32x4*>(a.y + pbase + 16 * cb) = v;
+                        if (!DGRAD) gout |= nibble(v) << sh;
+                    }
+                }
+                if (!DGRAD && a.gate_out) {  // uniform; the other half of the dword's bits sits in lane ^ 32
+                    const auto sw = __builtin_amdgcn_permlane32_swap(gout, gout, false, false);
+                    const unsigned full = sw[0] | sw[1];  // {own, partner} in either order
+                    if (g < 2 && pix_in) a.gate_out[gd] = full;
+                }
+            }
+            if (!DGRAD && a.pool_out) {  // uniform: AvgPool2d(2, 2) of the output, order ((y00 + y01) + y10) + y11
+                const int gy0 = ti.ty0 + 2 * wave;
+                const bool ok0 = gy0 < a.H && gx < a.W;
+                const unsigned qbase = (unsigned)(((ti.b * (a.H >> 1) + (gy0 >> 1)) * (a.W >> 1) + (gx >> 1)) * N + cq);
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    f32x4 v0 = acc[h][cb] + bq[cb], v1 = acc[2 + h][cb] + bq[cb], q;  // recomputed: no live copies of the rows
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (a.relu) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                        q[e] = (((v0[e] + partner(v0[e])) + v1[e]) + partner(v1[e])) * 0.25f;
+                    }
+                    if (!(lane & 1) && ok0 && cq + 16 * cb < N) *reinterpret_cast<f32x4*>(a.pool_out + qbase + 16 * cb) = q;
+                }
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (a.xcd_remap) tile = (tile & 7) * ((int)gridDim.x >> 3) + (tile >> 3);
+    if (tile >= a.ntiles) return;
+    int ch = 0;
+    TileInfo ti = decode(tile);
+    retarget(ti);
+    prefetch(0);
+#pragma unroll
+    for (int it = 0; it < XITER; ++it) split_unit(it);
+
+    // block codes: buffer * 4096 + tap * 16 + slot;  O(ph, t) = this chunk's tap t, P(ph, t) = the previous chunk's tap t
+#define X6B_O(ph, t) std::integral_constant<int, ((ph) & 1) * 4096 + (t) * 16 + x6b_slot(ph, t)>{}
+#define X6B_P(ph, t) std::integral_constant<int, (((ph) - 1) & 1) * 4096 + (t) * 16 + x6b_slot((ph) - 1, t)>{}
+    auto phase = [&](auto ph_c) __attribute__((always_inline)) -> bool {
+        constexpr int ph = decltype(ph_c)::value;
+        int nch = ch + 1, ntile = tile;
+        TileInfo nti = ti;
+        if (ph == 3 && nch == nchunks) {
+            nch = 0;
+            ntile = tile + (int)gridDim.x;
+            if (ntile < a.ntiles) nti = decode(ntile);
+        }
+        const bool has_next = ntile < a.ntiles;
+        if (!has_next) nch = ch;
+        if (ph == 3 && has_next && nch == 0) retarget(nti);
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(3);
+        commit(ph_c, nch);
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+        // lane-group pairs (0, 1) and (2, 3) take taps of one column (t, t + 3, t + 6 are 48 pixels apart) wherever the
+        // 9-tap arithmetic allows: 15 of the 18 pairs per 4 chunks; the other 3 cost their reads a second LDS cycle
+        auto s0 = [&]() __attribute__((always_inline)) { split_unit(0); };
+        auto s1 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int it = 1; it < XITER; ++it) split_unit(it);
+        };
+        auto s_ = []() {};
+        if (ph == 0) {
+            kstep(X6B_O(0, 0), X6B_O(0, 3), X6B_O(0, 1), X6B_O(0, 4), s0);
+            kstep(X6B_O(0, 2), X6B_O(0, 5), X6B_O(0, 6), X6B_O(0, 7), s1);
+        } else if (ph == 1) {
+            kstep(X6B_P(1, 8), X6B_O(1, 2), X6B_O(1, 0), X6B_O(1, 3), s0);
+            kstep(X6B_O(1, 1), X6B_O(1, 4), X6B_O(1, 5), X6B_O(1, 6), s1);
+        } else if (ph == 2) {
+            kstep(X6B_P(2, 7), X6B_O(2, 1), X6B_P(2, 8), X6B_O(2, 2), s0);
+            kstep(X6B_O(2, 0), X6B_O(2, 3), X6B_O(2, 4), X6B_O(2, 5), s1);
+        } else {
+            kstep(X6B_P(3, 6), X6B_O(3, 0), X6B_P(3, 7), X6B_O(3, 1), s0);
+            kstep(X6B_P(3, 8), X6B_O(3, 2), X6B_O(3, 3), X6B_O(3, 6), s1);
+            kstep(X6B_O(3, 4), X6B_O(3, 7), X6B_O(3, 5), X6B_O(3, 8), s_);
+        }
+        if (ph == 3 && ch == nchunks - 1) {  // no barrier: the epilogue touches no LDS, waves drain into it as they finish
+            epilogue(ti);
+            zero_acc();
+        }
+        tile = ntile;
+        ch = nch;
+        ti = nti;
+        return !has_next;
+    };
+#undef X6B_O
+#undef X6B_P
+    while (true) {
+        if (phase(std::integral_constant<int, 0>{})) break;
+        if (phase(std::integral_constant<int, 1>{})) break;
+        if (phase(std::integral_constant<int, 2>{})) break;
+        if (phase(std::integral_constant<int, 3>{})) break;
+    }
+}
+
 // planes[p][t'][k/8][n][8] <- split(w) ; mode 0 (forward): k = cin, n = cout, t' = t ;
 // mode 1 (input gradient): k = cout, n = cin, t' = kk-1-t (flipped taps)
 __global__ __launch_bounds__(256) void split_weights_x6_kernel(const float* __restrict__ w, __bf16* __restrict__ planes,
@@ -524,6 +870,7 @@ __global__ __launch_bounds__(256) void split_weights_x6_batch_kernel(const float
 }
 
 int g_x6_wg_per_cu = 2;
+bool g_x6_shape16 = [] { const char* e = getenv("PUNET_X6_MFMA_SHAPE"); return e && e[0] == '1' && e[1] == '6'; }();
 }  // namespace
 
 // shared with wgrad_x6.hip: bf16 planes per operand (3 = six products = the fp32-accurate parity arithmetic)
@@ -585,6 +932,12 @@ extern "C" int punet_conv3x3_x6_gated(const float* x0, int c0, const float* x1, 
                           gate_out, accumulate, relu, B, H, W, stream);
 }
 
+extern "C" int punet_set_x6_mfma_shape(int shape) {
+    PUNET_CHECK_ARG(shape == 16 || shape == 32, "punet_set_x6_mfma_shape: 32 (v_mfma_f32_32x32x16_bf16) or 16 (16x16x32), got %d", shape);
+    g_x6_shape16 = shape == 16;
+    return PUNET_OK;
+}
+
 extern "C" int punet_conv3x3_x6_pooled(const float* x0, int c0, const float* x1, int c1, const void* wplanes,
                                        long plane_stride, int n_row, int n_off, const float* bias, int bias_img_stride,
                                        float* y, int n_out, void* gate_out, float* pool_out, int relu, int B, int H, int W,
@@ -640,6 +993,14 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
     a.xcd_remap = grid % 8 == 0;  // same-process A/B: +0.5-0.8 % (the tensors of this workload fit the Infinity Cache)
     if (ksize == 1) {  // the two Fcomb layers: always the parity arithmetic (they are a rounding error of the step time)
         if (dgrad) conv3x3_x6_kernel<3, true, 1><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<3, false, 1><<<grid, 256, 0, st>>>(a);
+    } else if (g_x6_shape16 && (c0 + c1) % 32 == 0) {  // 16 x 16 x 32 MFMAs: four {tap, 8 channels} blocks per instruction
+        if (g_punet_x6_planes == 3) {
+            if (dgrad) conv3x3_x6b_kernel<3, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6b_kernel<3, false><<<grid, 256, 0, st>>>(a);
+        } else if (g_punet_x6_planes == 2) {
+            if (dgrad) conv3x3_x6b_kernel<2, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6b_kernel<2, false><<<grid, 256, 0, st>>>(a);
+        } else {
+            if (dgrad) conv3x3_x6b_kernel<1, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6b_kernel<1, false><<<grid, 256, 0, st>>>(a);
+        }
     } else if (g_punet_x6_planes == 3) {
         if (dgrad) conv3x3_x6_kernel<3, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<3, false><<<grid, 256, 0, st>>>(a);
     } else if (g_punet_x6_planes == 2) {

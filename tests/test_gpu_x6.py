@@ -21,6 +21,15 @@ def L():
     return _lib
 
 
+@pytest.fixture(params=[32, 16], ids=["mfma32x32x16", "mfma16x16x32"], autouse=True)
+def mfma_shape(request, L):
+    """Every test of this module runs with both MFMA shapes of the 3x3 kernels (16 = the experimental conv3x3_x6b_kernel,
+    taken by layers whose contracted channel count is a multiple of 32; process state of the library)."""
+    L.call("punet_set_x6_mfma_shape", request.param)
+    yield request.param
+    L.call("punet_set_x6_mfma_shape", 32)
+
+
 def S():
     return torch.cuda.current_stream().cuda_stream
 
@@ -257,3 +266,26 @@ def test_conv_x6_pooled_rejects_odd_sizes(L):
     with pytest.raises(RuntimeError, match="even H and W"):
         L.call("punet_conv3x3_x6_pooled", X.data_ptr(), 8, None, 0, pf.data_ptr(), 9 * 8 * 8, 8, 0, None, 0, y.data_ptr(), 8, None,
                q.data_ptr(), 1, 1, 5, 8, S())
+
+
+def test_whole_model_agrees_between_mfma_shapes(L):
+    """U-Net + prior + MC logits of a small PUNet with both kernels: the same function to fp32 rounding."""
+    from oracle import punet_oracle as O
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    nf = [32, 64, 96, 128]
+    m = ProbabilisticUnet(1, 1, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=False, device="cuda", seed=3)
+    x, x1, x2, y = O.synth_batch(2, 1, 64, 96, 5)
+    eps = torch.randn(4, 2, 6, generator=torch.Generator().manual_seed(1)).cuda()
+    outs = []
+    for shape in (32, 16):
+        L.call("punet_set_x6_mfma_shape", shape)
+        eng = m.engine
+        with torch.no_grad():
+            out = eng.forward_features(m.flat_params, eng.to_nhwc(x1))
+            z = eng.reparam(out["prior_muls"], eps)
+            ym, cz, lg = eng.sample(m.flat_params, out["features"], z, 0.9, 0.1, True, want_logits=True)
+        torch.cuda.synchronize()
+        outs.append((out["features"].t.clone(), lg.clone()))
+    (f32, l32), (f16, l16) = outs
+    assert (f32 - f16).abs().max().item() < 1e-5 * max(1.0, f32.abs().max().item())
+    assert (l32 - l16).abs().max().item() < 1e-4 * max(1.0, l32.abs().max().item())
