@@ -88,10 +88,11 @@ int punet_conv3x3_x6_gated(const float* x0, int c0, const float* x1, int c1, con
                            int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out,
                            const float* mask, const void* gate_bits, void* gate_out, int accumulate, int relu, int B,
                            int H, int W, void* stream);
-/* EXPERIMENTAL, off by default (process state; $PUNET_X6_MFMA_SHAPE=16 at load time): run the 3x3 forward / input-gradient
- * kernels of layers whose input channels are a multiple of 32 through v_mfma_f32_16x16x32_bf16 (conv3x3_x6b_kernel)
- * instead of v_mfma_f32_32x32x16_bf16.  Same results to rounding, same tests; measured at parity (+-1 %) with the
- * default kernel in round 1. */
+/* MFMA shape of the 3x3 forward / input-gradient kernels (process state; $PUNET_X6_MFMA_SHAPE=32 at load time selects the
+ * older kernel): 16 (default) = conv3x3_x6b_kernel on v_mfma_f32_16x16x32_bf16 for layers whose contracted channel count is
+ * a multiple of 32 - the energy-cheaper shape of a power-limited part, weights staged by LDS-DMA; 32 =
+ * conv3x3_x6_kernel on v_mfma_f32_32x32x16_bf16 (always used for other channel counts and for 1x1).  Same results to
+ * rounding; every kernel test runs with both. */
 int punet_set_x6_mfma_shape(int shape /* 32 | 16 */);
 /* Forward 3x3 convolution that ALSO writes AvgPool2d(2, 2) of its output (DownConvBlock = pool + 3 convs,
  * unet_blocks.py:17-24 / probabilistic_unet.py:54: the last conv of a block feeds the next block's pool): pool_out is

@@ -472,8 +472,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
 //   phase 3: {t6' t7' t8', t0 .. t8}
 // Left-over weight rows stay where they are: the slab has 12 slots and a chunk's rows go to the slots its predecessor's
 // left-overs do not occupy (x6b_slot).  A wave's 64 pixel x 64 channel tile is 4 x 4 sub-tiles; to stay inside the register
-// budget the weight fragments of two channel blocks are resident and the pixel fragments are streamed, i.e. read twice
-// per K-step (36 fragment reads per 96 MFMAs of 16 cycles instead of 24: measured cost about half of the shape's gain).
+// budget the weight planes are staged by LDS-DMA (no staging registers); then the weight fragments of all four channel
+// blocks stay resident during a K-step and the pixel fragments are streamed with one block of lookahead.
 // Output mapping: lane (l16 = lane % 16, g) holds pixel l16 of a 16-pixel block and channels 16 cb + 4 g .. + 3 - again a
 // 16-byte store per sub-tile straight from the accumulators.  Gate bits keep the punet_gate_dwords layout: a dword's 32
 // bits are held half by lane (l16, g) and half by lane (l16, g ^ 2) = lane ^ 32 (v_permlane32_swap joins them).
@@ -495,8 +495,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     constexpr int NPIXA = (HTH - 1) * HTWP + HTW;  // 466 units per plane
     constexpr int XUNITS = NPIX * (CK / 4);
     constexpr int XITER = (XUNITS + 255) / 256;
-    constexpr int WUNITS = NP * KK * TN;
-    constexpr int WITER = (WUNITS + 255) / 256;
     constexpr int WSLAB = 12 * TN;   // per plane: 12 slots of one {tap, 8 channels} row (64 output channels x 16 bytes)
     constexpr int XBUF = (NP * NPIXA + 15) / 16 * 16;  // one activation image (NP planes); two of them, by chunk parity
     constexpr int OPERANDS = 2 * XBUF + NP * WSLAB;
@@ -533,11 +531,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     zero_acc();
 
     // staging: identical to conv3x3_x6_kernel (see the comments there)
+    // Activations go through registers (they are split on the way); the weight planes are plain copies and go global -> LDS
+    // by LDS-DMA (global_load_lds_dwordx4: one wave-instruction = one {plane, tap} row of 64 output channels x 16 bytes),
+    // issued at the head of the commit of the chunk that needs them - no staging registers (the register-staged version
+    // kept 7 x 16 bytes + 7 offsets per thread across the K-steps, which is what the fragments of this kernel need).
     float4 rx[XITER];
-    uint4 rw[WITER];
     int xpix[XITER];
     bool xin[XITER];
-    unsigned wbase[WITER];
+    unsigned wlane = 0;  // this lane's output-channel offset (elements) inside a weight row
     auto retarget = [&](const TileInfo& ti) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < XITER; ++it) {
@@ -548,13 +549,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
             xin[it] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             xpix[it] = (ti.b * a.H + min(max(gy, 0), a.H - 1)) * a.W + min(max(gx, 0), a.W - 1);
         }
-#pragma unroll
-        for (int it = 0; it < WITER; ++it) {
-            const int u = min(tid + it * 256, WUNITS - 1);
-            const int n = u % TN, t = (u / TN) % KK, p = u / (TN * KK);
-            const int nc = min(ti.n0 + n, N - 1);
-            wbase[it] = (unsigned)(p * (int)a.plane_stride + (t * nchunks * a.n_row + a.n_off + nc) * 8);
-        }
+        wlane = (unsigned)((a.n_off + min(ti.n0 + lane, N - 1)) * 8);  // columns beyond N copy column N - 1 (never stored)
     };
     auto load_x = [&](int ch, int it) __attribute__((always_inline)) -> float4 {
         const int kbase = ch * CK;
@@ -563,14 +558,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         const int q = min(tid + it * 256, XUNITS - 1) % (CK / 4);
         return *reinterpret_cast<const float4*>(src + (unsigned)(xpix[it] * cs + coff + q * 4));
     };
-    auto load_w = [&](int ch, int it) __attribute__((always_inline)) -> uint4 {
-        return *reinterpret_cast<const uint4*>(a.wp + (wbase[it] + (unsigned)(ch * a.n_row * 8)));
-    };
     auto prefetch = [&](int ch) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < XITER; ++it) rx[it] = load_x(ch, it);
-#pragma unroll
-        for (int it = 0; it < WITER; ++it) rw[it] = load_w(ch, it);
     };
     bf16x4 px[XITER][NP];
     auto split_unit = [&](int it) __attribute__((always_inline)) {
@@ -587,9 +577,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         if (NP > 1) px[it][NP > 1 ? 1 : 0] = pm;
         if (NP > 2) px[it][NP > 2 ? 2 : 0] = pl;
     };
-    // registers -> LDS image (ph & 1) and weight slots x6b_slot(ph, tap); each register is re-loaded for chunk nch at once
-    auto commit = [&](auto ph_c, int nch) __attribute__((always_inline)) {
+    // chunk `ch`: weight rows -> slots x6b_slot(ph, tap) by LDS-DMA (first, so that a counted vmcnt can leave the younger
+    // activation loads in flight), packed activation planes -> LDS image (ph & 1), staging registers re-loaded for chunk nch
+    auto commit = [&](auto ph_c, int cch, int nch) __attribute__((always_inline)) {
         constexpr int ph = decltype(ph_c)::value;
+        constexpr int WROWS = NP * KK;
+        // 1. packed activation planes -> LDS image (ph & 1): before any DMA is pending (the compiler orders a ds_write
+        //    behind a pending LDS-DMA with vmcnt(0))
         uint4* sXc = sX + (ph & 1) * XBUF;
 #pragma unroll
         for (int it = 0; it < XITER; ++it) {
@@ -599,17 +593,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p)
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(&sXc[p * NPIXA + lpix]) + q * 8) = px[it][p];
-            rx[it] = load_x(nch, it);
         }
+        // 2. this chunk's weight rows -> slots x6b_slot(ph, tap) by LDS-DMA
 #pragma unroll
-        for (int it = 0; it < WITER; ++it) {
-            const int u = min(tid + it * 256, WUNITS - 1);
-            const int n = u % TN, t = (u / TN) % KK, p = u / (TN * KK);
-            // x6b_slot(ph, t) without a table: t below the first displaced tap keeps its slot, the others move up
-            const int slot = ph == 0 ? t : ph == 1 ? (t < 8 ? t : 9) : ph == 2 ? (t < 7 ? t : (t == 7 ? 8 : 10)) : (t < 6 ? t : 2 * t - 5);
-            sW[p * WSLAB + slot * TN + n] = rw[it];
-            rw[it] = load_w(nch, it);
+        for (int i = 0; i < (WROWS + 3) / 4; ++i) {
+            const int r = wave + 4 * i;  // wave-uniform
+            if (r < WROWS) {
+                const int p = r / KK, t = r % KK;
+                const int slot = ph == 0 ? t : ph == 1 ? (t < 8 ? t : 9) : ph == 2 ? (t < 7 ? t : (t == 7 ? 8 : 10)) : (t < 6 ? t : 2 * t - 5);
+                const __bf16* src = a.wp + ((size_t)p * a.plane_stride + (size_t)(t * nchunks + cch) * a.n_row * 8) + wlane;
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(sW + p * WSLAB + slot * TN), 16, 0, 0);
+            }
         }
+        // 3. the staging registers re-loaded for chunk nch: the youngest vector-memory operations, a counted vmcnt leaves
+        //    them in flight
+#pragma unroll
+        for (int it = 0; it < XITER; ++it) rx[it] = load_x(nch, it);
     };
 
     // One K-step: lane group g contracts block g = {image buffer, tap, weight slot} (compile-time per group).
@@ -621,35 +620,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         auto offB_of = [](int c) { return (c & 15) * TN; };
         const int offA = (g == 0 ? offA_of(c0) : g == 1 ? offA_of(c1) : g == 2 ? offA_of(c2) : offA_of(c3)) + l16;
         const int offB = (g == 0 ? offB_of(c0) : g == 1 ? offB_of(c1) : g == 2 ? offB_of(c2) : offB_of(c3)) + l16;
+        // all four channel blocks' weight fragments resident (48 registers), pixel fragments streamed with one block of
+        // lookahead (12 + 12): every fragment is read once per K-step (24 reads per 96 MFMAs, as in the 32 x 32 x 16 kernel)
+        U4 bw[NP][4];
 #pragma unroll
-        for (int chh = 0; chh < 2; ++chh) {
-            U4 bw[NP][2];
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
+            for (int cb = 0; cb < 4; ++cb) bw[p][cb].u = sW[p * WSLAB + offB + 16 * cb];
+        U4 ax[2][NP];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bw[p][j].u = sW[p * WSLAB + offB + 16 * (2 * chh + j)];
+        for (int p = 0; p < NP; ++p) ax[0][p].u = sX[offA + p * NPIXA + (2 * wave) * HTWP];
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb) {
-                U4 ax[NP];
+        for (int pb = 0; pb < 4; ++pb) {
+            if (pb < 3) {
 #pragma unroll
-                for (int p = 0; p < NP; ++p) ax[p].u = sX[offA + p * NPIXA + (2 * wave + (pb >> 1)) * HTWP + 16 * (pb & 1)];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {  // (alternating the two chains instead: -1.6 %, same-box)
-                    f32x4 c = acc[pb][2 * chh + j];
-                    if (NP > 2) {
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[P1][j].v, ax[P1].v, c, 0, 0, 0);  // mm
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0][j].v, ax[P2].v, c, 0, 0, 0);   // lh
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[P2][j].v, ax[0].v, c, 0, 0, 0);   // hl
-                    }
-                    if (NP > 1) {
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0][j].v, ax[P1].v, c, 0, 0, 0);  // mh
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[P1][j].v, ax[0].v, c, 0, 0, 0);  // hm
-                    }
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0][j].v, ax[0].v, c, 0, 0, 0);  // hh
-                    acc[pb][2 * chh + j] = c;
-                }
+                for (int p = 0; p < NP; ++p)
+                    ax[(pb + 1) & 1][p].u = sX[offA + p * NPIXA + (2 * wave + ((pb + 1) >> 1)) * HTWP + 16 * ((pb + 1) & 1)];
             }
-            if (chh == 0) mid();  // staging work of the next chunk, in the shadow of this K-step's MFMAs
+            U4(&A)[NP] = ax[pb & 1];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                f32x4 c = acc[pb][cb];
+                if (NP > 2) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[P1][cb].v, A[P1].v, c, 0, 0, 0);  // mm
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0][cb].v, A[P2].v, c, 0, 0, 0);   // lh
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[P2][cb].v, A[0].v, c, 0, 0, 0);   // hl
+                }
+                if (NP > 1) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0][cb].v, A[P1].v, c, 0, 0, 0);  // mh
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[P1][cb].v, A[0].v, c, 0, 0, 0);  // hm
+                }
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0][cb].v, A[0].v, c, 0, 0, 0);  // hh
+                acc[pb][cb] = c;
+            }
+            if (pb == 1) mid();  // staging work of the next chunk, in the shadow of this K-step's MFMAs
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -759,9 +763,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         if (ph == 3 && has_next && nch == 0) retarget(nti);
         __syncthreads();
         __builtin_amdgcn_s_setprio(3);
-        commit(ph_c, nch);
+        commit(ph_c, ch, nch);
         __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
+        // the weight DMAs (older) must have landed, the XITER activation loads issued after them may stay in flight;
+        // a __syncthreads() here would drain them too (its fence waits vmcnt(0) while an LDS-DMA is pending)
+        __builtin_amdgcn_s_waitcnt(XITER | (7 << 4) | (0 << 8));  // vmcnt(XITER) expcnt(7) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
         // lane-group pairs (0, 1) and (2, 3) take taps of one column (t, t + 3, t + 6 are 48 pixels apart) wherever the
         // 9-tap arithmetic allows: 15 of the 18 pairs per 4 chunks; the other 3 cost their reads a second LDS cycle
         auto s0 = [&]() __attribute__((always_inline)) { split_unit(0); };
@@ -870,7 +877,7 @@ __global__ __launch_bounds__(256) void split_weights_x6_batch_kernel(const float
 }
 
 int g_x6_wg_per_cu = 2;
-bool g_x6_shape16 = [] { const char* e = getenv("PUNET_X6_MFMA_SHAPE"); return e && e[0] == '1' && e[1] == '6'; }();
+bool g_x6_shape16 = [] { const char* e = getenv("PUNET_X6_MFMA_SHAPE"); return !(e && e[0] == '3' && e[1] == '2'); }();  // default 16
 }  // namespace
 
 // shared with wgrad_x6.hip: bf16 planes per operand (3 = six products = the fp32-accurate parity arithmetic)

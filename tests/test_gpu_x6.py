@@ -27,7 +27,7 @@ def mfma_shape(request, L):
     taken by layers whose contracted channel count is a multiple of 32; process state of the library)."""
     L.call("punet_set_x6_mfma_shape", request.param)
     yield request.param
-    L.call("punet_set_x6_mfma_shape", 32)
+    L.call("punet_set_x6_mfma_shape", 16)  # the library default
 
 
 def S():
