@@ -248,7 +248,7 @@ def main():
             traffic, traffic_note = None, "not collected"
             try:  # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.py)
                 if a.workload == "mean_teacher" and (B, H, W, N) == (4, 512, 512, 8) and eng.conv_mode in ("x6", "f32"):
-                    fn, key = {"x6": ("pmc_hbm_traffic_x6.json", "conv3x3_x6_kernel<3, false, 3>"),
+                    fn, key = {"x6": ("pmc_hbm_traffic_x6.json", "conv3x3_x6b_kernel<3, false>"),
                                "f32": ("pmc_hbm_traffic.json", "conv_mfma_kernel<3, false>")}[eng.conv_mode]
                     pm = json.load(open(os.path.join(ROOT, "profiles", "r01", fn)))
                     traffic = round(pm["kernels"][key]["hbm_bytes_per_launch"])
@@ -264,7 +264,8 @@ def main():
                     # n bf16 MFMAs per product: the roofline of THIS arithmetic is the bf16 dense peak / n
                     n = {"x6": 6, "x3": 3, "bf16": 1}[eng.conv_mode]
                     peak = BF16_MFMA_PEAK_TFLOPS / n
-                    kname = f"conv3x3_x6_kernel<{(n + 1) // 2 if n > 1 else 1} planes> (3x3 NHWC direct conv forward on BF16 MFMA)"
+                    kname = (f"conv3x3_x6b_kernel<{(n + 1) // 2 if n > 1 else 1} planes> (3x3 NHWC direct conv forward, "
+                             f"v_mfma_f32_16x16x32_bf16; conv3x3_x6_kernel for channel counts that are not multiples of 32)")
                     pnote = (f"bf16 dense MFMA peak {BF16_MFMA_PEAK_TFLOPS} TFLOP/s / {n} MFMAs per product = {peak:.1f} TFLOP/s of "
                              f"algorithmic work; executed bf16 MFMA rate = {n} x achieved = {n * ach:.0f} TFLOP/s "
                              f"({n * ach / BF16_MFMA_PEAK_TFLOPS:.3f} of the bf16 peak; a register-only MFMA loop with "

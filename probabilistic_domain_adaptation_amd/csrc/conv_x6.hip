@@ -1000,13 +1000,13 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
     a.xcd_remap = grid % 8 == 0;  // same-process A/B: +0.5-0.8 % (the tensors of this workload fit the Infinity Cache)
     if (ksize == 1) {  // the two Fcomb layers: always the parity arithmetic (they are a rounding error of the step time)
         if (dgrad) conv3x3_x6_kernel<3, true, 1><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<3, false, 1><<<grid, 256, 0, st>>>(a);
-    } else if (g_x6_shape16 && (c0 + c1) % 32 == 0) {  // 16 x 16 x 32 MFMAs: four {tap, 8 channels} blocks per instruction
+    } else if (g_x6_shape16 && (c0 + c1) % 32 == 0 && g_punet_x6_planes >= 2) {
+        // 16 x 16 x 32 MFMAs: four {tap, 8 channels} blocks per instruction.  (Not for the one-plane fast mode: that one is
+        // bound by its staging, not by the matrix cores, and measured 15 % slower through this kernel.)
         if (g_punet_x6_planes == 3) {
             if (dgrad) conv3x3_x6b_kernel<3, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6b_kernel<3, false><<<grid, 256, 0, st>>>(a);
-        } else if (g_punet_x6_planes == 2) {
-            if (dgrad) conv3x3_x6b_kernel<2, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6b_kernel<2, false><<<grid, 256, 0, st>>>(a);
         } else {
-            if (dgrad) conv3x3_x6b_kernel<1, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6b_kernel<1, false><<<grid, 256, 0, st>>>(a);
+            if (dgrad) conv3x3_x6b_kernel<2, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6b_kernel<2, false><<<grid, 256, 0, st>>>(a);
         }
     } else if (g_punet_x6_planes == 3) {
         if (dgrad) conv3x3_x6_kernel<3, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<3, false><<<grid, 256, 0, st>>>(a);
