@@ -165,6 +165,29 @@ int punet_latent_kl(const float* muls_q, const float* muls_p, float* kl, int B, 
 int punet_latent_kl_bwd(const float* muls_q, const float* muls_p, const float* eps, const float* dz, float coef,
                         float* d_muls_q, float* d_muls_p, int B, int L, void* stream);
 
+/* per-image KL kl_rows[B] (nullable) and its batch mean kl_mean[0] (probabilistic_unet.py:324-339,351): z == NULL -> analytic
+ * (torch.distributions.kl, :332); z[B][L] != NULL -> the single-sample estimate log q(z) - log p(z) (:334-338). */
+int punet_latent_kl_rows(const float* muls_q, const float* muls_p, const float* z, float* kl_rows, float* kl_mean, int B,
+                         int L, void* stream);
+/* punet_latent_kl_bwd with elbo()'s two options (probabilistic_unet.py:341-358): kl_sampled != 0 <-> analytic_kl=False
+ * (estimate at z = mu_q + sigma_q * eps); z_is_mean != 0 <-> reconstruct_posterior_mean=True (dz reaches mu_q only). */
+int punet_latent_kl_bwd_ex(const float* muls_q, const float* muls_p, const float* eps, const float* dz, float coef,
+                           int kl_sampled, int z_is_mean, float* d_muls_q, float* d_muls_p, int B, int L, void* stream);
+/* loc[b][d] = mu, scale[b][d] = exp(log_sigma): the Normal(loc, scale) the reference stores (probabilistic_unet.py:136-141) */
+int punet_latent_split(const float* muls, float* loc, float* scale, int B, int L, void* stream);
+
+/* ---- layout / concat helpers at the API edge.  torch.cat([patch, segm], 1) of the posterior's input
+ *      (probabilistic_unet.py:115-118) on NHWC tensors with ca, cb channels; NCHW <-> NHWC of the caller's patches. */
+int punet_concat_nhwc(const float* a, int ca, const float* b, int cb, float* out, long P, void* stream);
+int punet_nchw_to_nhwc(const float* x, float* y, int B, int C, long HW, void* stream);
+int punet_nhwc_to_nchw(const float* x, float* y, int B, int C, long HW, void* stream);
+
+/* ---- FixMatch distribution alignment (fixmatch_trainer.py:77-84): target class frequencies of (y >= 0.5) counted exactly
+ *      on the device (no torch.unique host sync), ratio = source / target, out = clip(y * ratio[class], 0, 1);
+ *      ratio[2] (nullable) receives the two ratios; count_ws = 8 bytes of scratch. */
+int punet_align_distribution(const float* y, const float* source_distribution, float* out, float* ratio,
+                             unsigned long long* count_ws, long P, void* stream);
+
 /* ---- Fcomb pieces (probabilistic_unet.py:200-214) used by the single-sample training path */
 int punet_fcomb_zbias(const float* z, const float* w1, const float* b1, float* zb, int NB, int L, int CH, void* stream);
 /* backward of the folded z term: S[b][CH] = per-image column sums of dZ1 (punet_chan_sum) */

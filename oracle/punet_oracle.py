@@ -16,8 +16,8 @@ by ``tests/golden/gen_golden.py`` (in-memory stubs for the absent ``torch_em`` /
 ``torchvision``; in-memory channel fix for the ``input_dim`` bug at
 ``probabilistic_unet.py:50-51`` / ``unet.py:27-28``).  The committed fixtures in
 ``tests/golden/*.npz`` hold the reference's outputs; ``tests/test_oracle_golden.py``
-checks this file against them on every run, and ``tests/test_oracle_vs_reference.py``
-re-checks against a live import when ``/root/reference`` exists.
+checks this file against them on every run (the generator itself asserts oracle == live reference
+while it writes them, so re-running ``gen_golden.py`` in the build container is the live re-check).
 
 Parity status: BCE criterion (``rl_swap=False``) fully pinned.  The Dice
 criterion (``rl_swap=True``) lives in the un-vendored, un-pinned third-party
@@ -313,13 +313,27 @@ def punet_sample(P: Params, cfg: PUNetConfig, st, eps: torch.Tensor) -> torch.Te
     return fcomb(P, st["features"], mu + sig * eps, cfg.no_convs_fcomb)
 
 
-def punet_elbo(P: Params, cfg: PUNetConfig, st, segm, consm, eps: torch.Tensor):
-    """ProbabilisticUnet.elbo (probabilistic_unet.py:341-371).  Returns (elbo, dict of scalars/tensors)."""
+def kl_sampled(mu_q, sig_q, mu_p, sig_p, z) -> torch.Tensor:
+    """kl_divergence(analytic=False) (probabilistic_unet.py:334-338): log q(z) - log p(z) of the two
+    Independent(Normal) -> [B] (Normal.log_prob = -(z-mu)^2/(2 var) - log sigma - log sqrt(2 pi))."""
+    def lp(mu, sig):
+        return (-((z - mu) ** 2) / (2 * sig ** 2) - sig.log() - math.log(math.sqrt(2 * math.pi))).sum(-1)
+    return lp(mu_q, sig_q) - lp(mu_p, sig_p)
+
+
+def punet_elbo(P: Params, cfg: PUNetConfig, st, segm, consm, eps: torch.Tensor, analytic_kl: bool = True,
+               reconstruct_posterior_mean: bool = False):
+    """ProbabilisticUnet.elbo (probabilistic_unet.py:341-371).  Returns (elbo, dict of scalars/tensors).
+    reconstruct_posterior_mean: the reference reads `.loc` of an Independent there (:318), which raises
+    AttributeError on torch 2.x; the evident intent (base_dist.loc = mu_q) is what this restates."""
     mu_q, sig_q = st["posterior"]
     mu_p, sig_p = st["prior"]
     z = mu_q + sig_q * eps  # :349 rsample
-    kl = kl_diag_gaussians(mu_q, sig_q, mu_p, sig_p).mean()  # :351-353
-    recon = fcomb(P, st["features"], z, cfg.no_convs_fcomb)  # :356-358
+    if analytic_kl:
+        kl = kl_diag_gaussians(mu_q, sig_q, mu_p, sig_p).mean()  # :351-353
+    else:
+        kl = kl_sampled(mu_q, sig_q, mu_p, sig_p, z).mean()  # :334-338
+    recon = fcomb(P, st["features"], mu_q if reconstruct_posterior_mean else z, cfg.no_convs_fcomb)  # :356-358
     if cfg.consensus_masking and consm is not None:
         lg, tg = recon * consm, segm * consm  # :363-364 (masks the LOGITS)
     else:
@@ -340,11 +354,13 @@ def l2_regularisation(P: Params, names: Sequence[str]) -> torch.Tensor:
     return sum(P[n].norm(2) for n in names)
 
 
-def training_loss(P: Params, cfg: PUNetConfig, x, y, consm, eps, reg_weight: float = 1e-5, taps=None):
+def training_loss(P: Params, cfg: PUNetConfig, x, y, consm, eps, reg_weight: float = 1e-5, taps=None, target=None,
+                  analytic_kl: bool = True, reconstruct_posterior_mean: bool = False):
     """Body shared by all trainers (e.g. mean_teacher_trainer.py:113-117):
-    forward(x, y, True); elbo(y, z); loss = -elbo + 1e-5 * (l2(post) + l2(prior) + l2(fcomb.layers))."""
+    forward(x, y, True); elbo(y, z); loss = -elbo + 1e-5 * (l2(post) + l2(prior) + l2(fcomb.layers)).
+    target: the segm handed to elbo() when it differs from forward()'s (the API allows it; no trainer does it)."""
     st = punet_forward(P, cfg, x, y, True, taps)
-    elbo, aux = punet_elbo(P, cfg, st, y, consm, eps)
+    elbo, aux = punet_elbo(P, cfg, st, y if target is None else target, consm, eps, analytic_kl, reconstruct_posterior_mean)
     reg = l2_regularisation(P, l2_reg_param_names(P))
     loss = -elbo + reg_weight * reg
     aux.update(reg=reg, loss=loss, state=st)
@@ -499,6 +515,100 @@ def mc_prediction(P: Params, cfg: PUNetConfig, raw, eps_n):
         st = punet_forward(P, cfg, raw, None, False)
         n = eps_n.shape[0]
         return torch.stack([torch.sigmoid(punet_sample(P, cfg, st, eps_n[i])) for i in range(n)], 0).sum(0) / n
+
+
+def punet_validate(P: Params, cfg: PUNetConfig, batches, eps_elbo, eps_samples, reg_weight: float = 1e-5):
+    """PUNetTrainer._validate_impl (punet_trainer.py:52-97) -> (metric_val, loss_val): per batch the no-grad training
+    loss, then the mean of 8 sigmoid(sample(testing=False)) (:70-78) and 1 - dice_score against y (:79-82), averaged over
+    the loader (:88-90).  eps_elbo[i]: [B, L]; eps_samples[i]: [n, B, L]."""
+    metric = loss_val = 0.0
+    with torch.no_grad():
+        for (x, y), e1, en in zip(batches, eps_elbo, eps_samples):
+            loss, aux = training_loss(P, cfg, x, y, None, e1, reg_weight)
+            st = aux["state"]
+            pred = torch.stack([torch.sigmoid(punet_sample(P, cfg, st, en[i])) for i in range(en.shape[0])], 0).sum(0) / en.shape[0]
+            metric += 1.0 - dice_score(pred.numpy().squeeze(), y.numpy().squeeze())
+            loss_val += loss.item()
+    return metric / len(batches), loss_val / len(batches)
+
+
+def mean_teacher_validate(P_s: Params, P_t: Params, cfg: PUNetConfig, batches, eps_teacher, eps_elbo, eps_model,
+                          masking: bool, reg_weight: float = 1e-5):
+    """MeanTeacherTrainer._validate_impl (mean_teacher_trainer.py:142-191) -> dict(metric, loss, gt_metric, samples, y, z)
+    (samples / y / z of the last batch): teacher pseudo-labels on x1 (:153), no-grad student loss on x2 with elbo(y, z)
+    (:157-161), sample_from_model (:163, :90-93), 1 - dice vs the pseudo-label (:164-166) and vs the true gt (:168-170)."""
+    metric = loss_val = gt_metric = 0.0
+    out = {}
+    with torch.no_grad():
+        for (x, x1, x2, gt), et, e1, em in zip(batches, eps_teacher, eps_elbo, eps_model):
+            y, z = sample_consensus(P_t, cfg, x1, et, masking=masking)
+            loss, aux = training_loss(P_s, cfg, x2, y, z, e1, reg_weight)
+            st = aux["state"]
+            samples = torch.stack([torch.sigmoid(punet_sample(P_s, cfg, st, em[i])) for i in range(em.shape[0])], 0).sum(0) / em.shape[0]
+            pred = samples.numpy().squeeze()
+            metric += 1.0 - dice_score(pred, y.numpy().squeeze())
+            gt_metric += 1.0 - dice_score(pred, gt.numpy().squeeze())
+            loss_val += loss.item()
+            out.update(samples=samples, y=y, z=z)
+    n = len(batches)
+    out.update(metric=metric / n, loss=loss_val / n, gt_metric=gt_metric / n)
+    return out
+
+
+def standardize_np(raw: np.ndarray, eps: float = 1e-7) -> np.ndarray:
+    """[RECALLED - parity unpinned] torch_em.transform.raw.standardize with default arguments: float32,
+    (raw - mean) / (std + eps) over the whole array (population std)."""
+    raw = raw.astype("float32")
+    return (raw - raw.mean()) / (raw.std() + eps)
+
+
+def halo_tiles(shape, block_shape, halo):
+    """[RECALLED - parity unpinned] the blocking of torch_em.util.prediction.predict_with_halo (called at
+    punet_predictions.py:41-49 with block (384, 384), halo (64, 64)): blocks in row-major order; every block is read as
+    the FULL block_shape + 2 * halo window around its origin and the part of the window outside the image is filled by
+    np.pad(mode="reflect") of the part inside.  Yields (y0, y1, x0, x1) of the block clipped to the image."""
+    for y0 in range(0, shape[0], block_shape[0]):
+        for x0 in range(0, shape[1], block_shape[1]):
+            yield y0, min(y0 + block_shape[0], shape[0]), x0, min(x0 + block_shape[1], shape[1])
+
+
+def load_halo_block(image: np.ndarray, y0, x0, block_shape, halo) -> np.ndarray:
+    """[RECALLED] one outer tile of predict_with_halo: clip the window to the image, reflect-pad what is missing."""
+    H, W = image.shape
+    ys, ye = y0 - halo[0], y0 + block_shape[0] + halo[0]
+    xs, xe = x0 - halo[1], x0 + block_shape[1] + halo[1]
+    data = image[max(ys, 0):min(ye, H), max(xs, 0):min(xe, W)]
+    pad = ((max(-ys, 0), max(ye - H, 0)), (max(-xs, 0), max(xe - W, 0)))
+    if any(p for pr in pad for p in pr):
+        data = np.pad(data, pad, mode="reflect")
+    return data
+
+
+def tiled_prediction(P: Params, cfg: PUNetConfig, image: np.ndarray, eps_tiles, block_shape=(384, 384), halo=(64, 64)):
+    """punet_prediction's tiling=True branch (punet_predictions.py:40-50) with the recalled predict_with_halo semantics:
+    per tile standardise (its default preprocess), `_custom_punet_prediction` (:29-33), crop the halo, write the block.
+    eps_tiles[t]: [N, 1, L] draws of tile t (row-major block order)."""
+    out = np.zeros(image.shape, dtype="float32")
+    for t, (y0, y1, x0, x1) in enumerate(halo_tiles(image.shape, block_shape, halo)):
+        tile = standardize_np(load_halo_block(image, y0, x0, block_shape, halo))
+        pred = mc_prediction(P, cfg, torch.from_numpy(tile)[None, None], eps_tiles[t])[0, 0].numpy()
+        out[y0:y1, x0:x1] = pred[halo[0]:halo[0] + (y1 - y0), halo[1]:halo[1] + (x1 - x0)]
+    return out
+
+
+def pseudo_prediction(P: Params, cfg: PUNetConfig, image: np.ndarray, eps_n, upper=0.9, lower=0.1):
+    """punet_pseudo_prediction's per-image body (punet_predictions.py:103-124): standardise the whole image, forward, N
+    sigmoid(sample(testing=True)); mean -> float32 map; per-sample numpy mask (s >= upper) + (s <= lower), consensus =
+    (sum / N == 1) -> uint8."""
+    with torch.no_grad():
+        patch = torch.from_numpy(standardize_np(image))[None, None]
+        st = punet_forward(P, cfg, patch, None, False)
+        n = eps_n.shape[0]
+        samples = [torch.sigmoid(punet_sample(P, cfg, st, eps_n[i])) for i in range(n)]
+        mean = (torch.stack(samples, 0).sum(0) / n).numpy().squeeze()
+        masks = [(s.numpy().squeeze() >= upper) + (s.numpy().squeeze() <= lower) for s in samples]
+        cons = np.stack(masks, 0).sum(0) / n
+        return mean, np.where(cons == 1, 1, 0).astype("uint8")
 
 
 # ----------------------------------------------------------------------------------------------------------------------

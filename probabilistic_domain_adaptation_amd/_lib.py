@@ -54,6 +54,13 @@ _SIGS = {
     "punet_reparam": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "punet_latent_kl": (_i, [_p, _p, _p, _i, _i, _p]),
     "punet_latent_kl_bwd": (_i, [_p, _p, _p, _p, _f, _p, _p, _i, _i, _p]),
+    "punet_latent_kl_rows": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
+    "punet_latent_kl_bwd_ex": (_i, [_p, _p, _p, _p, _f, _i, _i, _p, _p, _i, _i, _p]),
+    "punet_latent_split": (_i, [_p, _p, _p, _i, _i, _p]),
+    "punet_concat_nhwc": (_i, [_p, _i, _p, _i, _p, _l, _p]),
+    "punet_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _l, _p]),
+    "punet_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _l, _p]),
+    "punet_align_distribution": (_i, [_p, _p, _p, _p, _p, _l, _p]),
     "punet_fcomb_zbias": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "punet_fcomb_z_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "punet_dot_bias": (_i, [_p, _p, _p, _p, _l, _i, _p]),

@@ -355,6 +355,146 @@ __global__ void latent_kl_bwd_kernel(const float* __restrict__ mq, const float* 
     }
 }
 
+// per-image KL (probabilistic_unet.py:324-339): analytic (z == NULL; torch.distributions.kl, :332) or the single-sample
+// estimate log q(z) - log p(z) of :334-338 (the -log sqrt(2 pi) terms of the two log_probs cancel); kl_mean = batch mean
+// (:351).  One thread per image, images summed in order (B is the per-GPU batch).
+__global__ void latent_kl_rows_kernel(const float* __restrict__ mq, const float* __restrict__ mp, const float* __restrict__ z,
+                                      float* __restrict__ kl_rows, float* __restrict__ kl_mean, int B, int L) {
+    __shared__ float sh[256];
+    for (int b0 = 0; b0 < B; b0 += 256) {
+        const int b = b0 + threadIdx.x;
+        if (b < B) {
+            float kb = 0.f;
+            if (z == nullptr) {
+                for (int d = 0; d < L; ++d) {
+                    const float muq = mq[b * 2 * L + d], sq = expf(mq[b * 2 * L + L + d]);
+                    const float mup = mp[b * 2 * L + d], sp = expf(mp[b * 2 * L + L + d]);
+                    const float r = sq / sp, vr = r * r;
+                    const float t = (muq - mup) / sp, t1 = t * t;
+                    kb += 0.5f * (vr + t1 - 1.f - logf(vr));
+                }
+            } else {
+                float lq = 0.f, lp = 0.f;  // log_prob sums as Normal.log_prob writes them (minus the common constant)
+                for (int d = 0; d < L; ++d) {
+                    const float zz = z[b * L + d];
+                    const float muq = mq[b * 2 * L + d], lsq = mq[b * 2 * L + L + d], sq = expf(lsq);
+                    const float mup = mp[b * 2 * L + d], lsp = mp[b * 2 * L + L + d], sp = expf(lsp);
+                    lq += -((zz - muq) * (zz - muq)) / (2.f * sq * sq) - lsq;
+                    lp += -((zz - mup) * (zz - mup)) / (2.f * sp * sp) - lsp;
+                }
+                kb = lq - lp;
+            }
+            if (kl_rows) kl_rows[b] = kb;
+            sh[threadIdx.x] = kb;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = b0 == 0 ? 0.f : kl_mean[0];
+            const int nb = B - b0 < 256 ? B - b0 : 256;
+            for (int i = 0; i < nb; ++i) tot += sh[i];
+            kl_mean[0] = (b0 + 256 >= B) ? tot / (float)B : tot;
+        }
+        __syncthreads();
+    }
+}
+
+// latent_kl_bwd with the two options of elbo() (probabilistic_unet.py:341-358): kl_sampled != 0: the KL term is the
+// single-sample estimate at z = mu_q + s_q * eps (analytic_kl=False); z_is_mean != 0: Fcomb saw mu_q instead of z
+// (reconstruct_posterior_mean=True), so the upstream dz reaches mu_q only.
+__global__ void latent_kl_bwd_ex_kernel(const float* __restrict__ mq, const float* __restrict__ mp, const float* __restrict__ eps,
+                                        const float* __restrict__ dz, float coef, int kl_sampled, int z_is_mean,
+                                        float* __restrict__ dq, float* __restrict__ dp, int B, int L) {
+    const int n = B * L;
+    GRID_STRIDE(i, (size_t)n) {
+        const int d = (int)(i % L), b = (int)(i / L);
+        const float muq = mq[b * 2 * L + d], sq = expf(mq[b * 2 * L + L + d]);
+        const float mup = mp[b * 2 * L + d], sp = expf(mp[b * 2 * L + L + d]);
+        const float ivp = 1.f / (sp * sp);
+        const float g = dz[i], e = eps[i];
+        float kmq, ksq, kmp, ksp;
+        if (kl_sampled) {  // log q(z) = sum -ls_q - eps^2/2 (z - mu_q = s_q eps exactly), log p(z) = sum -ls_p - (z - mu_p)^2 / (2 s_p^2)
+            const float u = (muq + sq * e - mup);
+            kmq = u * ivp;
+            ksq = -1.f + u * sq * e * ivp;
+            kmp = -u * ivp;
+            ksp = 1.f - u * u * ivp;
+        } else {
+            const float diff = muq - mup;
+            kmq = diff * ivp;
+            ksq = sq * sq * ivp - 1.f;
+            kmp = -diff * ivp;
+            ksp = 1.f - sq * sq * ivp - diff * diff * ivp;
+        }
+        dq[b * 2 * L + d] = g + coef * kmq;
+        dq[b * 2 * L + L + d] = (z_is_mean ? 0.f : g * sq * e) + coef * ksq;
+        dp[b * 2 * L + d] = coef * kmp;
+        dp[b * 2 * L + L + d] = coef * ksp;
+    }
+}
+
+// (mu, sigma) of Independent(Normal(mu, exp(log_sigma)), 1) as separate tensors (probabilistic_unet.py:136-141)
+__global__ void latent_split_kernel(const float* __restrict__ muls, float* __restrict__ loc, float* __restrict__ scale, int B,
+                                    int L) {
+    GRID_STRIDE(i, (size_t)(B * L)) {
+        const int d = (int)(i % L), b = (int)(i / L);
+        loc[i] = muls[b * 2 * L + d];
+        scale[i] = expf(muls[b * 2 * L + L + d]);
+    }
+}
+
+// torch.cat([a, b], dim=1) of two NHWC tensors with few channels (the posterior's [patch, segm] input,
+// probabilistic_unet.py:115-118): out[p][0:ca] = a[p], out[p][ca:ca+cb] = b[p]
+__global__ void concat_nhwc_kernel(const float* __restrict__ a, int ca, const float* __restrict__ b, int cb,
+                                   float* __restrict__ out, size_t P) {
+    const int c = ca + cb;
+    GRID_STRIDE(i, P * (size_t)c) {
+        const size_t p = i / c;
+        const int k = (int)(i % c);
+        out[i] = k < ca ? a[p * ca + k] : b[p * cb + (k - ca)];
+    }
+}
+
+// [B,C,H,W] -> [B,H,W,C] (the API takes the reference's NCHW patches; the kernels run NHWC)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, size_t HW) {
+    GRID_STRIDE(i, (size_t)B * C * HW) {
+        const int c = (int)(i % C);
+        const size_t p = (i / C) % HW, b = i / ((size_t)C * HW);
+        y[i] = x[(b * C + c) * HW + p];
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, size_t HW) {
+    GRID_STRIDE(i, (size_t)B * C * HW) {
+        const size_t p = i % HW;
+        const int c = (int)((i / HW) % C);
+        const size_t b = i / ((size_t)C * HW);
+        y[i] = x[(b * HW + p) * C + c];
+    }
+}
+
+// FixMatch distribution alignment (fixmatch_trainer.py:77-84): count (y >= 0.5) exactly (integer atomics: order
+// independent), then y = clip(y * (source[c] / target[c]), 0, 1) with c = (y >= 0.5), target = counts / numel
+__global__ __launch_bounds__(256) void count_ge_kernel(const float* __restrict__ y, size_t P, float thr,
+                                                       unsigned long long* __restrict__ count) {
+    __shared__ unsigned sh[4];
+    unsigned c = 0;
+    GRID_STRIDE(i, P) c += y[i] >= thr ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(count, (unsigned long long)(sh[0] + sh[1] + sh[2] + sh[3]));
+}
+__global__ void align_distribution_kernel(const float* __restrict__ y, const float* __restrict__ src, size_t P,
+                                          const unsigned long long* __restrict__ count, float* __restrict__ out,
+                                          float* __restrict__ ratio) {
+    const float n = (float)P, pos = (float)count[0], neg = (float)(P - count[0]);
+    const float r0 = src[0] / (neg / n), r1 = src[1] / (pos / n);
+    if (ratio && blockIdx.x == 0 && threadIdx.x == 0) { ratio[0] = r0; ratio[1] = r1; }
+    GRID_STRIDE(i, P) {
+        const float v = y[i];
+        out[i] = fminf(fmaxf(v < 0.5f ? v * r0 : v * r1, 0.f), 1.f);
+    }
+}
+
 // backward of the latent head's 1x1 conv on the pooled vector
 __global__ void latent_head_bwd_kernel(const float* __restrict__ d, const float* __restrict__ mean, const float* __restrict__ w,
                                        float* __restrict__ dw, float* __restrict__ db, float* __restrict__ dmean, int B, int C,
@@ -878,6 +1018,65 @@ extern "C" int punet_latent_kl_bwd(const float* muls_q, const float* muls_p, con
     PUNET_CHECK_ARG(muls_q && muls_p && eps && dz && d_muls_q && d_muls_p, "punet_latent_kl_bwd: null pointer");
     latent_kl_bwd_kernel<<<1, 256, 0, STREAM>>>(muls_q, muls_p, eps, dz, coef, d_muls_q, d_muls_p, B, L);
     PUNET_LAUNCH_CHECK("latent_kl_bwd");
+    return PUNET_OK;
+}
+
+extern "C" int punet_latent_kl_rows(const float* muls_q, const float* muls_p, const float* z, float* kl_rows, float* kl_mean,
+                                    int B, int L, void* stream) {
+    PUNET_CHECK_ARG(muls_q && muls_p && kl_mean && B > 0 && L > 0, "punet_latent_kl_rows: bad args");
+    latent_kl_rows_kernel<<<1, 256, 0, STREAM>>>(muls_q, muls_p, z, kl_rows, kl_mean, B, L);
+    PUNET_LAUNCH_CHECK("latent_kl_rows");
+    return PUNET_OK;
+}
+
+extern "C" int punet_latent_kl_bwd_ex(const float* muls_q, const float* muls_p, const float* eps, const float* dz, float coef,
+                                      int kl_sampled, int z_is_mean, float* d_muls_q, float* d_muls_p, int B, int L,
+                                      void* stream) {
+    PUNET_CHECK_ARG(muls_q && muls_p && eps && dz && d_muls_q && d_muls_p, "punet_latent_kl_bwd_ex: null pointer");
+    latent_kl_bwd_ex_kernel<<<1, 256, 0, STREAM>>>(muls_q, muls_p, eps, dz, coef, kl_sampled, z_is_mean, d_muls_q, d_muls_p, B, L);
+    PUNET_LAUNCH_CHECK("latent_kl_bwd_ex");
+    return PUNET_OK;
+}
+
+extern "C" int punet_latent_split(const float* muls, float* loc, float* scale, int B, int L, void* stream) {
+    PUNET_CHECK_ARG(muls && loc && scale && B > 0 && L > 0, "punet_latent_split: bad args");
+    latent_split_kernel<<<ew_grid((size_t)B * L), EW_BLOCK, 0, STREAM>>>(muls, loc, scale, B, L);
+    PUNET_LAUNCH_CHECK("latent_split");
+    return PUNET_OK;
+}
+
+extern "C" int punet_concat_nhwc(const float* a, int ca, const float* b, int cb, float* out, long P, void* stream) {
+    PUNET_CHECK_ARG(a && b && out && ca > 0 && cb > 0 && P > 0, "punet_concat_nhwc: bad args");
+    concat_nhwc_kernel<<<ew_grid((size_t)P * (ca + cb), 8192), EW_BLOCK, 0, STREAM>>>(a, ca, b, cb, out, (size_t)P);
+    PUNET_LAUNCH_CHECK("concat_nhwc");
+    return PUNET_OK;
+}
+
+extern "C" int punet_nchw_to_nhwc(const float* x, float* y, int B, int C, long HW, void* stream) {
+    PUNET_CHECK_ARG(x && y && x != y && B > 0 && C > 0 && HW > 0, "punet_nchw_to_nhwc: bad args");
+    nchw_to_nhwc_kernel<<<ew_grid((size_t)B * C * HW, 8192), EW_BLOCK, 0, STREAM>>>(x, y, B, C, (size_t)HW);
+    PUNET_LAUNCH_CHECK("nchw_to_nhwc");
+    return PUNET_OK;
+}
+
+extern "C" int punet_nhwc_to_nchw(const float* x, float* y, int B, int C, long HW, void* stream) {
+    PUNET_CHECK_ARG(x && y && x != y && B > 0 && C > 0 && HW > 0, "punet_nhwc_to_nchw: bad args");
+    nhwc_to_nchw_kernel<<<ew_grid((size_t)B * C * HW, 8192), EW_BLOCK, 0, STREAM>>>(x, y, B, C, (size_t)HW);
+    PUNET_LAUNCH_CHECK("nhwc_to_nchw");
+    return PUNET_OK;
+}
+
+extern "C" int punet_align_distribution(const float* y, const float* source_distribution, float* out, float* ratio,
+                                        unsigned long long* count_ws, long P, void* stream) {
+    PUNET_CHECK_ARG(y && source_distribution && out && count_ws && P > 0, "punet_align_distribution: bad args");
+    if (hipMemsetAsync(count_ws, 0, sizeof(unsigned long long), STREAM) != hipSuccess) {
+        punet_set_error("punet_align_distribution: hipMemsetAsync failed");
+        return PUNET_ERR_HIP;
+    }
+    count_ge_kernel<<<ew_grid((size_t)P, 1024), 256, 0, STREAM>>>(y, (size_t)P, 0.5f, count_ws);
+    PUNET_LAUNCH_CHECK("count_ge");
+    align_distribution_kernel<<<ew_grid((size_t)P), EW_BLOCK, 0, STREAM>>>(y, source_distribution, (size_t)P, count_ws, out, ratio);
+    PUNET_LAUNCH_CHECK("align_distribution");
     return PUNET_OK;
 }
 

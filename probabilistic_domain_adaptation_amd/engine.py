@@ -267,9 +267,22 @@ class PUNetEngine:
         return flat.data_ptr() + 4 * conv.b_off
 
     def to_nhwc(self, x: torch.Tensor) -> torch.Tensor:
-        """[B,C,H,W] (any strides) -> contiguous NHWC fp32 on the device (a no-op view when C == 1)."""
-        x = x.to(device=self.device, dtype=torch.float32)
-        return x.permute(0, 2, 3, 1).contiguous()
+        """[B,C,H,W] (any strides) -> contiguous NHWC fp32 on the device (the same bytes when C == 1)."""
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        B, C, H, W = x.shape
+        if C == 1:
+            return x.view(B, H, W, 1)
+        y = self._empty(B, H, W, C)
+        _lib.call("punet_nchw_to_nhwc", x.data_ptr(), y.data_ptr(), B, C, H * W, _stream())
+        return y
+
+    def to_nchw(self, a: "Act") -> torch.Tensor:
+        """NHWC activation -> contiguous [B,C,H,W] tensor (what the reference's attributes such as unet_features hold)."""
+        if a.C == 1:
+            return a.t.view(a.B, 1, a.H, a.W)
+        y = self._empty(a.B, a.C, a.H, a.W)
+        _lib.call("punet_nhwc_to_nchw", a.ptr, y.data_ptr(), a.B, a.C, a.H * a.W, _stream())
+        return y
 
     # ---------------------------------------------------------------- forward ops
     def conv(self, flat, name: str, x0: Act, x1: Optional[Act] = None, relu=True, tape=None, taps=None, tape_bits=False,
@@ -433,6 +446,30 @@ class PUNetEngine:
         _lib.call("punet_reparam", muls.data_ptr(), eps.data_ptr(), z.data_ptr(), N, B, Ld, _stream())
         return z
 
+    def latent_split(self, muls: torch.Tensor):
+        """(mu, sigma) [B, L] each of the Normal the reference stores (probabilistic_unet.py:136-141)."""
+        B, Ld = muls.shape[0], muls.shape[1] // 2
+        loc, scale = self._empty(B, Ld), self._empty(B, Ld)
+        _lib.call("punet_latent_split", muls.data_ptr(), loc.data_ptr(), scale.data_ptr(), B, Ld, _stream())
+        return loc, scale
+
+    def kl_rows(self, muls_q: torch.Tensor, muls_p: torch.Tensor, z: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """kl_divergence(analytic = z is None) (probabilistic_unet.py:324-339) -> [B]."""
+        B, Ld = muls_q.shape[0], muls_q.shape[1] // 2
+        rows, mean = self._empty(B), self._empty(1)
+        _lib.call("punet_latent_kl_rows", muls_q.data_ptr(), muls_p.data_ptr(), z.data_ptr() if z is not None else None,
+                  rows.data_ptr(), mean.data_ptr(), B, Ld, _stream())
+        return rows
+
+    def align_distribution(self, y: torch.Tensor, source_distribution: torch.Tensor):
+        """FixMatch distribution alignment (fixmatch_trainer.py:77-84) -> (aligned y, ratio [2]); no host sync."""
+        y = y.contiguous()
+        out, ratio = torch.empty_like(y), self._empty(2)
+        cnt = self.ws.get("count", 2)
+        _lib.call("punet_align_distribution", y.data_ptr(), source_distribution.data_ptr(), out.data_ptr(), ratio.data_ptr(),
+                  cnt.data_ptr(), y.numel(), _stream())
+        return out, ratio
+
     def consensus(self, logits: torch.Tensor, upper=0.9, lower=0.1, masking=False):
         """K8 on given logits [N, ...] (unit parity of mean_teacher_trainer.py:74-86)."""
         N = logits.shape[0]
@@ -444,31 +481,52 @@ class PUNetEngine:
         return y, z
 
     # ---------------------------------------------------------------- training path
-    def elbo_forward(self, flat, x_nhwc, y_tgt, consm, eps, loss_kind="bce", beta=1.0, gscale=1.0, record=True, taps=None):
-        """forward(patch, segm, training=True) + elbo(segm, consm) (probabilistic_unet.py:285-293,341-371).
-        y_tgt, consm: [B,1,H,W] float (consm may be None); eps: [B, L].  When record is True the tape and the
-        d loss / d logit (scaled by gscale) are kept for elbo_backward."""
+    def train_forward(self, flat, x_nhwc, segm, record=True, taps=None):
+        """forward(patch, segm, training=True) (probabilistic_unet.py:285-293): posterior on [patch, segm], prior and U-Net
+        features.  segm: [B,1,H,W] float.  With record the tapes for elbo_backward are kept."""
         L = self.L
         B, H, W, C = x_nhwc.shape
-        Ld, CH = L.latent_dim, L.nf[0]
-        st = {"B": B, "H": H, "W": W, "gscale": gscale, "beta": beta}
+        st = {"B": B, "H": H, "W": W, "recorded": bool(record)}
         self.prepare_forward_weights(flat)
         xin = Act(x_nhwc, B, H, W, C, needs_grad=False)
-        xq = Act(torch.cat([x_nhwc, y_tgt.reshape(B, H, W, 1)], dim=3), B, H, W, C + 1, needs_grad=False)  # [patch, segm]
+        xq_t = self._empty(B, H, W, C + 1)  # torch.cat([patch, segm], 1) (probabilistic_unet.py:118), NHWC
+        _lib.call("punet_concat_nhwc", x_nhwc.data_ptr(), C, segm.data_ptr(), 1, xq_t.data_ptr(), B * H * W, _stream())
+        xq = Act(xq_t, B, H, W, C + 1, needs_grad=False)
         tq = [] if record else None
         tp = [] if record else None
         tu = [] if record else None
         muls_q, mean_q, enc_q = self.latent(flat, "posterior", xq, tq, taps)
         muls_p, mean_p, enc_p = self.latent(flat, "prior", xin, tp, taps)
         feat = self.unet(flat, xin, tu, taps)
+        st.update(muls_q=muls_q, muls_p=muls_p, mean_q=mean_q, mean_p=mean_p, enc_q=enc_q, enc_p=enc_p, feat=feat,
+                  tapes=(tq, tp, tu))
+        return st
+
+    def elbo_head(self, flat, st, y_tgt, consm, eps, loss_kind="bce", beta=1.0, gscale=1.0, record=True, taps=None,
+                  analytic_kl=True, posterior_mean=False):
+        """elbo(segm, consm, analytic_kl, reconstruct_posterior_mean) (probabilistic_unet.py:341-371) on the state of
+        train_forward: z = posterior.rsample() (:349), KL (:351-353), Fcomb on z - or on mu_q when posterior_mean (:356-358;
+        the reference reads `.loc` of an Independent there, which raises AttributeError - the intended mean is used),
+        criterion (:360-369).  y_tgt, consm: [B,1,H,W] float (consm may be None); eps: [B, L].  With record the
+        d loss / d logit (scaled by gscale) is kept for elbo_backward."""
+        L = self.L
+        B, H, W = st["B"], st["H"], st["W"]
+        Ld, CH = L.latent_dim, L.nf[0]
+        record = bool(record and st["recorded"])
+        st = dict(st)
+        st.update(gscale=gscale, beta=beta)
+        muls_q, muls_p, feat = st["muls_q"], st["muls_p"], st["feat"]
         eps3 = eps.reshape(1, B, Ld).contiguous()
         z = self.reparam(muls_q, eps3)  # [1, B, L]
         kl = self._empty(1)
-        _lib.call("punet_latent_kl", muls_q.data_ptr(), muls_p.data_ptr(), kl.data_ptr(), B, Ld, _stream())
+        kl_rows = self._empty(B)
+        _lib.call("punet_latent_kl_rows", muls_q.data_ptr(), muls_p.data_ptr(), None if analytic_kl else z.data_ptr(),
+                  kl_rows.data_ptr(), kl.data_ptr(), B, Ld, _stream())
+        zf = self.reparam(muls_q, torch.zeros_like(eps3)) if posterior_mean else z  # what Fcomb sees
         # Fcomb, single sample, activations materialised for the backward
         c1, c3 = L.convs["fcomb.layers.0"], L.convs["fcomb.last_layer"]
         zb = self._empty(B, CH)
-        _lib.call("punet_fcomb_zbias", z.data_ptr(), self._wptr(flat, c1), self._bptr(flat, c1), zb.data_ptr(), B, Ld, CH,
+        _lib.call("punet_fcomb_zbias", zf.data_ptr(), self._wptr(flat, c1), self._bptr(flat, c1), zb.data_ptr(), B, Ld, CH,
                   _stream())
         h = Act(self._empty(B, H, W, CH), B, H, W, CH, relu_out=True)
         p1 = self._x6_1x1.get((flat.data_ptr(), 0), {}).get(c1.name) if self.x6 else None
@@ -504,9 +562,14 @@ class PUNetEngine:
                       rec.data_ptr(), wsl.data_ptr(), P, _stream())
         else:
             raise ValueError(loss_kind)
-        st.update(muls_q=muls_q, muls_p=muls_p, mean_q=mean_q, mean_p=mean_p, enc_q=enc_q, enc_p=enc_p, feat=feat, z=z,
-                  eps=eps3, kl=kl, rec=rec, logits=logits, dlogit=dlogit, hs=hs, tapes=(tq, tp, tu), loss_kind=loss_kind)
+        st.update(z=zf, z_posterior=z, eps=eps3, kl=kl, kl_rows=kl_rows, rec=rec, logits=logits, dlogit=dlogit, hs=hs,
+                  loss_kind=loss_kind, kl_sampled=not analytic_kl, z_is_mean=bool(posterior_mean), recorded=record)
         return st
+
+    def elbo_forward(self, flat, x_nhwc, y_tgt, consm, eps, loss_kind="bce", beta=1.0, gscale=1.0, record=True, taps=None):
+        """forward(patch, segm, training=True) + elbo(segm, consm) with segm = y_tgt for both (every reference trainer)."""
+        st = self.train_forward(flat, x_nhwc, y_tgt, record, taps)
+        return self.elbo_head(flat, st, y_tgt, consm, eps, loss_kind, beta, gscale, record, taps)
 
     def _wgrad(self, gflat, c: ConvP, x: Act, ci_off: int, dz: torch.Tensor, with_bias: bool, accumulate: bool):
         B, H, W = x.B, x.H, x.W
@@ -662,6 +725,8 @@ class PUNetEngine:
         U-Net's slice of gflat (the first L.unet_numel floats) is final - the data-parallel step starts that slice's
         all-reduce there, under the encoders' backward."""
         L = self.L
+        if not st.get("recorded", True):
+            raise RuntimeError("elbo_backward needs a state recorded with grad mode on (forward() ran under no_grad)")
         B, H, W = st["B"], st["H"], st["W"]
         Ld, CH = L.latent_dim, L.nf[0]
         acc = int(accumulate)
@@ -703,8 +768,9 @@ class PUNetEngine:
         dq = self._empty(B, 2 * Ld)
         dp = self._empty(B, 2 * Ld)
         coef = float(st["gscale"]) * float(st["beta"]) / B
-        _lib.call("punet_latent_kl_bwd", st["muls_q"].data_ptr(), st["muls_p"].data_ptr(), st["eps"].data_ptr(), dz.data_ptr(),
-                  coef, dq.data_ptr(), dp.data_ptr(), B, Ld, _stream())
+        _lib.call("punet_latent_kl_bwd_ex", st["muls_q"].data_ptr(), st["muls_p"].data_ptr(), st["eps"].data_ptr(), dz.data_ptr(),
+                  coef, int(st.get("kl_sampled", False)), int(st.get("z_is_mean", False)), dq.data_ptr(), dp.data_ptr(), B, Ld,
+                  _stream())
         for net, d, mean, enc, tape in (("posterior", dq, st["mean_q"], st["enc_q"], tq),
                                        ("prior", dp, st["mean_p"], st["enc_p"], tp)):
             c = L.convs[f"{net}.conv_layer"]

@@ -45,11 +45,14 @@ class _LatentSpace:
     """What the trainers may read from `prior_latent_space` / `posterior_latent_space`
     (Independent(Normal(mu, sigma), 1) in the reference, probabilistic_unet.py:141)."""
 
-    def __init__(self, muls: torch.Tensor, latent_dim: int):
+    def __init__(self, muls: torch.Tensor, engine: PUNetEngine):
         self.muls = muls
-        self.loc = muls[:, :latent_dim]
-        self.scale = muls[:, latent_dim:].exp()
+        self.loc, self.scale = engine.latent_split(muls)
         self.base_dist = self
+
+    @property
+    def mean(self):
+        return self.loc
 
     def distribution(self):
         return torch.distributions.Independent(torch.distributions.Normal(self.loc, self.scale), 1)
@@ -104,6 +107,7 @@ class ProbabilisticUnet(nn.Module):
             _attach(self, name, nn.Parameter(v, requires_grad=True))
         self.reset_parameters(seed)
         self._state = None
+        self._features_nchw = None
         self.generator = None  # optional torch.Generator (device) for the latent draws
 
     # ------------------------------------------------------------------ parameters
@@ -161,37 +165,41 @@ class ProbabilisticUnet(nn.Module):
         eps = eps.to(device=self.device, dtype=torch.float32).reshape(n, batch, self.latent_dim).contiguous()
         return eps
 
+    def _b1hw(self, t, B, H, W):
+        return t.to(device=self.device, dtype=torch.float32).reshape(B, 1, H, W).contiguous()
+
     def forward(self, patch, segm, training=True):
-        """probabilistic_unet.py:285-293.  Returns None; stores prior_latent_space / unet_features (and remembers
-        patch, segm so that elbo() can run the fused training forward+backward)."""
+        """probabilistic_unet.py:285-293.  Returns None; stores posterior_latent_space (training only),
+        prior_latent_space and unet_features.  With grad mode on and training=True the activations are kept for the
+        backward that elbo() runs."""
         eng = self.engine
         x = eng.to_nhwc(patch)
-        if training and segm is None:
-            raise ValueError("forward(patch, None, training=True) is invalid: the posterior needs the segmentation")
-        self._state = {"x": x, "segm": segm, "training": training}
-        if torch.is_grad_enabled() and training:
-            # the expensive pass happens in elbo(), which knows the target; keep only what sample() may need lazily
-            self._state["lazy"] = True
-            return None
-        self._run_inference_forward()
+        B, H, W = x.shape[0], x.shape[1], x.shape[2]
+        if training:
+            if segm is None:
+                raise ValueError("forward(patch, None, training=True) is invalid: the posterior needs the segmentation")
+            st = eng.train_forward(self._flat, x, self._b1hw(segm, B, H, W), record=torch.is_grad_enabled())
+            self._state = {"x": x, "training": True, "train": st, "features": st["feat"], "prior_muls": st["muls_p"]}
+            self.posterior_latent_space = _LatentSpace(st["muls_q"], eng)
+        else:
+            out = eng.forward_features(self._flat, x)
+            self._state = {"x": x, "training": False, "features": out["features"], "prior_muls": out["prior_muls"]}
+        self.prior_latent_space = _LatentSpace(self._state["prior_muls"], eng)
+        self._features_nchw = None
         return None
 
-    def _run_inference_forward(self):
-        st = self._state
-        out = self.engine.forward_features(self._flat, st["x"])
-        st.update(out)
-        st["lazy"] = False
-        self.unet_features = out["features"].t.permute(0, 3, 1, 2)
-        self.prior_latent_space = _LatentSpace(out["prior_muls"], self.latent_dim)
-        if st["training"]:
-            # posterior for no-grad validation (mean_teacher_trainer.py:160): computed inside elbo()
-            pass
+    @property
+    def unet_features(self):
+        """[B, C, H, W] view of the U-Net features (probabilistic_unet.py:293); converted from NHWC on first access."""
+        if self._state is None:
+            raise AttributeError("unet_features: call forward() first")
+        if self._features_nchw is None:
+            self._features_nchw = self.engine.to_nchw(self._state["features"])
+        return self._features_nchw
 
     def _ensure_features(self):
         if self._state is None:
             raise RuntimeError("call forward() first")
-        if self._state.get("lazy", False) or "features" not in self._state:
-            self._run_inference_forward()
 
     def sample(self, testing=False, eps: Optional[torch.Tensor] = None):
         """probabilistic_unet.py:295-309: logits of one prior sample ([B,1,H,W])."""
@@ -213,60 +221,61 @@ class ProbabilisticUnet(nn.Module):
         y, c, _ = self.engine.sample(self._flat, st["features"], z, upper, lower, masking)
         return y, c
 
-    def reconstruct(self, use_posterior_mean=False, calculate_posterior=False, z_posterior=None):
-        """probabilistic_unet.py:311-322 (forward only)."""
+    def _posterior_muls(self):
+        st = self._state
+        if st is None or not st["training"]:
+            raise RuntimeError("the posterior needs forward(patch, segm, training=True) first")
+        return st["train"]["muls_q"]
+
+    def reconstruct(self, use_posterior_mean=False, calculate_posterior=False, z_posterior=None,
+                    eps: Optional[torch.Tensor] = None):
+        """probabilistic_unet.py:311-322 (forward only): Fcomb on the posterior mean / a fresh posterior rsample / the
+        supplied z.  (use_posterior_mean reads `posterior_latent_space.loc` in the reference, which an Independent does
+        not have - AttributeError there; the intended base_dist.loc is used here.)"""
         self._ensure_features()
         st = self._state
+        B = st["x"].shape[0]
         if use_posterior_mean:
             z_posterior = self.posterior_latent_space.loc
         elif calculate_posterior:
-            B = st["x"].shape[0]
-            z_posterior = self.engine.reparam(self.posterior_latent_space.muls, self._eps(1, B, None))[0]
-        z = z_posterior.reshape(1, -1, self.latent_dim).contiguous()
+            z_posterior = self.engine.reparam(self._posterior_muls(), self._eps(1, B, eps))[0]
+        z = z_posterior.to(device=self.device, dtype=torch.float32).reshape(1, B, self.latent_dim).contiguous()
         _, _, logits = self.engine.sample(self._flat, st["features"], z, want_logits=True, want_consensus=False)
         return logits[0]
 
-    def kl_divergence(self, analytic=True, calculate_posterior=False, z_posterior=None):
-        """probabilistic_unet.py:324-339 -> [B]."""
-        q = self.posterior_latent_space.distribution()
-        p = self.prior_latent_space.distribution()
+    def kl_divergence(self, analytic=True, calculate_posterior=False, z_posterior=None, eps: Optional[torch.Tensor] = None):
+        """probabilistic_unet.py:324-339 -> [B]: analytic KL(Q||P), or log q(z) - log p(z) at a posterior sample."""
+        mq, mp = self._posterior_muls(), self._state["prior_muls"]
         if analytic:
-            return torch.distributions.kl.kl_divergence(q, p)
+            return self.engine.kl_rows(mq, mp, None)
+        B = mq.shape[0]
         if calculate_posterior:
-            z_posterior = q.rsample()
-        return q.log_prob(z_posterior) - p.log_prob(z_posterior)
+            z_posterior = self.engine.reparam(mq, self._eps(1, B, eps))[0]
+        z = z_posterior.to(device=self.device, dtype=torch.float32).reshape(B, self.latent_dim).contiguous()
+        return self.engine.kl_rows(mq, mp, z)
 
     def elbo(self, segm, consm=None, analytic_kl=True, reconstruct_posterior_mean=False, view=False,
              eps: Optional[torch.Tensor] = None):
         """probabilistic_unet.py:341-371: -(reconstruction_loss + beta * kl).
 
-        Runs posterior/prior encoders, U-Net, Fcomb, criterion and KL on the GPU; with grad mode on it also runs the
-        whole backward and returns a scalar wired into autograd (see _ElboFn)."""
-        if not analytic_kl or reconstruct_posterior_mean:
-            raise NotImplementedError("the HIP path implements analytic_kl=True, reconstruct_posterior_mean=False "
-                                      "(the only combination the reference trainers use)")
+        Runs rsample, KL, Fcomb and the criterion on the state forward() stored; with grad mode on it also runs the whole
+        backward (Fcomb, U-Net, both encoders) and returns a scalar wired into autograd (see _ElboFn).  `segm` is the
+        criterion's target; the posterior saw forward()'s segm (:291) - they may differ, as in the reference."""
         st = self._state
         if st is None or not st["training"]:
             raise RuntimeError("elbo() needs forward(patch, segm, training=True) first")
         eng = self.engine
-        B = st["x"].shape[0]
-        H, W = st["x"].shape[1], st["x"].shape[2]
-        tgt = st["segm"] if st["segm"] is not None else segm
-        # the posterior saw forward()'s segm (probabilistic_unet.py:291); the criterion uses elbo()'s (== in every trainer)
-        tgt = tgt.to(device=self.device, dtype=torch.float32).reshape(B, 1, H, W).contiguous()
-        seg = segm.to(device=self.device, dtype=torch.float32).reshape(B, 1, H, W).contiguous()
-        if seg.data_ptr() != tgt.data_ptr() and not torch.equal(seg, tgt):
-            raise NotImplementedError("elbo(segm) with a segm different from forward()'s is not supported")
+        B, H, W = st["x"].shape[0], st["x"].shape[1], st["x"].shape[2]
+        tgt = self._b1hw(segm, B, H, W)
         cm = None
         if self.consensus_masking is True and consm is not None:
-            cm = consm.to(device=self.device, dtype=torch.float32).reshape(B, 1, H, W).contiguous()
+            cm = self._b1hw(consm, B, H, W)
         e = self._eps(1, B, eps)[0]
-        record = torch.is_grad_enabled()
-        es = eng.elbo_forward(self._flat, st["x"], tgt, cm, e, "dice" if self.rl_swap else "bce", self.beta, 1.0, record)
-        self.posterior_latent_space = _LatentSpace(es["muls_q"], self.latent_dim)
-        self.prior_latent_space = _LatentSpace(es["muls_p"], self.latent_dim)
-        self.unet_features = es["feat"].t.permute(0, 3, 1, 2)
-        st.update(features=es["feat"], prior_muls=es["muls_p"], lazy=False)
+        record = torch.is_grad_enabled() and st["train"]["recorded"]
+        es = eng.elbo_head(self._flat, st["train"], tgt, cm, e, "dice" if self.rl_swap else "bce", self.beta, 1.0, record,
+                           analytic_kl=analytic_kl, posterior_mean=reconstruct_posterior_mean)
+        if view:
+            print(es["logits"].shape, segm.shape)
         self.kl = es["kl"][0]
         self.reconstruction = es["logits"]
         self.reconstruction_loss = es["rec"][0]

@@ -6,8 +6,8 @@ wrappers `punet_prediction` / `punet_pseudo_prediction` keep the reference signa
 
 Tiling follows what the reference delegates to the un-vendored `torch_em.util.prediction.predict_with_halo`
 (punet_predictions.py:41-49: block 384x384, halo 64x64 -> 512x512 outer tile) as RECALLED in SURVEY.md §8c: blocks
-read with their halo, reflect padding where the halo leaves the image, per-tile standardisation, halo cropped from the
-output.  That third-party routine is not in /root/reference -> tiling parity is unpinned; per-tile arithmetic is the
+read as full (block + 2 * halo) windows, reflect padding where a window leaves the image, per-tile standardisation,
+halo cropped from the output.  That third-party routine is not in /root/reference -> tiling parity is unpinned; per-tile arithmetic is the
 pinned `_custom_punet_prediction` body (punet_predictions.py:29-33).
 """
 from __future__ import annotations
@@ -34,48 +34,53 @@ def mc_prediction(model, raw: torch.Tensor, prior_samples: int = 8, eps=None) ->
     return y
 
 
-def _tiles(shape, block_shape, halo):
+def _blocks(shape, block_shape):
+    """Row-major blocks (y0, y1, x0, x1) of the image, the last ones clipped."""
     for y0 in range(0, shape[0], block_shape[0]):
         for x0 in range(0, shape[1], block_shape[1]):
-            y1, x1 = min(y0 + block_shape[0], shape[0]), min(x0 + block_shape[1], shape[1])
-            yield (y0, y1, x0, x1)
+            yield y0, min(y0 + block_shape[0], shape[0]), x0, min(x0 + block_shape[1], shape[1])
 
 
 @torch.no_grad()
 def predict_image(model, image: np.ndarray, prior_samples: int = 8, block_shape=(384, 384), halo=(64, 64),
-                  tile_batch: int = 4, multiple_of: int = 8, shard_over_ranks: bool = True) -> np.ndarray:
+                  tile_batch: int = 4, multiple_of: int = 8, shard_over_ranks: bool = True, eps=None) -> np.ndarray:
     """Tiled MC prediction of one 2-D image -> float32 mean-probability map (punet_predictions.py:35-50).
-    Tiles of equal outer shape are batched (`tile_batch` per launch); every tile gets its own latent draws.
+    Every block is read as the full (block + 2 * halo) window - what lies outside the image is reflect-padded, also for
+    the clipped last blocks ([recalled] predict_with_halo) -, standardised per tile, predicted, and its halo cropped.
+    All tiles have one shape and are batched `tile_batch` per launch; every tile gets its own latent draws
+    (eps: optional [n_tiles, prior_samples, latent_dim] in row-major block order, for parity tests).
     Under an initialised `torch.distributed` group (one process per GPU) the tile batches are dealt round-robin to the
     ranks - tiles are independent, so this is replicas-only - and the disjoint partial maps are joined by
     ONE all_reduce(sum) of the output; every rank returns the full map."""
     assert image.ndim == 2, "2-D single-channel images (every reference script uses input_channels=1)"
     H, W = image.shape
     out = np.zeros((H, W), dtype="float32")
-    pad = ((halo[0], halo[0] + block_shape[0]), (halo[1], halo[1] + block_shape[1]))
-    padded = np.pad(image.astype("float32"), pad, mode="reflect" if min(H, W) > max(halo) else "symmetric")
-    groups = {}
-    for (y0, y1, x0, x1) in _tiles((H, W), block_shape, halo):
-        bh, bw = y1 - y0, x1 - x0
-        oh = -(-(bh + 2 * halo[0]) // multiple_of) * multiple_of
-        ow = -(-(bw + 2 * halo[1]) // multiple_of) * multiple_of
-        tile = standardize(padded[y0:y0 + oh, x0:x0 + ow])  # padded origin is (-halo, -halo)
-        groups.setdefault((oh, ow), []).append(((y0, y1, x0, x1), tile))
+    oh = -(-(block_shape[0] + 2 * halo[0]) // multiple_of) * multiple_of  # outer tile (512 x 512 for 384 / 64)
+    ow = -(-(block_shape[1] + 2 * halo[1]) // multiple_of) * multiple_of
+    img = image.astype("float32")
+
+    def window(y0, x0):
+        """The (oh, ow) window with origin (y0 - halo, x0 - halo): clipped to the image, the rest reflect-padded from the
+        clipped part (per block, as predict_with_halo does - not from the whole image)."""
+        ys, ye, xs, xe = y0 - halo[0], y0 - halo[0] + oh, x0 - halo[1], x0 - halo[1] + ow
+        data = img[max(ys, 0):min(ye, H), max(xs, 0):min(xe, W)]
+        pw = ((max(-ys, 0), max(ye - H, 0)), (max(-xs, 0), max(xe - W, 0)))
+        return np.pad(data, pw, mode="reflect") if (pw[0][0] or pw[0][1] or pw[1][0] or pw[1][1]) else data
+
+    items = [((y0, y1, x0, x1), standardize(window(y0, x0))) for (y0, y1, x0, x1) in _blocks((H, W), block_shape)]
     dev = model.device
     import torch.distributed as dist
     world = dist.get_world_size() if shard_over_ranks and dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
-    n_chunk = 0
-    for (oh, ow), items in groups.items():
-        for i in range(0, len(items), tile_batch):
-            n_chunk += 1
-            if (n_chunk - 1) % world != rank:
-                continue
-            chunk = items[i:i + tile_batch]
-            raw = torch.from_numpy(np.stack([t for _, t in chunk])[:, None]).to(dev)
-            pred = mc_prediction(model, raw, prior_samples).cpu().numpy()[:, 0]
-            for k, ((y0, y1, x0, x1), _) in enumerate(chunk):
-                out[y0:y1, x0:x1] = pred[k, halo[0]:halo[0] + (y1 - y0), halo[1]:halo[1] + (x1 - x0)]
+    for n_chunk, i in enumerate(range(0, len(items), tile_batch)):
+        if n_chunk % world != rank:
+            continue
+        chunk = items[i:i + tile_batch]
+        raw = torch.from_numpy(np.stack([t for _, t in chunk])[:, None]).to(dev)
+        e = None if eps is None else torch.as_tensor(eps)[i:i + len(chunk)].transpose(0, 1).contiguous()  # [N, tiles, L]
+        pred = mc_prediction(model, raw, prior_samples, eps=e).cpu().numpy()[:, 0]
+        for k, ((y0, y1, x0, x1), _) in enumerate(chunk):
+            out[y0:y1, x0:x1] = pred[k, halo[0]:halo[0] + (y1 - y0), halo[1]:halo[1] + (x1 - x0)]
     if world > 1:  # every pixel was written by exactly one rank, the others hold 0 there
         joined = torch.from_numpy(out).to(dev)
         dist.all_reduce(joined, op=dist.ReduceOp.SUM)
@@ -84,12 +89,13 @@ def predict_image(model, image: np.ndarray, prior_samples: int = 8, block_shape=
 
 
 @torch.no_grad()
-def pseudo_predict_image(model, image: np.ndarray, prior_samples: int = 8, upper_threshold=0.9, lower_threshold=0.1):
+def pseudo_predict_image(model, image: np.ndarray, prior_samples: int = 8, upper_threshold=0.9, lower_threshold=0.1,
+                         eps=None):
     """Whole-image forward, mean of N sigmoids and the binary consensus mask (punet_predictions.py:96-124):
     returns (mean float32 [H, W], consensus uint8 [H, W])."""
     patch = torch.from_numpy(standardize(image))[None, None].to(model.device)
     model.forward(patch, None, training=False)
-    y, z = model.sample_consensus(prior_samples, upper_threshold, lower_threshold, masking=True)
+    y, z = model.sample_consensus(prior_samples, upper_threshold, lower_threshold, masking=True, eps=eps)
     return y[0, 0].cpu().numpy(), z[0, 0].cpu().numpy().astype("uint8")
 
 

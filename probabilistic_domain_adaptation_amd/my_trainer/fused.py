@@ -153,7 +153,7 @@ def fused_self_training_step(model, teacher, opt: FusedAdam, x1, x2, n_samples: 
     y, z = pseudo_labels(teacher, x1, n_samples, masking, eps_pl)
     ratio = None
     if source_distribution is not None:
-        y, ratio = distribution_alignment(y, source_distribution)
+        y, ratio = distribution_alignment(y, source_distribution, eng)
     rec, kl, st = elbo_grad_pass(model, opt.grad_flat, x2, y, z, eps_s, 1.0, False, overlap=True)
     reg, norms = eng.l2_reg(model.flat_params)
     eng.l2_reg_add_grad(model.flat_params, opt.grad_flat, norms, reg_weight)
@@ -180,12 +180,10 @@ def fused_joint_step(model, teacher, opt: FusedAdam, xs, ys, xt1, xt2, n_samples
     return loss, y, z
 
 
-def distribution_alignment(y: torch.Tensor, source_distribution: torch.Tensor):
-    """fixmatch_trainer.py:77-84 with device-side counting (no torch.unique host sync):
-    target class frequencies of (y >= 0.5), ratio = source / target, rescale and clip."""
-    src = torch.as_tensor(source_distribution, dtype=torch.float32, device=y.device)
-    pos = (y >= 0.5).sum().to(torch.float32)
-    n = float(y.numel())
-    target = torch.stack([n - pos, pos]) / n
-    ratio = src / target
-    return torch.where(y < 0.5, y * ratio[0], y * ratio[1]).clip(0, 1), ratio
+def distribution_alignment(y: torch.Tensor, source_distribution: torch.Tensor, engine=None):
+    """fixmatch_trainer.py:77-84 on the device (K-align: exact integer count of (y >= 0.5), no torch.unique host sync):
+    target class frequencies, ratio = source / target, rescale and clip.  Returns (aligned y, ratio [2])."""
+    if engine is None:
+        raise RuntimeError("distribution_alignment runs on the HIP engine of the model (no CPU fallback)")
+    src = torch.as_tensor(source_distribution, dtype=torch.float32, device=y.device).contiguous()
+    return engine.align_distribution(y, src)

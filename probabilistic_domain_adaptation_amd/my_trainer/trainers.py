@@ -112,6 +112,8 @@ class PUNetTrainer(_PUNetTrainerBase):
                 metric_val += 1.0 - d
         n = len(self.val_loader)
         print(f"The Average Dice Score for the Current Epoch is {dice_metric / n}")
+        # what the reference hands to its tensorboard logger (punet_trainer.py:94-96); kept as an attribute instead
+        self.last_validation = {"metric": metric_val / n, "loss": loss_val / n, "dice": dice_metric / n}
         return metric_val / n
 
 
@@ -162,6 +164,9 @@ class _SelfTrainingBase(_PUNetTrainerBase):
                 gt_metric_val += 1.0 - dg
         n = len(self.val_loader)
         print(f"The Average Dice Score for the Current Epoch is {dice_metric / n}")
+        # what the reference hands to its tensorboard logger (mean_teacher_trainer.py:185-190); kept as an attribute instead
+        self.last_validation = {"metric": metric_val / n, "loss": loss_val / n, "dice": dice_metric / n,
+                                "gt_metric": gt_metric_val / n, "y": y, "z": z, "samples": samples}
         return metric_val / n
 
 
@@ -263,7 +268,7 @@ class FixMatchTrainer(_SelfTrainingBase):
                 with torch.no_grad():
                     y, z = self.sample_from_weak_model(x1)
                 if self.source_distribution is not None:
-                    y, _ = FU.distribution_alignment(y, self.source_distribution)  # :77-84
+                    y, _ = FU.distribution_alignment(y, self.source_distribution, self.model.engine)  # :77-84
                 self.optimizer.zero_grad()
                 with forward_context():
                     loss = self._dropin_loss(x2, y, z, "student")

@@ -62,7 +62,30 @@ te.loss.dice = _mod("torch_em.loss.dice", DiceLossWithLogits=_Dice)
 te.trainer = _mod("torch_em.trainer", DefaultTrainer=_DefaultTrainer)
 te.trainer.logger_base = _mod("torch_em.trainer.logger_base", TorchEmLogger=_Logger)
 te.transform = _mod("torch_em.transform")
-te.transform.raw = _mod("torch_em.transform.raw", _normalize_torch=lambda x, **k: x)
+te.transform.raw = _mod("torch_em.transform.raw", _normalize_torch=lambda x, **k: x,
+                        standardize=lambda raw, *a, **k: O.standardize_np(raw))  # [recalled] third-party; see oracle
+
+
+def _predict_with_halo(input_, model, gpu_ids, block_shape, halo, output=None, prediction_function=None, **kw):
+    """[RECALLED, stated as such in the oracle] stand-in for the un-vendored torch_em.util.prediction.predict_with_halo:
+    only the blocking / padding / per-block standardise / halo crop are ours (oracle.halo_tiles, load_halo_block,
+    standardize_np); the per-block arithmetic is the REFERENCE's own `_custom_punet_prediction` (punet_predictions.py:29-33)
+    passed in as prediction_function, running the reference model."""
+    for (y0, y1, x0, x1) in O.halo_tiles(input_.shape, block_shape, halo):
+        tile = O.standardize_np(O.load_halo_block(input_, y0, x0, block_shape, halo))
+        pred = prediction_function(model, torch.from_numpy(tile)[None, None].to(gpu_ids[0]))
+        pred = pred.detach().cpu().numpy()[0, 0]
+        output[y0:y1, x0:x1] = pred[halo[0]:halo[0] + (y1 - y0), halo[1]:halo[1] + (x1 - x0)]
+    return output
+
+
+te.util = _mod("torch_em.util")
+te.util.prediction = _mod("torch_em.util.prediction", predict_with_halo=_predict_with_halo, predict_with_padding=None)
+IMAGES = {}   # path -> array "read" by the imageio stand-in
+WRITTEN = {}  # path -> array "written"
+iio = _mod("imageio")
+iio.v3 = _mod("imageio.v3", imread=lambda path, **k: IMAGES[path],
+              imwrite=lambda path, arr, **k: WRITTEN.__setitem__(path, np.asarray(arr).copy()))
 tv = _mod("torchvision")
 tv.utils = _mod("torchvision.utils", make_grid=lambda *a, **k: None)
 import matplotlib  # noqa: E402
@@ -362,6 +385,174 @@ def gen_trainer_case(name, nf, B, H, W, n_samples, seeds=(3, 4, 5)):
     print(f"[gen_golden] wrote {name}.npz ({os.path.getsize(os.path.join(HERE, name + '.npz')) / 1e6:.2f} MB)")
 
 
+class _CaptureLogger:
+    """Stands where the tensorboard logger would: receives what `_validate_impl` computed (metric, loss, ...)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def log_validation(self, *a, **k):
+        self.calls.append((a, k))
+
+
+def gen_api_case(name, nf, B, H, W, n_samples, seeds=(13, 14, 15)):
+    """Model-API corners and the validation / prediction loops, produced by the reference's own methods:
+    reconstruct / kl_divergence / elbo option space (probabilistic_unet.py:311-371), PUNetTrainer._validate_impl
+    (punet_trainer.py:52-97), MeanTeacherTrainer._validate_impl + sample_from_model (mean_teacher_trainer.py:90-93,
+    142-191), punet_pseudo_prediction and punet_prediction (punet_predictions.py:15-136; file I/O, standardize and
+    predict_with_halo replaced by in-memory stand-ins, see the stubs above)."""
+    import tempfile
+    from prob_utils.my_predictions.punet_predictions import punet_prediction, punet_pseudo_prediction
+    out = {}
+    C, L = 1, 6
+    cfg = O.PUNetConfig(C, 1, nf, L, 3, 1.0, consensus_masking=True, rl_swap=False)
+    x, x1, x2, gt = O.synth_batch(B, C, H, W, seeds[0])
+    xb, x1b, x2b, gtb = O.synth_batch(B, C, H, W, seeds[0] + 1)
+    out["meta"] = np.array([B, C, H, W, seeds[0], seeds[1], seeds[2], n_samples] + list(nf), dtype=np.int64)
+    m, Pnp = make_ref_model(cfg, seeds[1], True)
+    Po = O.to_torch(Pnp)
+
+    def E(n, k):
+        return eps_draws(n, B, L, seeds[2] + k)
+
+    # ---------------- model API: forward(x2, gt, True) then the option space -------------------------------------
+    y_other = torch.roll(gt, shifts=3, dims=3)  # an elbo() target that differs from forward()'s segm
+    consm = (torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(21)) > 0.4).float()
+    with torch.no_grad():
+        m.forward(x2, gt, training=True)
+        out["post_mu"] = m.posterior_latent_space.base_dist.loc.numpy().copy()
+        out["post_sigma"] = m.posterior_latent_space.base_dist.scale.numpy().copy()
+        out["kl_analytic"] = m.kl_divergence(analytic=True).numpy().copy()
+        z_given = m.posterior_latent_space.base_dist.loc + 0.7 * m.posterior_latent_space.base_dist.scale * E(1, 1)[0]
+        out["z_given"] = z_given.numpy().copy()
+        out["kl_sampled_z"] = m.kl_divergence(analytic=False, z_posterior=z_given).numpy().copy()
+        EPS.push(E(1, 2)[0])
+        out["kl_sampled_calc"] = m.kl_divergence(analytic=False, calculate_posterior=True).numpy().copy()
+        out["recon_z"] = m.reconstruct(z_posterior=z_given).numpy().copy()
+        EPS.push(E(1, 3)[0])
+        out["recon_calc"] = m.reconstruct(calculate_posterior=True).numpy().copy()
+        try:
+            m.reconstruct(use_posterior_mean=True)
+            out["recon_mean_raises"] = np.array([0])
+        except AttributeError:  # Independent has no .loc (probabilistic_unet.py:318)
+            out["recon_mean_raises"] = np.array([1])
+        so = O.punet_forward(Po, cfg, x2, gt, True)
+        assert np.abs(O.kl_sampled(*so["posterior"], *so["prior"], z_given).numpy() - out["kl_sampled_z"]).max() < 1e-5
+        assert np.abs(O.fcomb(Po, so["features"], z_given, 3).numpy() - out["recon_z"]).max() < 1e-5
+    for tag, kw, tgt in (("sampledkl", dict(analytic_kl=False), gt), ("othertarget", dict(), y_other)):
+        m.zero_grad()
+        m.forward(x2, gt, training=True)
+        EPS.push(E(1, 4)[0])
+        elbo = m.elbo(tgt, consm, **kw)
+        reg = mm.l2_regularisation(m.posterior) + mm.l2_regularisation(m.prior) + mm.l2_regularisation(m.fcomb.layers)
+        loss = -elbo + 1e-5 * reg
+        loss.backward()
+        out[f"elbo_{tag}_scalars"] = np.array([loss.item(), m.reconstruction_loss.item(), m.mean_reconstruction_loss.item(),
+                                               m.kl.item(), reg.item()], dtype=np.float64)
+        out[f"elbo_{tag}_grad_digest"] = np.stack([tensor_digest(p.grad) for p in m.parameters()])
+        Pg = O.to_torch(Pnp, requires_grad=True)
+        lo, _ = O.training_loss(Pg, cfg, x2, gt, consm, E(1, 4)[0], target=tgt, **kw)
+        assert abs(lo.item() - loss.item()) <= 1e-5 * abs(loss.item()) + 1e-6, (tag, lo.item(), loss.item())
+        for (k, g), p_ in zip(O.grads_of(lo, Pg).items(), m.parameters()):
+            assert (g - p_.grad).abs().max().item() <= 1e-4 * (p_.grad.abs().max().item() + 1e-6) + 1e-7, (tag, k)
+    m.zero_grad()
+
+    # ---------------- PUNetTrainer._validate_impl over two batches ------------------------------------------------
+    batches = [(x, gt), (xb, gtb)]
+    tr = mt.PUNetTrainer(name="g", train_loader=[], val_loader=batches, model=m, optimizer=None, device="cpu")
+    tr.logger = _CaptureLogger()
+    for i in range(2):
+        EPS.push(E(1, 10 + i)[0])
+        for e in E(8, 20 + i):
+            EPS.push(e)
+    for e in E(16, 30):  # the logger branch draws 16 more samples (punet_trainer.py:95-96, :15-17)
+        EPS.push(e)
+    metric = tr._validate_impl(contextlib.nullcontext)
+    (a, k), = tr.logger.calls
+    out["punet_val"] = np.array([metric, a[2]], dtype=np.float64)  # metric_val, loss_val
+    assert a[1] == metric and not EPS.q
+    mo, lo_ = O.punet_validate(Po, cfg, batches, [E(1, 10 + i)[0] for i in range(2)], [E(8, 20 + i) for i in range(2)])
+    assert abs(mo - metric) < 1e-6 and abs(lo_ - a[2]) <= 1e-5 * abs(a[2]), (mo, metric, lo_, a[2])
+
+    # ---------------- MeanTeacherTrainer._validate_impl + sample_from_model ---------------------------------------
+    Pt_np = O.synth_params(cfg.spec(), seeds[1] + 1)  # a teacher that differs from the student
+    mbatches = [(x, x1, x2, gt), (xb, x1b, x2b, gtb)]
+    for masking in (True, False):
+        tag = "mask" if masking else "weight"
+        tr = mt.MeanTeacherTrainer(name="g", train_loader=[], val_loader=mbatches, model=m, optimizer=None, device="cpu",
+                                   do_consensus_masking=masking)
+        tr.teacher.load_state_dict({k: torch.from_numpy(v) for k, v in Pt_np.items()})
+        tr.n_samples = n_samples
+        tr.logger = _CaptureLogger()
+        for i in range(2):
+            for e in E(n_samples, 40 + i):
+                EPS.push(e)
+            EPS.push(E(1, 50 + i)[0])
+            for e in E(n_samples, 60 + i):
+                EPS.push(e)
+        for e in E(n_samples, 70):  # the logger branch samples once more (mean_teacher_trainer.py:186-187)
+            EPS.push(e)
+        metric = tr._validate_impl(contextlib.nullcontext)
+        (a, k), = tr.logger.calls
+        assert a[1] == metric and not EPS.q
+        out[f"mt_val_{tag}"] = np.array([metric, a[2], k["gt_metric"]], dtype=np.float64)
+        out[f"mt_val_{tag}_y"] = a[6].detach().numpy().copy()
+        out[f"mt_val_{tag}_z"] = a[7].detach().numpy().copy()
+        out[f"mt_val_{tag}_logged_samples"] = a[9].detach().numpy().copy()  # sample_from_model() on the last batch's state
+        r = O.mean_teacher_validate(Po, O.to_torch(Pt_np), cfg, mbatches, [E(n_samples, 40 + i) for i in range(2)],
+                                    [E(1, 50 + i)[0] for i in range(2)], [E(n_samples, 60 + i) for i in range(2)], masking)
+        assert abs(r["metric"] - metric) < 1e-6 and abs(r["gt_metric"] - k["gt_metric"]) < 1e-6
+        assert abs(r["loss"] - a[2]) <= 1e-5 * abs(a[2])
+        assert (r["z"].numpy() == a[7].numpy()).all()
+    # sample_from_model() on its own (mean_teacher_trainer.py:90-93)
+    with torch.no_grad():
+        tr.model.forward(x2, gt, training=True)
+        for e in E(n_samples, 80):
+            EPS.push(e)
+        out["sample_from_model"] = tr.sample_from_model().numpy().copy()
+
+    # ---------------- punet_pseudo_prediction / punet_prediction through their real bodies -------------------------
+    rng = np.random.default_rng(seeds[0])
+    tmp = tempfile.mkdtemp()
+    img_a = (rng.normal(size=(40, 56)) * 30 + 100).astype("float32")
+    img_b = (rng.normal(size=(80, 104)) * 30 + 100).astype("float32")  # 2 x 3 blocks of 40 with halo 8 below
+    out["img_a"], out["img_b"] = img_a, img_b
+    pa = os.path.join(tmp, "cellA_0.tif")
+    open(pa, "w").close()
+    IMAGES[pa] = img_a
+    for e in eps_draws(5, 1, L, seeds[2] + 90):
+        EPS.push(e)
+    punet_pseudo_prediction(tmp + "/", tmp + "/out/", m, prior_samples=5, device="cpu", cellname_="cellA", split_name="val")
+    assert not EPS.q
+    out["pseudo_mean"] = WRITTEN[tmp + "/out/annotations/val/cellA/cellA_0.tif"]
+    out["pseudo_consensus"] = WRITTEN[tmp + "/out/consensus/val/cellA/cellA_0.tif"]
+    mo, co = O.pseudo_prediction(Po, cfg, img_a, eps_draws(5, 1, L, seeds[2] + 90))
+    assert np.abs(mo - out["pseudo_mean"]).max() < 1e-6 and (co == out["pseudo_consensus"]).all()
+    assert out["pseudo_consensus"].dtype == np.uint8 and 0 < out["pseudo_consensus"].mean() < 1
+    # punet_prediction: block 40 / halo 8 via a patched call (the reference hard-codes 384 / 64 at :45-46; the stand-in
+    # receives those and substitutes the small geometry so the fixture stays small)
+    pb = os.path.join(tmp, "imgB.tif")
+    open(pb, "w").close()
+    IMAGES[pb] = img_b
+    geo = {"block": (40, 40), "halo": (8, 8)}
+    real = te.util.prediction.predict_with_halo
+    import prob_utils.my_predictions.punet_predictions as pp
+    pp.predict_with_halo = lambda **kw: real(**{**kw, "block_shape": geo["block"], "halo": geo["halo"]})
+    n_tiles = len(list(O.halo_tiles(img_b.shape, geo["block"], geo["halo"])))
+    eps_tiles = [eps_draws(3, 1, L, seeds[2] + 100 + t) for t in range(n_tiles)]
+    for et in eps_tiles:
+        for e in et:
+            EPS.push(e)
+    punet_prediction(pb, tmp + "/pred", m, prior_samples=3, device="cpu")
+    assert not EPS.q
+    out["tiled_pred"] = WRITTEN[os.path.join(tmp + "/pred", "imgB.tif")].astype("float32")
+    out["tiled_geo"] = np.array(list(geo["block"]) + list(geo["halo"]) + [3, n_tiles], dtype=np.int64)
+    to = O.tiled_prediction(Po, cfg, img_b, eps_tiles, geo["block"], geo["halo"])
+    assert np.abs(to - out["tiled_pred"]).max() < 1e-6
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(f"[gen_golden] wrote {name}.npz ({os.path.getsize(os.path.join(HERE, name + '.npz')) / 1e6:.2f} MB)")
+
+
 def gen_plain_unet_case(name, nf, H, W, seed=1):
     """BASELINE.json configs[0]: plain Unet forward (prob_utils/my_models/unet.py, apply_last_layer=True) on one
     synthetic patch, CPU reference."""
@@ -387,6 +578,9 @@ def gen_plain_unet_case(name, nf, H, W, seed=1):
 
 
 if __name__ == "__main__":
+    if "--only-api" in sys.argv:
+        gen_api_case("api_small", [32, 64, 64, 96], B=2, H=32, W=32, n_samples=4)
+        sys.exit(0)
     if "--only-unet" in sys.argv:
         gen_plain_unet_case("plain_unet_256", [64, 128, 256, 512], 256, 256)
         sys.exit(0)
@@ -404,5 +598,7 @@ if __name__ == "__main__":
     gen_model_case("full_nf", [64, 128, 256, 512], fixed=True, B=1, C=1, H=64, W=64, n_list=[4], full_grads=False)
     # (5) one real iteration of every PUNet trainer
     gen_trainer_case("trainers_small", [32, 64, 64, 96], B=2, H=32, W=32, n_samples=4)
+    # (5b) model-API corners, validation loops, prediction bodies
+    gen_api_case("api_small", [32, 64, 64, 96], B=2, H=32, W=32, n_samples=4)
     # (6) BASELINE.json configs[0]: plain Unet forward, one 256x256x1 patch
     gen_plain_unet_case("plain_unet_256", [64, 128, 256, 512], 256, 256)

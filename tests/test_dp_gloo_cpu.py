@@ -107,17 +107,13 @@ class _PointwiseModel:
 
 
 def _tiled_reference(img, block, halo):
+    """The oracle's (recalled) predict_with_halo blocking with the pointwise stand-in as the per-tile prediction."""
     import numpy as np
-    from probabilistic_domain_adaptation_amd.my_predictions.punet_predictions import standardize
-    H, W = img.shape
+    from oracle import punet_oracle as O
     out = np.zeros_like(img)
-    pad = np.pad(img, ((halo, halo + block), (halo, halo + block)), mode="reflect")
-    for y0 in range(0, H, block):
-        for x0 in range(0, W, block):
-            y1, x1 = min(y0 + block, H), min(x0 + block, W)
-            oh, ow = -(-(y1 - y0 + 2 * halo) // 8) * 8, -(-(x1 - x0 + 2 * halo) // 8) * 8
-            t = standardize(pad[y0:y0 + oh, x0:x0 + ow])
-            out[y0:y1, x0:x1] = (1.0 / (1.0 + np.exp(-t.astype("float64"))))[halo:halo + y1 - y0, halo:halo + x1 - x0]
+    for (y0, y1, x0, x1) in O.halo_tiles(img.shape, (block, block), (halo, halo)):
+        t = O.standardize_np(O.load_halo_block(img, y0, x0, (block, block), (halo, halo)))
+        out[y0:y1, x0:x1] = (1.0 / (1.0 + np.exp(-t.astype("float64"))))[halo:halo + y1 - y0, halo:halo + x1 - x0]
     return out
 
 

@@ -1,0 +1,203 @@
+"""GPU: the corners of the model API (reconstruct / kl_divergence / elbo option space), the validation loops of the
+trainers, sample_from_model and the prediction bodies, against `api_small.npz` - produced by the REFERENCE's own methods
+(tests/golden/gen_golden.py::gen_api_case; file I/O, standardize and predict_with_halo are in-memory stand-ins there,
+the last two [recalled])."""
+import contextlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import punet_oracle as O
+
+pytestmark = pytest.mark.gpu
+L = 6
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def case(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "api_small.npz"))
+    B, C, H, W, s0, s1, s2, n = [int(v) for v in fx["meta"][:8]]
+    nf = [int(v) for v in fx["meta"][8:]]
+    cfg = O.PUNetConfig(C, 1, nf, L, 3, 1.0, consensus_masking=True, rl_swap=False)
+    Pnp = O.synth_params(cfg.spec(), s1)
+    E = lambda k, m: torch.randn(k, B, L, generator=torch.Generator().manual_seed(s2 + m))
+    return dict(fx=fx, nf=nf, B=B, H=H, W=W, n=n, cfg=cfg, Pnp=Pnp, Pt_np=O.synth_params(cfg.spec(), s1 + 1), E=E, s=(s0, s1, s2),
+                a=O.synth_batch(B, C, H, W, s0), b=O.synth_batch(B, C, H, W, s0 + 1))
+
+
+def _model(case, dev, pnp=None):
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    m = ProbabilisticUnet(1, 1, case["nf"], L, 3, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in (pnp or case["Pnp"]).items()})
+    return m
+
+
+def _close(got, ref, atol, rtol=0.0):
+    np.testing.assert_allclose(got.detach().cpu().numpy() if torch.is_tensor(got) else got, ref, atol=atol, rtol=rtol)
+
+
+def test_forward_sets_posterior_eagerly_and_kl_reconstruct(case, dev):
+    """forward(patch, segm, training=True) stores posterior_latent_space at once (probabilistic_unet.py:290-291);
+    kl_divergence() and reconstruct() in all their modes against the reference's values."""
+    fx, E = case["fx"], case["E"]
+    x, x1, x2, gt = case["a"]
+    m = _model(case, dev)
+    with torch.no_grad():
+        m.forward(x2.to(dev), gt.to(dev), training=True)
+        _close(m.posterior_latent_space.base_dist.loc, fx["post_mu"], 1e-4)
+        _close(m.posterior_latent_space.base_dist.scale, fx["post_sigma"], 0, 1e-4)
+        _close(m.kl_divergence(analytic=True), fx["kl_analytic"], 1e-3, 2e-4)
+        zg = torch.from_numpy(fx["z_given"]).to(dev)
+        _close(m.kl_divergence(analytic=False, z_posterior=zg), fx["kl_sampled_z"], 1e-3, 2e-4)
+        _close(m.kl_divergence(analytic=False, calculate_posterior=True, eps=E(1, 2)), fx["kl_sampled_calc"], 1e-3, 2e-4)
+        _close(m.reconstruct(z_posterior=zg), fx["recon_z"], 1e-3)
+        _close(m.reconstruct(calculate_posterior=True, eps=E(1, 3)), fx["recon_calc"], 1e-3)
+        # use_posterior_mean: the reference itself raises AttributeError here (Independent has no .loc, :318) - recorded in
+        # the fixture; the build implements the evident intent, checked against the oracle
+        assert int(fx["recon_mean_raises"][0]) == 1
+        Po = O.to_torch(case["Pnp"])
+        so = O.punet_forward(Po, case["cfg"], x2, gt, True)
+        ref = O.fcomb(Po, so["features"], so["posterior"][0], 3)
+        _close(m.reconstruct(use_posterior_mean=True), ref.numpy(), 1e-3)
+        assert tuple(m.unet_features.shape) == (case["B"], case["nf"][0], case["H"], case["W"])
+        _close(m.unet_features, so["features"].numpy(), 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("tag", ["sampledkl", "othertarget", "posteriormean"])
+def test_elbo_option_space(case, dev, tag):
+    """elbo(analytic_kl=False), elbo(segm != forward's segm), elbo(reconstruct_posterior_mean=True) through the drop-in
+    path (autograd-visible .grad): scalars and gradient norms vs the reference, every gradient vs the oracle's autograd."""
+    from probabilistic_domain_adaptation_amd.my_models import l2_regularisation
+    fx, E, cfg = case["fx"], case["E"], case["cfg"]
+    x, x1, x2, gt = case["a"]
+    B, H, W = case["B"], case["H"], case["W"]
+    consm = (torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(21)) > 0.4).float()
+    kw = dict(analytic_kl=False) if tag == "sampledkl" else dict(reconstruct_posterior_mean=True) if tag == "posteriormean" else {}
+    tgt = torch.roll(gt, shifts=3, dims=3) if tag == "othertarget" else gt
+    m = _model(case, dev)
+    m.forward(x2.to(dev), gt.to(dev), training=True)
+    elbo = m.elbo(tgt.to(dev), consm.to(dev), eps=E(1, 4), **kw)
+    reg = l2_regularisation(m.posterior) + l2_regularisation(m.prior) + l2_regularisation(m.fcomb.layers)
+    loss = -elbo + 1e-5 * reg
+    loss.backward()
+    torch.cuda.synchronize()
+    Pg = O.to_torch(case["Pnp"], requires_grad=True)
+    okw = dict(analytic_kl=False) if tag == "sampledkl" else dict(reconstruct_posterior_mean=True) if tag == "posteriormean" else {}
+    lo, aux = O.training_loss(Pg, cfg, x2, gt, consm, E(1, 4)[0], target=tgt, **okw)
+    go = O.grads_of(lo, Pg)
+    np.testing.assert_allclose(loss.item(), lo.item(), rtol=2e-4)
+    if tag != "posteriormean":  # the reference raises for that option; the other two are pinned by its own numbers
+        sc = fx[f"elbo_{tag}_scalars"]
+        np.testing.assert_allclose([loss.item(), m.reconstruction_loss.item(), m.mean_reconstruction_loss.item(), m.kl.item()],
+                                   [sc[0], sc[1], sc[2], sc[3]], rtol=2e-4)
+        for row, (k, p) in zip(fx[f"elbo_{tag}_grad_digest"], m.named_parameters()):
+            nrm = float(p.grad.double().pow(2).sum().sqrt())
+            assert abs(nrm - row[0]) <= 5e-3 * row[0] + 1e-7, (k, nrm, row[0])
+    bad = {}
+    for (k, ref), (_, p) in zip(go.items(), m.named_parameters()):
+        e = (p.grad.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-8)
+        if e > 5e-3:  # un-gated oracle ReLUs: a flip within fp32 rounding of 0 moves single entries by O(1e-3)
+            bad[k] = e
+    assert not bad, bad
+
+
+class _Queues:
+    """eps_source with one queue of draws per kind, consumed call by call."""
+
+    def __init__(self, **q):
+        self.q = {k: list(v) for k, v in q.items()}
+
+    def __call__(self, kind, n, b):
+        e = self.q[kind].pop(0)
+        assert e.shape[0] == n
+        return e
+
+    def empty(self):
+        return all(not v for v in self.q.values())
+
+
+def test_punet_trainer_validate(case, dev):
+    """PUNetTrainer._validate_impl (punet_trainer.py:52-97) over two batches: metric and loss vs the reference's."""
+    from probabilistic_domain_adaptation_amd.my_trainer import PUNetTrainer
+    fx, E = case["fx"], case["E"]
+    (x, _, _, gt), (xb, _, _, gtb) = case["a"], case["b"]
+    m = _model(case, dev)
+    tr = PUNetTrainer(name=None, train_loader=[], val_loader=[(x, gt), (xb, gtb)], model=m, optimizer=None, device=dev)
+    tr.eps_source = _Queues(student=[E(1, 10), E(1, 11)], val=[E(8, 20), E(8, 21)])
+    metric = tr._validate_impl(contextlib.nullcontext)
+    assert tr.eps_source.empty()
+    np.testing.assert_allclose(metric, fx["punet_val"][0], atol=2e-5)
+    np.testing.assert_allclose(tr.last_validation["loss"], fx["punet_val"][1], rtol=2e-4)
+
+
+@pytest.mark.parametrize("masking,tag", [(True, "mask"), (False, "weight")])
+def test_mean_teacher_validate_and_sample_from_model(case, dev, masking, tag):
+    """MeanTeacherTrainer._validate_impl (mean_teacher_trainer.py:142-191): metric, loss, gt metric, the last batch's
+    pseudo-label / consensus (bit-exact) and sample_from_model() output vs the reference's."""
+    from probabilistic_domain_adaptation_amd.my_trainer import MeanTeacherTrainer
+    fx, E, n = case["fx"], case["E"], case["n"]
+    m = _model(case, dev)
+    tr = MeanTeacherTrainer(name=None, train_loader=[], val_loader=[case["a"], case["b"]], model=m, optimizer=None, device=dev,
+                            do_consensus_masking=masking)
+    tr.teacher.load_state_dict({k: torch.from_numpy(v) for k, v in case["Pt_np"].items()})
+    tr.n_samples = n
+    tr.eps_source = _Queues(teacher=[E(n, 40), E(n, 41)], student=[E(1, 50), E(1, 51)], val=[E(n, 60), E(n, 61)])
+    metric = tr._validate_impl(contextlib.nullcontext)
+    assert tr.eps_source.empty()
+    ref = fx[f"mt_val_{tag}"]  # metric, loss, gt_metric
+    lv = tr.last_validation
+    np.testing.assert_allclose([metric, lv["gt_metric"]], [ref[0], ref[2]], atol=2e-5)
+    np.testing.assert_allclose(lv["loss"], ref[1], rtol=2e-4)
+    _close(lv["y"], fx[f"mt_val_{tag}_y"], 1e-4)
+    z = lv["z"].cpu().numpy()
+    assert z.dtype == fx[f"mt_val_{tag}_z"].dtype and int((z != fx[f"mt_val_{tag}_z"]).sum()) == 0
+    # sample_from_model() right after a training-mode forward (mean_teacher_trainer.py:90-93)
+    x, x1, x2, gt = case["a"]
+    with torch.no_grad():
+        tr.model.forward(x2.to(dev), gt.to(dev), training=True)
+        tr.eps_source = _Queues(val=[E(n, 80)])
+        _close(tr.sample_from_model(), fx["sample_from_model"], 1e-4)
+        # and the one the reference's logger branch took on the last validation batch's state (:186-187)
+        tr.model.forward(case["b"][2].to(dev), torch.from_numpy(fx[f"mt_val_{tag}_y"]).to(dev), training=True)
+        tr.eps_source = _Queues(val=[E(n, 70)])
+        _close(tr.sample_from_model(), fx[f"mt_val_{tag}_logged_samples"], 1e-4)
+
+
+def test_pseudo_prediction_and_tiled_prediction(case, dev):
+    """pseudo_predict_image vs what the reference's punet_pseudo_prediction wrote (mean 1e-4, consensus mask bit-exact);
+    predict_image vs what its punet_prediction wrote under the recalled predict_with_halo blocking."""
+    from probabilistic_domain_adaptation_amd.my_predictions import predict_image, pseudo_predict_image
+    fx = case["fx"]
+    s2 = case["s"][2]
+    m = _model(case, dev)
+    g = lambda k, seed: torch.randn(k, 1, L, generator=torch.Generator().manual_seed(seed))
+    mean, cons = pseudo_predict_image(m, fx["img_a"], prior_samples=5, eps=g(5, s2 + 90))
+    assert np.abs(mean - fx["pseudo_mean"]).max() < 1e-4
+    assert cons.dtype == np.uint8 and int((cons != fx["pseudo_consensus"]).sum()) == 0
+    bh, bw, hh, hw, n, nt = [int(v) for v in fx["tiled_geo"]]
+    eps = torch.stack([g(n, s2 + 100 + t)[:, 0] for t in range(nt)])  # [tiles, N, L]
+    for tile_batch in (1, 4):
+        pred = predict_image(m, fx["img_b"], prior_samples=n, block_shape=(bh, bw), halo=(hh, hw), tile_batch=tile_batch, eps=eps)
+        assert np.abs(pred - fx["tiled_pred"]).max() < 1e-4, tile_batch
+
+
+def test_predict_image_reference_geometry_against_oracle_tiling(case, dev):
+    """The reference's geometry (block 384, halo 64 -> 512 x 512 outer tiles, punet_predictions.py:45-46) on an image with
+    clipped last blocks, against the oracle's tiling built from O.mc_prediction per tile."""
+    from probabilistic_domain_adaptation_amd.my_predictions import predict_image
+    m = _model(case, dev)
+    img = (np.random.default_rng(5).normal(size=(600, 520)) * 20 + 90).astype("float32")
+    n, nt = 2, 4
+    eps = torch.randn(nt, n, L, generator=torch.Generator().manual_seed(6))
+    ref = O.tiled_prediction(O.to_torch(case["Pnp"]), case["cfg"], img, [eps[t][:, None] for t in range(nt)])
+    pred = predict_image(m, img, prior_samples=n, tile_batch=3, eps=eps)
+    assert pred.shape == img.shape and np.abs(pred - ref).max() < 1e-4

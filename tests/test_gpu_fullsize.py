@@ -59,8 +59,64 @@ def test_inference_fullsize_against_oracle(dev, channels, size, n):
     safe = ((probs - 0.9).abs().min(0).values > 1e-5) & ((probs - 0.1).abs().min(0).values > 1e-5)
     assert safe.float().mean().item() > 0.999
     assert torch.equal(cz.cpu()[safe], ref[safe])
+    # the full count, near-threshold pixels included: a pixel can only differ where some sigmoid sits within
+    # rounding of 0.9 / 0.1, i.e. never more pixels than the unsafe ones
+    mism = int((cz.cpu() != ref).sum())
+    print(f"consensus mask: {mism} of {ref.numel()} pixels differ from the oracle ({int((~safe).sum())} within 1e-5 of a threshold)")
+    assert mism <= int((~safe).sum())
     assert 0.01 < ref.mean().item() < 0.99  # a non-trivial mask
     assert (ym.cpu() - probs.mean(0)).abs().max().item() < 1e-4
+
+
+def test_training_step_512_b1_against_oracle(dev):
+    """The production instantiations (persistent grids with tile wrap-around, 256 split-K slabs, XCD remap, fused pooling,
+    LDS-DMA weight staging) against the CPU oracle's autograd at the bench's patch size and filters: one 512 x 512 patch,
+    nf = [64, 128, 256, 512], consensus-masked BCE ELBO + L2 regulariser - loss scalars and ALL 100 parameter gradients.
+    The oracle's ReLUs are gated by the GPU's own forward activations (which are checked first), so that a
+    pre-activation within fp32 rounding of 0 cannot turn into an O(1) difference of single gradient entries."""
+    m = _model(dev)
+    eng, lay, flat = m.engine, m.layout, m.flat_params
+    cfg = O.PUNetConfig(1, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    x, x1, x2, y = O.synth_batch(1, 1, 512, 512, 0)
+    g = torch.Generator().manual_seed(4)
+    eps_s = torch.randn(1, 6, generator=g)
+    y_soft = (0.8 * y + 0.1 * torch.rand(y.shape, generator=g)).clamp(0, 1)  # a soft pseudo-label, as the trainers feed
+    consm = (torch.rand(y.shape, generator=g) > 0.3).float()
+    taps = {}
+    st = eng.elbo_forward(flat, eng.to_nhwc(x2.to(dev)), y_soft.to(dev), consm.to(dev), eps_s.to(dev), "bce", 1.0, 1.0, True, taps)
+    gflat = torch.full((lay.numel,), float("nan"), device=dev)
+    eng.elbo_backward(flat, gflat, st, accumulate=False)
+    reg, norms = eng.l2_reg(flat)
+    eng.l2_reg_add_grad(flat, gflat, norms, 1e-5)
+    torch.cuda.synchronize()
+    gates = {k[5:]: (v.t > 0).permute(0, 3, 1, 2).cpu() for k, v in taps.items() if k.startswith("conv:")}
+    otaps = {}
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    O.RELU_GATES = gates
+    try:
+        lo, aux = O.training_loss(P, cfg, x2, y_soft, consm, eps_s[0:1].reshape(1, 6), taps=otaps)
+        go = O.grads_of(lo, P)
+    finally:
+        O.RELU_GATES = None
+    # forward: block outputs (under the GPU's gates the oracle's activations must still agree, else the gates were wrong)
+    for k, v in otaps.items():
+        got = taps[k].t.permute(0, 3, 1, 2).cpu()
+        assert (got - v.detach()).abs().max().item() <= 2e-4 * (v.abs().max().item() + 1e-9), k
+    rec, kl = st["rec"].item(), st["kl"].item()
+    np.testing.assert_allclose([rec, kl, reg.item()],
+                               [aux["reconstruction_loss"].item(), aux["kl"].item(), aux["reg"].item()], rtol=2e-4)
+    gv = lay.views(gflat)
+    worst, bad = 0.0, {}
+    for k, ref in go.items():
+        got = gv[k].cpu()
+        assert torch.isfinite(got).all(), k
+        e = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-8)
+        worst = max(worst, e)
+        if e > 5e-4:
+            bad[k] = e
+    print(f"\n512x512 B=1 training step: worst gradient error {worst:.2e} of the tensor max over {len(go)} tensors")
+    assert len(go) == 100 and not bad, bad
 
 
 def test_mean_teacher_step_batch4_512_is_bit_reproducible(dev):

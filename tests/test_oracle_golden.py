@@ -164,3 +164,54 @@ def test_trainer_steps(golden_dir):
     r = O.punet_step(P, cfg, O.AdamState(P, lr=lr), xs, ys, eps_sup, consm=zmask)
     np.testing.assert_allclose(r["loss"].item(), fx["pseudo_loss"][0], rtol=2e-5)
     _check_digest(P, fx["pseudo_student"], lr, "pseudo")
+
+
+def test_api_corners_validation_and_prediction(golden_dir):
+    """api_small.npz (gen_golden.py::gen_api_case): kl_divergence / reconstruct / elbo option space, the two validation
+    loops, sample_from_model, punet_pseudo_prediction and punet_prediction as the reference's own code produced them."""
+    fx = _load(golden_dir, "api_small")
+    B, C, H, W, s0, s1, s2, n = [int(v) for v in fx["meta"][:8]]
+    nf = [int(v) for v in fx["meta"][8:]]
+    cfg = O.PUNetConfig(C, 1, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    Pnp = O.synth_params(cfg.spec(), s1)
+    P = O.to_torch(Pnp)
+    E = lambda k, m: _eps(k, B, 6, s2 + m)
+    a, b = O.synth_batch(B, C, H, W, s0), O.synth_batch(B, C, H, W, s0 + 1)
+    x, x1, x2, gt = a
+    with torch.no_grad():
+        st = O.punet_forward(P, cfg, x2, gt, True)
+        (mq, sq), (mp, sp) = st["posterior"], st["prior"]
+        np.testing.assert_allclose(mq.numpy(), fx["post_mu"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(sq.numpy(), fx["post_sigma"], rtol=1e-5)
+        np.testing.assert_allclose(O.kl_diag_gaussians(mq, sq, mp, sp).numpy(), fx["kl_analytic"], rtol=1e-5, atol=1e-6)
+        zg = torch.from_numpy(fx["z_given"])
+        np.testing.assert_allclose(O.kl_sampled(mq, sq, mp, sp, zg).numpy(), fx["kl_sampled_z"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(O.kl_sampled(mq, sq, mp, sp, mq + sq * E(1, 2)[0]).numpy(), fx["kl_sampled_calc"], rtol=1e-5,
+                                   atol=1e-5)
+        np.testing.assert_allclose(O.fcomb(P, st["features"], zg, 3).numpy(), fx["recon_z"], atol=1e-5)
+        np.testing.assert_allclose(O.fcomb(P, st["features"], mq + sq * E(1, 3)[0], 3).numpy(), fx["recon_calc"], atol=1e-5)
+    consm = (torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(21)) > 0.4).float()
+    for tag, kw, tgt in (("sampledkl", dict(analytic_kl=False), gt), ("othertarget", dict(), torch.roll(gt, shifts=3, dims=3))):
+        Pg = O.to_torch(Pnp, requires_grad=True)
+        lo, aux = O.training_loss(Pg, cfg, x2, gt, consm, E(1, 4)[0], target=tgt, **kw)
+        sc = fx[f"elbo_{tag}_scalars"]
+        np.testing.assert_allclose([lo.item(), aux["reconstruction_loss"].item(), aux["mean_reconstruction_loss"].item(),
+                                    aux["kl"].item(), aux["reg"].item()], sc, rtol=1e-5)
+        for row, g in zip(fx[f"elbo_{tag}_grad_digest"], O.grads_of(lo, Pg).values()):
+            assert abs(float(g.double().pow(2).sum().sqrt()) - row[0]) <= 1e-4 * row[0] + 1e-8
+    mo, lo_ = O.punet_validate(P, cfg, [(x, gt), (b[0], b[3])], [E(1, 10)[0], E(1, 11)[0]], [E(8, 20), E(8, 21)])
+    np.testing.assert_allclose([mo, lo_], fx["punet_val"], rtol=1e-5)
+    Pt = O.to_torch(O.synth_params(cfg.spec(), s1 + 1))
+    for masking, tag in ((True, "mask"), (False, "weight")):
+        r = O.mean_teacher_validate(P, Pt, cfg, [a, b], [E(n, 40), E(n, 41)], [E(1, 50)[0], E(1, 51)[0]], [E(n, 60), E(n, 61)],
+                                    masking)
+        np.testing.assert_allclose([r["metric"], r["loss"], r["gt_metric"]], fx[f"mt_val_{tag}"], rtol=1e-5)
+        assert (r["z"].numpy() == fx[f"mt_val_{tag}_z"]).all()
+        np.testing.assert_allclose(r["y"].numpy(), fx[f"mt_val_{tag}_y"], atol=1e-6)
+    g1 = lambda k, seed: torch.randn(k, 1, 6, generator=torch.Generator().manual_seed(seed))
+    mean, cons = O.pseudo_prediction(P, cfg, fx["img_a"], g1(5, s2 + 90))
+    np.testing.assert_allclose(mean, fx["pseudo_mean"], atol=1e-6)
+    assert (cons == fx["pseudo_consensus"]).all()
+    bh, bw, hh, hw, ns, nt = [int(v) for v in fx["tiled_geo"]]
+    tiled = O.tiled_prediction(P, cfg, fx["img_b"], [g1(ns, s2 + 100 + t) for t in range(nt)], (bh, bw), (hh, hw))
+    np.testing.assert_allclose(tiled, fx["tiled_pred"], atol=1e-6)
