@@ -13,8 +13,10 @@ from __future__ import annotations
 import contextlib
 import os
 import time
+import warnings
 
 import torch
+import torch.distributed as dist
 
 
 class _Progress:
@@ -28,10 +30,78 @@ class _Progress:
         pass
 
 
+# ---------------------------------------------------------------------------------------- data-parallel control plane
+def dp_world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def dp_rank():
+    return dist.get_rank() if dp_world() > 1 else 0
+
+
+def _comm_device(device):
+    """Collectives of an RCCL ("nccl") group need device tensors, gloo takes CPU tensors."""
+    return device if dp_world() > 1 and dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def allreduce_scalars(values, device, op="mean"):
+    """All-reduce a short list of host floats over the ranks (the validation metric and the logged loss, so
+    that ReduceLROnPlateau, the best-checkpoint rule and early stopping decide identically everywhere).  fp64 on the
+    wire; identity in a single process."""
+    w = dp_world()
+    if w == 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=_comm_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.MIN if op == "min" else dist.ReduceOp.SUM)
+    if op == "mean":
+        t /= w
+    return [float(v) for v in t.cpu().tolist()]
+
+
+def broadcast_tensors(tensors, device, src=0):
+    """Make every rank hold rank `src`'s values of the given (flat) tensors, in place."""
+    if dp_world() == 1:
+        return
+    cd = _comm_device(device)
+    for t in tensors:
+        if t.device == cd:
+            dist.broadcast(t, src=src)
+        else:
+            buf = t.detach().to(cd)
+            dist.broadcast(buf, src=src)
+            with torch.no_grad():
+                t.copy_(buf)
+
+
+class RankShard:
+    """View of a loader that yields every world-th batch, starting at `rank`; all ranks get the same number of batches
+    (the remainder is dropped), so that the per-step gradient all-reduce always has all its participants."""
+
+    def __init__(self, loader, rank=None, world=None):
+        self.loader = loader
+        self.rank = dp_rank() if rank is None else rank
+        self.world = dp_world() if world is None else world
+
+    def __len__(self):
+        return len(self.loader) // self.world
+
+    def __iter__(self):
+        n = len(self)
+        for i, batch in enumerate(self.loader):
+            if i >= n * self.world:
+                break
+            if i % self.world == self.rank:
+                yield batch
+
+
 class DefaultTrainer:
     def __init__(self, name=None, train_loader=None, val_loader=None, model=None, loss=None, optimizer=None, metric=None,
                  device=None, lr_scheduler=None, log_image_interval=100, mixed_precision=True, early_stopping=None,
-                 logger=None, logger_kwargs=None, save_root=None, compile_model=None, rank=None, **unused):
+                 logger=None, logger_kwargs=None, save_root=None, compile_model=None, rank=None, shard_loaders=False,
+                 **unused):
+        """shard_loaders (extension, data parallel): False = the caller hands every rank its own loader shard (e.g. a
+        DistributedSampler) - fit() then checks that all ranks see the same number of batches; True = every rank was handed
+        the SAME loader and takes every world-th batch of it (RankShard)."""
         self.name = name
         self.train_loader, self.val_loader = train_loader, val_loader
         self.model, self.loss, self.optimizer, self.metric = model, loss, optimizer, metric
@@ -42,10 +112,13 @@ class DefaultTrainer:
         self.early_stopping = early_stopping
         self.logger = None  # tensorboard loggers are out of scope
         self.save_root = save_root
+        self.shard_loaders = shard_loaders
         self._iteration, self._epoch = 0, 0
         self.max_iteration, self.max_epoch = 10 ** 9, 10 ** 9
         self._best_metric = float("inf")
         self.train_time = 0.0
+        self.last_loss = None
+        self.last_epoch_loss = float("nan")  # logged training loss of the last epoch's last step, mean over ranks
 
     # ------------------------------------------------------------------ checkpoints
     @property
@@ -53,24 +126,45 @@ class DefaultTrainer:
         root = self.save_root if self.save_root is not None else "."
         return os.path.join(root, "checkpoints", self.name or "punet")
 
+    def _init_record(self):
+        """[recalled] torch_em stores the trainer's constructor arguments under "init" so that a checkpoint can rebuild
+        its trainer; loaders / model / optimizer objects are not serialisable here, so only their class names go in."""
+        return {"trainer_class": type(self).__module__ + "." + type(self).__name__, "name": self.name,
+                "model_class": type(self.model).__name__ if self.model is not None else None,
+                "optimizer_class": type(self.optimizer).__name__ if self.optimizer is not None else None,
+                "device": str(self.device), "mixed_precision": self.mixed_precision,
+                "log_image_interval": self.log_image_interval}
+
     def save_checkpoint(self, name, current_metric, best_metric, train_time=0.0, **extra_save_dict):
-        os.makedirs(self.checkpoint_folder, exist_ok=True)
-        save_dict = {"iteration": self._iteration, "epoch": self._epoch, "best_epoch": getattr(self, "_best_epoch", 0),
-                     "best_metric": best_metric, "current_metric": current_metric, "train_time": train_time,
-                     "model_state": {k: v.detach().cpu().contiguous() for k, v in self.model.state_dict().items()},
-                     "optimizer_state": self.optimizer.state_dict() if self.optimizer is not None else None}
-        if self.lr_scheduler is not None:
-            save_dict["scheduler_state"] = self.lr_scheduler.state_dict()
-        for k, v in extra_save_dict.items():
-            save_dict[k] = {kk: vv.detach().cpu().contiguous() for kk, vv in v.items()} if isinstance(v, dict) else v
-        torch.save(save_dict, os.path.join(self.checkpoint_folder, f"{name}.pt"))
+        """torch_em-style `best.pt` / `latest.pt`.  Under data parallelism rank 0 writes (the replicas are identical),
+        the others wait at the barrier so that nobody reads a half-written file."""
+        if dp_rank() == 0:
+            os.makedirs(self.checkpoint_folder, exist_ok=True)
+            save_dict = {"iteration": self._iteration, "epoch": self._epoch, "best_epoch": getattr(self, "_best_epoch", 0),
+                         "best_metric": best_metric, "current_metric": current_metric, "train_time": train_time,
+                         "init": self._init_record(),
+                         "model_state": {k: v.detach().cpu().contiguous() for k, v in self.model.state_dict().items()},
+                         "optimizer_state": self.optimizer.state_dict() if self.optimizer is not None else None}
+            if self.lr_scheduler is not None:
+                save_dict["scheduler_state"] = self.lr_scheduler.state_dict()
+            for k, v in extra_save_dict.items():
+                save_dict[k] = {kk: vv.detach().cpu().contiguous() for kk, vv in v.items()} if isinstance(v, dict) else v
+            path = os.path.join(self.checkpoint_folder, f"{name}.pt")
+            torch.save(save_dict, path + ".tmp")
+            os.replace(path + ".tmp", path)
+        if dp_world() > 1:
+            dist.barrier()
 
     def load_checkpoint(self, checkpoint="best"):
         path = checkpoint if os.path.isfile(str(checkpoint)) else os.path.join(self.checkpoint_folder, f"{checkpoint}.pt")
         save_dict = torch.load(path, map_location="cpu", weights_only=False)
         self.model.load_state_dict(save_dict["model_state"])
         if self.optimizer is not None and save_dict.get("optimizer_state") is not None:
-            self.optimizer.load_state_dict(save_dict["optimizer_state"])
+            try:
+                self.optimizer.load_state_dict(save_dict["optimizer_state"])
+            except (KeyError, ValueError, RuntimeError) as e:  # a foreign optimizer's state: keep the weights, restart the moments
+                warnings.warn(f"optimizer_state of {path} does not fit {type(self.optimizer).__name__} ({e!r}); "
+                              "continuing with fresh optimizer state")
         if self.lr_scheduler is not None and "scheduler_state" in save_dict:
             self.lr_scheduler.load_state_dict(save_dict["scheduler_state"])
         self._iteration, self._epoch = save_dict["iteration"], save_dict["epoch"]
@@ -89,6 +183,48 @@ class DefaultTrainer:
             best_metric = self._best_metric
         return best_metric
 
+    # ------------------------------------------------------------------ data parallel
+    def _replicated_tensors(self):
+        """Everything that must be identical on all ranks before the first step: student (and teacher) weights and the
+        optimizer's moments.  Flat buffers when the objects have them, per-tensor otherwise."""
+        out = []
+        for mod in (self.model, getattr(self, "teacher", None)):
+            if mod is None:
+                continue
+            flat = getattr(mod, "flat_params", None)
+            out += [flat] if flat is not None else [p.data for p in mod.parameters()]
+        opt = self.optimizer
+        if opt is not None:
+            if hasattr(opt, "exp_avg"):
+                out += [opt.exp_avg, opt.exp_avg_sq]
+            else:
+                for stt in opt.state.values():
+                    out += [v for v in stt.values() if torch.is_tensor(v) and v.numel() > 1]
+        return out
+
+    def _dp_prepare(self):
+        """Start of fit() under torch.distributed: replicate rank 0's state (a model built with seed=None differs per
+        process), shard or verify the loaders."""
+        if dp_world() == 1:
+            return
+        broadcast_tensors(self._replicated_tensors(), self.device, src=0)
+        step = getattr(self.optimizer, "step_count", None)
+        if step is not None:
+            self.optimizer.step_count = int(allreduce_scalars([step], self.device, "max")[0])
+        for attr in ("train_loader", "val_loader", "source_train_loader", "target_train_loader"):
+            ld = getattr(self, attr, None)
+            if ld is None or isinstance(ld, RankShard):
+                continue
+            if self.shard_loaders:
+                setattr(self, attr, RankShard(ld))
+            else:
+                n = len(ld)
+                lo, = allreduce_scalars([n], self.device, "min")
+                hi, = allreduce_scalars([n], self.device, "max")
+                if lo != hi:
+                    raise RuntimeError(f"{attr}: ranks see {int(lo)}..{int(hi)} batches per epoch; every rank must step the "
+                                       "same number of times (pass equal shards, or shard_loaders=True with one common loader)")
+
     # ------------------------------------------------------------------ the loop
     def _backprop(self, loss):
         loss.backward()
@@ -100,6 +236,7 @@ class DefaultTrainer:
                 and load_from_checkpoint is None:
             load_from_checkpoint = "latest"
         best_metric = self._initialize(iterations, load_from_checkpoint, epochs)
+        self._dp_prepare()
         progress = progress or _Progress(self.max_iteration)
         forward_context = contextlib.nullcontext
         t0 = time.time()
@@ -108,8 +245,11 @@ class DefaultTrainer:
             current_metric = float("nan")
             if self.val_loader is not None:
                 current_metric = self._validate_impl(forward_context)
-                if self.lr_scheduler is not None:
-                    self.lr_scheduler.step(current_metric)
+            loss = float(self.last_loss) if self.last_loss is not None else float("nan")
+            # ONE scalar all-reduce per epoch: every rank steps the scheduler / picks "best" on the same numbers
+            current_metric, self.last_epoch_loss = allreduce_scalars([current_metric, loss], self.device, "mean")
+            if self.val_loader is not None and self.lr_scheduler is not None:
+                self.lr_scheduler.step(current_metric)
             self._epoch += 1
             total = self.train_time + time.time() - t0
             if self.save_root is not None or self.name is not None:
@@ -118,6 +258,8 @@ class DefaultTrainer:
                     self._best_epoch = self._epoch
                     self.save_checkpoint("best", current_metric, best_metric, train_time=total)
                 self.save_checkpoint("latest", current_metric, best_metric, train_time=total)
+                if save_every_kth_epoch and self._epoch % save_every_kth_epoch == 0:
+                    self.save_checkpoint(f"epoch-{self._epoch}", current_metric, best_metric, train_time=total)
         self._best_metric = best_metric
         return best_metric
 

@@ -64,15 +64,63 @@ class FusedAdam(torch.optim.Optimizer):
         self.fused_step()
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(),
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        """torch.optim.Adam's layout (what the reference's checkpoints hold under "optimizer_state", LIVECell/livecell_mt.py:83
+        + torch_em's save_checkpoint): state[i] = {step, exp_avg, exp_avg_sq} per parameter in state-dict order, moments in
+        the parameter's logical [cout, cin, ky, kx] shape; param_groups with torch's Adam defaults.  A checkpoint written
+        here resumes under torch.optim.Adam and vice versa."""
+        lay = self.model.layout
+        state = {}
+        if self.step_count > 0:
+            m_views, v_views = lay.views(self.exp_avg), lay.views(self.exp_avg_sq)
+            for i, name in enumerate(m_views):
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": m_views[name].detach().cpu().contiguous(),
+                            "exp_avg_sq": v_views[name].detach().cpu().contiguous()}
+        groups = []
+        for g in self.param_groups:
+            d = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False}
+            d.update({k: v for k, v in g.items() if k not in d and k != "params"})  # e.g. a scheduler's initial_lr
+            d["params"] = list(range(len(lay.entries)))
+            groups.append(d)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self.step_count = sd["step"]
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+        """Accepts torch.optim.Adam's layout (above; also from a reference checkpoint) and this build's round-1 flat layout
+        {step, exp_avg, exp_avg_sq}."""
+        lay = self.model.layout
+        if "state" in sd:
+            st = sd["state"]
+            if len(st) not in (0, len(lay.entries)):
+                raise ValueError(f"optimizer state has {len(st)} parameter entries, the model has {len(lay.entries)}")
+            g0 = sd["param_groups"][0] if sd.get("param_groups") else {}
+            if g0.get("amsgrad") or g0.get("weight_decay"):
+                raise ValueError("FusedAdam implements plain Adam (no amsgrad, no weight decay)")
+            self.step_count = 0
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            if st:
+                m_views, v_views = lay.views(self.exp_avg), lay.views(self.exp_avg_sq)
+                steps = set()
+                with torch.no_grad():
+                    for i, name in enumerate(m_views):
+                        e = st[i] if i in st else st[str(i)]
+                        if tuple(e["exp_avg"].shape) != tuple(m_views[name].shape):
+                            raise ValueError(f"optimizer state {i} ({name}): shape {tuple(e['exp_avg'].shape)} != "
+                                             f"{tuple(m_views[name].shape)}")
+                        m_views[name].copy_(e["exp_avg"])
+                        v_views[name].copy_(e["exp_avg_sq"])
+                        steps.add(int(float(e["step"])))
+                if len(steps) != 1:
+                    raise ValueError(f"per-parameter step counts differ ({sorted(steps)}); the fused kernel keeps one")
+                self.step_count = steps.pop()
+        else:
+            self.step_count = sd["step"]
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        for g, s_ in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v for k, v in s_.items() if k != "params"})
 
 
 def ema_update(model: ProbabilisticUnet, teacher: ProbabilisticUnet, momentum: float):

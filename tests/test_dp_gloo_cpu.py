@@ -151,3 +151,135 @@ def test_tiled_prediction_sharded_over_ranks_world2():
     for rank, err, tot in res:
         assert err < 1e-6
         assert abs(tot - float(single.sum())) < 1e-2
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fit() under data parallelism: the control plane of my_trainer/default_trainer.py with a CPU stand-in
+# trainer (the HIP trainers inherit exactly this fit(); their per-iteration bodies need the GPU)
+# ------------------------------------------------------------------------------------------------------------------
+def _make_dp_trainer(rank, save_root, shard):
+    import torch.nn as nn
+    from probabilistic_domain_adaptation_amd.my_trainer.default_trainer import DefaultTrainer
+
+    class _Toy(DefaultTrainer):
+        """Linear regression; the validation metric is RANK-LOCAL and differs between the ranks' shards by construction."""
+
+        def _train_epoch_impl(self, progress, forward_context, backprop):
+            from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+            for x, y in self.train_loader:
+                self.optimizer.zero_grad()
+                loss = ((self.model(x) - y) ** 2).mean()
+                loss.backward()
+                flat = torch.cat([p.grad.reshape(-1) for p in self.model.parameters()])
+                scale = FU.allreduce_grads(flat)  # the same call the fused steps make
+                off = 0
+                for p in self.model.parameters():
+                    p.grad.copy_(flat[off:off + p.numel()].view_as(p) * scale)
+                    off += p.numel()
+                self.optimizer.step()
+                self.last_loss = loss.detach()
+                self._iteration += 1
+                progress.update(1)
+            return 0.0
+
+        def _validate_impl(self, forward_context):
+            self.seen_val = [float(x.sum()) for x, _ in self.val_loader]
+            # epoch 0: both fine; afterwards rank 0's shard "improves" and rank 1's "stalls" - rank-local decisions would differ
+            r = torch.distributed.get_rank()
+            self.local_metrics = getattr(self, "local_metrics", [])
+            m = 1.0 / (1 + self._epoch) if r == 0 else 1.0 + 0.5 * self._epoch
+            self.local_metrics.append(m)
+            return m
+
+    torch.manual_seed(100 + rank)  # different initial weights per rank, as with seed=None models
+    model = nn.Linear(4, 1)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.5, patience=0)
+    g = torch.Generator().manual_seed(5)
+    data = [(torch.randn(8, 4, generator=g), torch.randn(8, 1, generator=g)) for _ in range(5)]
+    if not shard:  # caller-side sharding: rank r holds batches r, r+2 (equal counts)
+        data = data[rank:4:2]
+    tr = _Toy(name="toy", train_loader=data, val_loader=data, model=model, optimizer=opt, device="cpu", lr_scheduler=sched,
+              save_root=save_root, shard_loaders=shard)
+    return tr
+
+
+def _worker_fit(rank, world, port, q, save_root, shard):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = _make_dp_trainer(rank, save_root, shard)
+    w0 = torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()]).clone()
+    best = tr.fit(epochs=3)
+    w = torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()])
+    lrs = [g["lr"] for g in tr.optimizer.param_groups]
+    q.put((rank, w0.tolist(), w.tolist(), lrs, best, tr.local_metrics, tr.last_epoch_loss, len(tr.train_loader), tr.seen_val))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_fit(tmp_path, shard):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fit, args=(r, 2, port, q, str(tmp_path), shard)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_fit_world2_same_lr_decision_one_checkpoint(tmp_path):
+    """Two ranks with different initial weights and different validation shards: rank 0's state is broadcast at the start,
+    the validation metric is all-reduced (mean) before ReduceLROnPlateau and the best-checkpoint rule, so both ranks end
+    with the same LR and bit-equal weights; only rank 0 writes best.pt / latest.pt."""
+    (r0, w00, w0, lr0, best0, loc0, el0, n0, _), (r1, w01, w1, lr1, best1, loc1, el1, n1, _) = _run_fit(tmp_path, False)
+    assert w00 != w01            # the processes really started apart ...
+    assert w0 == w1              # ... and ended bit-equal
+    assert loc0 != loc1          # rank-local metrics differ: 1, .5, .33 vs 1, 1.5, 2
+    assert lr0 == lr1 == [1e-2 * 0.25]  # mean metric 1.0, 1.0, 1.17 with patience 0: reduced after epochs 1 and 2 on BOTH
+    #                                     ranks; rank-local rules would have left rank 0 (always improving) at 1e-2
+    assert best0 == best1 == 1.0 and el0 == el1
+    files = sorted(os.listdir(os.path.join(str(tmp_path), "checkpoints", "toy")))
+    assert files == ["best.pt", "latest.pt"], files
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoints", "toy", "latest.pt"), weights_only=False)
+    assert ck["epoch"] == 3 and ck["current_metric"] == (1.0 / 3 + 2.0) / 2 and "init" in ck
+    assert torch.cat([v.reshape(-1) for v in ck["model_state"].values()]).tolist() == w0
+
+
+def test_fit_world2_shards_a_common_loader(tmp_path):
+    """shard_loaders=True: both ranks were handed the same 5-batch loader; each takes every second batch, the odd one out is
+    dropped so that both step twice per epoch."""
+    (r0, _, w0, _, _, _, _, n0, seen0), (r1, _, w1, _, _, _, _, n1, seen1) = _run_fit(tmp_path, True)
+    assert n0 == n1 == 2 and w0 == w1
+    assert len(seen0) == len(seen1) == 2 and not set(seen0) & set(seen1)
+
+
+def _worker_unequal(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr = _make_dp_trainer(rank, None, False)
+    tr.train_loader = tr.train_loader[:1 + rank]
+    try:
+        tr.fit(epochs=1)
+        q.put((rank, "no error"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fit_world2_refuses_unequal_shards():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_unequal, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all("same number of times" in msg for _, msg in res), res

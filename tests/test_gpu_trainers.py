@@ -224,3 +224,77 @@ def test_plain_unet_config0(golden_dir, dev):
     y = m(x.to(dev), False)
     torch.cuda.synchronize()
     assert np.abs(y.cpu().numpy() - fx["logits"]).max() < 1e-3
+
+
+def _mt_trainer(case, dev, tmp_path, fused=True, n_batches=2, **kw):
+    from probabilistic_domain_adaptation_amd.my_trainer import MeanTeacherTrainer
+    m = _model(case, dev)
+    tr = MeanTeacherTrainer(name="mt", train_loader=[case["batch"]] * n_batches, val_loader=None, model=m,
+                            optimizer=_optim(m, fused), device=dev, do_consensus_masking=True, save_root=str(tmp_path), **kw)
+    tr.n_samples = case["n"]
+    tr.eps_source = lambda kind, n, b: case["eps"][kind]
+    return tr
+
+
+def test_checkpoint_resume_equals_uninterrupted_run(case, dev, tmp_path):
+    """save -> load -> one more step == three uninterrupted steps, bit for bit (weights, teacher, Adam moments, step count);
+    `load_from_checkpoint` and the ckpt_model / ckpt_teacher constructor paths (mean_teacher_trainer.py:44-50)."""
+    import contextlib
+    a = _mt_trainer(case, dev, tmp_path)
+    a.fit(iterations=2)
+    assert a._iteration == 2
+    a.train_loader = [case["batch"]]
+    a._train_epoch_impl(_P(), contextlib.nullcontext, None)  # the third step, uninterrupted
+    b = _mt_trainer(case, dev, tmp_path, n_batches=1)
+    b.fit(iterations=3, load_from_checkpoint="latest")  # resumes at iteration 2, runs one step
+    torch.cuda.synchronize()
+    assert b._iteration == 3 and b.optimizer.step_count == a.optimizer.step_count == 3
+    assert torch.equal(a.model.flat_params, b.model.flat_params) and torch.equal(a.teacher.flat_params, b.teacher.flat_params)
+    assert torch.equal(a.optimizer.exp_avg, b.optimizer.exp_avg) and torch.equal(a.optimizer.exp_avg_sq, b.optimizer.exp_avg_sq)
+    # constructor paths: student and teacher initialised from two checkpoint files
+    path = os.path.join(str(tmp_path), "checkpoints", "mt", "latest.pt")
+    ck = torch.load(path, weights_only=False)
+    tpath = os.path.join(str(tmp_path), "teacher_as_model.pt")
+    torch.save({"model_state": ck["teacher_state"]}, tpath)
+    c = _mt_trainer(case, dev, tmp_path / "c", ckpt_model=path, ckpt_teacher=tpath)
+    for k, v in ck["model_state"].items():
+        assert torch.equal(c.model.state_dict()[k].cpu(), v), k
+    for k, v in ck["teacher_state"].items():
+        assert torch.equal(c.teacher.state_dict()[k].cpu(), v), k
+
+
+def test_optimizer_state_is_torch_adam_layout(case, dev, tmp_path):
+    """The checkpoint's optimizer_state is torch.optim.Adam's own layout: torch.optim.Adam loads what FusedAdam wrote (and
+    then steps like it), FusedAdam loads what torch.optim.Adam wrote."""
+    import contextlib
+    a = _mt_trainer(case, dev, tmp_path)
+    a.fit(iterations=2)
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoints", "mt", "latest.pt"), weights_only=False)
+    osd = ck["optimizer_state"]
+    assert set(osd) == {"state", "param_groups"} and len(osd["state"]) == 100 and osd["param_groups"][0]["params"] == list(range(100))
+    m2 = _model(case, dev)
+    m2.load_state_dict(ck["model_state"])
+    topt = torch.optim.Adam(m2.parameters(), lr=LR)
+    topt.load_state_dict(osd)  # shapes are the parameters' logical shapes
+    for (k, p), (_, v) in zip(m2.named_parameters(), a.model.layout.views(a.optimizer.exp_avg).items()):
+        assert torch.equal(topt.state[p]["exp_avg"], v), k
+        assert float(topt.state[p]["step"]) == 2.0
+    # one drop-in step under torch's Adam from that state == one fused step of the original trainer
+    tr2 = _mt_trainer(case, dev, tmp_path / "t", fused=False, n_batches=1)
+    tr2.model.load_state_dict(ck["model_state"])
+    tr2.teacher.load_state_dict(ck["teacher_state"])
+    tr2.optimizer.load_state_dict(osd)
+    tr2._train_epoch_impl(_P(), contextlib.nullcontext, lambda loss: (loss.backward(), tr2.optimizer.step()))
+    a.train_loader = [case["batch"]]
+    a._train_epoch_impl(_P(), contextlib.nullcontext, None)
+    torch.cuda.synchronize()
+    d = (tr2.model.flat_params - a.model.flat_params).abs().max().item()
+    assert d <= 2e-2 * LR, d
+    # and back: FusedAdam takes torch.optim.Adam's state_dict
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
+    m3 = _model(case, dev)
+    f3 = FusedAdam(m3, lr=LR)
+    f3.load_state_dict(tr2.optimizer.state_dict())
+    assert f3.step_count == 3
+    for (k, p), (_, v) in zip(tr2.model.named_parameters(), m3.layout.views(f3.exp_avg).items()):
+        assert torch.equal(tr2.optimizer.state[p]["exp_avg"], v), k
