@@ -15,6 +15,8 @@
  *    them under the reference's state-dict names/shapes [cout,cin,ky,kx] as permuted views of the same memory).
  *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work is enqueued on it,
  *    no hidden synchronisation, no host reads -> every call is hipGraph-capturable.
+ *  - no hidden process state: the library keeps nothing between calls except a per-device cache of the CU count;
+ *    every entry point may be called from several threads at once.
  *  - return 0 on success, negative on error (PUNET_ERR_ARG = -1 bad argument, PUNET_ERR_HIP = -2 launch failure);
  *    punet_last_error() returns a thread-local message.  Nothing throws across the ABI.
  *  - `workspace` pointers are caller-provided scratch; the matching *_workspace_floats() gives the required size.
@@ -45,10 +47,6 @@ int punet_conv_fwd(const float* x0, int c0, const float* x1, int c1, const float
 int punet_conv_dgrad(const float* dz, int cout, const float* w, int cin_total, int cin_off, int cin, float* dx,
                      const float* mask, int accumulate, int B, int H, int W, int ksize, void* stream);
 
-/* tuning knob of K1/K2: persistent grid size in workgroups per CU (default 3 = one residency round); 0 = one workgroup
- * per output tile. */
-int punet_set_conv_wg_per_cu(int n);
-
 /* ---- K2 fast form: the dgrad's weight slab is first brought into forward-kernel orientation,
  *      wt[k*k-1-t][cout][cin_total] = w[t][cin_total][cout] (once per step for all layers), after which the input gradient
  *      is exactly the K1 kernel.  cin_total, cin_off, cin multiples of 4. */
@@ -62,10 +60,18 @@ int punet_conv_dgrad_t(const float* dz, int cout, const float* wt, int cin_total
  *      planes[3][9][K/8][n_row][8] bf16, plane_stride elements apart; mode 0: K = cin, n = cout (forward);
  *      mode 1: K = cout, n = cin, taps flipped (input gradient).  The conv computes output channels
  *      [n_off, n_off + n_out) of the n_row available; mask/accumulate/relu/bias as in K1/K2. */
-/* bf16 products per fp32 product for K1x6/K2x6/K3x6 (process state): 6 (default) = fp32-accurate parity arithmetic;
- * 3 = two planes, hh+hm+mh, 16 significand bits; 1 = plain bf16.  3 and 1 are opt-in fast modes, the counterpart of the
- * reference scripts' mixed_precision=True (LIVECell/livecell_mt.py:107); they are NOT parity modes. */
-int punet_set_x6_products(int n);
+/* Arithmetic options of K1x6/K2x6/K3x6 travel WITH EACH CALL in an options word (no process state; thread-safe):
+ *   products: bf16 products per fp32 product - 6 (default) = fp32-accurate parity arithmetic; 3 = two planes, hh+hm+mh, 16
+ *     significand bits; 1 = plain bf16.  3 and 1 are opt-in fast modes, the counterpart of the reference scripts'
+ *     mixed_precision=True (LIVECell/livecell_mt.py:107); they are NOT parity modes.
+ *   shape: MFMA shape of the 3x3 forward / input-gradient kernels - 16 (default) = conv3x3_x6b_kernel on
+ *     v_mfma_f32_16x16x32_bf16 for layers whose contracted channel count is a multiple of 32 (the energy-cheaper shape of a
+ *     power-limited part, weights staged by LDS-DMA); 32 = conv3x3_x6_kernel on v_mfma_f32_32x32x16_bf16 (always used for
+ *     other channel counts and for 1x1).  Same results to rounding; every kernel test runs with both.
+ * opts = 0 selects both defaults. */
+#define PUNET_X6_OPTS(products, shape) ((int)(products) | ((int)(shape) << 8))
+/* compute units of the current device (grids are sized from it: persistent kernels launch one residency round) */
+int punet_compute_units(void);
 int punet_split_weights_x6(const float* w, void* planes, long plane_stride, int cin, int cout, int ksize, int mode,
                            void* stream);
 /* every 3x3 slab of a flat parameter buffer in ONE launch.  table (device, int64) has nconv+1 rows of 4:
@@ -75,7 +81,7 @@ int punet_split_weights_x6_batch(const float* flat, void* planes, const long* ta
                                  int mode, void* stream);
 int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride, int n_row,
                      int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
-                     int accumulate, int relu, int B, int H, int W, void* stream);
+                     int accumulate, int relu, int B, int H, int W, int opts, void* stream);
 /* The same with the ReLU gate as BITS (1/32 of the fp32 gate's traffic and no per-lane load chain in the epilogue).
  * A [B,H,W,C] activation has punet_gate_dwords(B,H,W,C) = B*H*ceil(W/32)*ceil(C/64)*64 dwords: the block {row y,
  * pixels 32t..32t+31, channels 64cb..64cb+63} owns dwords ((((b*H + y)*ceil(W/32) + t)*ceil(C/64) + cb)*64 + l),
@@ -87,19 +93,13 @@ size_t punet_gate_dwords(int B, int H, int W, int C);
 int punet_conv3x3_x6_gated(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
                            int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out,
                            const float* mask, const void* gate_bits, void* gate_out, int accumulate, int relu, int B,
-                           int H, int W, void* stream);
-/* MFMA shape of the 3x3 forward / input-gradient kernels (process state; $PUNET_X6_MFMA_SHAPE=32 at load time selects the
- * older kernel): 16 (default) = conv3x3_x6b_kernel on v_mfma_f32_16x16x32_bf16 for layers whose contracted channel count is
- * a multiple of 32 - the energy-cheaper shape of a power-limited part, weights staged by LDS-DMA; 32 =
- * conv3x3_x6_kernel on v_mfma_f32_32x32x16_bf16 (always used for other channel counts and for 1x1).  Same results to
- * rounding; every kernel test runs with both. */
-int punet_set_x6_mfma_shape(int shape /* 32 | 16 */);
+                           int H, int W, int opts, void* stream);
 /* Forward 3x3 convolution that ALSO writes AvgPool2d(2, 2) of its output (DownConvBlock = pool + 3 convs,
  * unet_blocks.py:17-24 / probabilistic_unet.py:54: the last conv of a block feeds the next block's pool): pool_out is
  * [B, H/2, W/2, n_out]; H and W must be even (ceil_mode never engages); bit-identical to punet_pool2x2_fwd of y. */
 int punet_conv3x3_x6_pooled(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
                             int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out,
-                            void* gate_out, float* pool_out, int relu, int B, int H, int W, void* stream);
+                            void* gate_out, float* pool_out, int relu, int B, int H, int W, int opts, void* stream);
 /* The same kernel for 1x1 convolutions (the Fcomb layers, probabilistic_unet.py:168-173): planes from
  * punet_split_weights_x6(..., ksize = 1, ...), c0/c1 multiples of 8; always the six-product parity arithmetic. */
 int punet_conv1x1_x6_gated(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
@@ -122,7 +122,7 @@ int punet_conv_wgrad(const float* x, int cs, const float* dz, int cout, float* d
 int punet_wgrad_x6_slices(int cs, int cout, int B, int H, int W); /* split-K slices (one resident workgroup per CU) */
 int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off,
                         float* dbias, float* workspace, int nslices, int B, int H, int W, int accumulate, float scale,
-                        void* stream);
+                        int opts, void* stream);
 
 /* ---- K1s: first-layer 3x3 conv with cin in 1..4 (image / [image, mask], probabilistic_unet.py:39-42,118) and its
  *      weight + bias gradient (no input gradient exists). */

@@ -21,23 +21,21 @@ _SIGS = {
     "punet_device_ok": (_i, []),
     "punet_conv_fwd": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "punet_conv_dgrad": (_i, [_p, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "punet_set_conv_wg_per_cu": (_i, [_i]),
     "punet_flip_transpose_weights": (_i, [_p, _p, _i, _i, _i, _p]),
     "punet_conv_dgrad_t": (_i, [_p, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "punet_set_x6_products": (_i, [_i]),
+    "punet_compute_units": (_i, []),
     "punet_split_weights_x6": (_i, [_p, _p, _l, _i, _i, _i, _i, _p]),
     "punet_split_weights_x6_batch": (_i, [_p, _p, _p, _i, _l, _i, _p]),
-    "punet_conv3x3_x6": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "punet_conv3x3_x6": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "punet_gate_dwords": (_sz, [_i, _i, _i, _i]),
-    "punet_conv3x3_x6_gated": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "punet_set_x6_mfma_shape": (_i, [_i]),
-    "punet_conv3x3_x6_pooled": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "punet_conv3x3_x6_gated": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "punet_conv3x3_x6_pooled": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "punet_conv1x1_x6_gated": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "punet_wgrad_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "punet_wgrad_slices": (_i, [_i, _i, _i, _i, _i]),
     "punet_wgrad_x6_slices": (_i, [_i, _i, _i, _i, _i]),
     "punet_conv_wgrad": (_i, [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
-    "punet_conv_wgrad_x6": (_i, [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "punet_conv_wgrad_x6": (_i, [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "punet_conv3x3_small_fwd": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "punet_small_wgrad_workspace_floats": (_sz, [_i, _i]),
     "punet_conv3x3_small_wgrad": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
@@ -81,7 +79,7 @@ _SIGS = {
     "punet_augment_view": (_i, [_p, _p, _p, _p, _i, _f, _f, _p, _p, _i, _i, _i, _i, _p]),
 }
 
-_NO_WRAP = {"punet_last_error", "punet_build_info", "punet_device_ok", "punet_wgrad_workspace_floats", "punet_gate_dwords",
+_NO_WRAP = {"punet_last_error", "punet_build_info", "punet_device_ok", "punet_compute_units", "punet_wgrad_workspace_floats", "punet_gate_dwords",
             "punet_wgrad_slices", "punet_wgrad_x6_slices", "punet_small_wgrad_workspace_floats", "punet_chan_sum_workspace_floats",
             "punet_dot_bwd_workspace_floats", "punet_loss_workspace_floats", "punet_standardize_workspace_doubles"}
 
@@ -119,6 +117,11 @@ def load():
 def last_error() -> str:
     load()
     return _fn["punet_last_error"]().decode()
+
+
+def x6_opts(products: int = 6, shape: int = 16) -> int:
+    """PUNET_X6_OPTS(products, shape) of punet_hip.h: the per-call options word of the split-plane kernels."""
+    return int(products) | (int(shape) << 8)
 
 
 def call(name, *args):

@@ -33,3 +33,16 @@ extern "C" int punet_device_ok(void) {
     }
     return 1;
 }
+
+int punet_num_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    __atomic_store_n(&cached[dev], n, __ATOMIC_RELAXED);
+    return n;
+}
+
+extern "C" int punet_compute_units(void) { return punet_num_cus(); }

@@ -41,6 +41,20 @@ int punet_launch_reduce_slabs_pair(const float* partial_w, size_t stride_w, int 
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// compute units of the current device (hipDeviceProp_t::multiProcessorCount; 256 on an MI355X), queried once per device;
+// 256 when no device can be queried (host-only calls such as punet_wgrad_x6_slices in a container without a GPU)
+int punet_num_cus();
+
+// decode the per-call options word of the split-plane kernels (PUNET_X6_OPTS in punet_hip.h); 0 = defaults
+static inline int punet_x6_planes_of(int opts) {  // bf16 planes per operand: 3 (six products), 2 (three), 1 (one)
+    const int p = opts & 0xff;
+    return p == 0 || p == 6 ? 3 : (p == 3 ? 2 : (p == 1 ? 1 : -1));
+}
+static inline int punet_x6_shape_of(int opts) {  // 16 or 32
+    const int s = (opts >> 8) & 0xff;
+    return s == 0 ? 16 : (s == 16 || s == 32 ? s : -1);
+}
+
 // C/D fragment map of v_mfma_f32_32x32x2_f32 (dtype independent on gfx950):
 //   col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 __device__ __forceinline__ int mfma32_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }

@@ -48,8 +48,7 @@ struct ConvArgs {
 };
 
 constexpr int TH = 8, TW = 32, TN = 64, CK = 8;
-constexpr int NUM_CU = 256;
-int g_conv_wg_per_cu = 3;  // persistent grid = this many workgroups per CU; 0 = one workgroup per tile (tuning knob)
+constexpr int WG_PER_CU = 3;  // persistent grid = one residency round (30.6 KB of LDS, 148 VGPRs: three workgroups per CU)
 
 struct TileInfo {
     int b, ty0, tx0, n0;
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
 template <int KS, bool TR>
 int launch_conv(ConvArgs& a, hipStream_t stream) {
     a.ntiles = a.B * ceil_div(a.H, TH) * ceil_div(a.W, TW) * ceil_div(a.n_total, TN);
-    const int cap = g_conv_wg_per_cu > 0 ? g_conv_wg_per_cu * NUM_CU : a.ntiles;
+    const int cap = WG_PER_CU * punet_num_cus();
     int grid = a.ntiles < cap ? a.ntiles : cap;
     conv_mfma_kernel<KS, TR><<<grid, 256, 0, stream>>>(a);
     PUNET_LAUNCH_CHECK("conv_mfma");
@@ -279,12 +278,6 @@ __global__ __launch_bounds__(256) void flip_transpose_kernel(const float* __rest
 }
 
 }  // namespace
-
-extern "C" int punet_set_conv_wg_per_cu(int n) {
-    PUNET_CHECK_ARG(n >= 0 && n <= 8, "punet_set_conv_wg_per_cu: 0..8");
-    g_conv_wg_per_cu = n;
-    return PUNET_OK;
-}
 
 extern "C" int punet_conv_fwd(const float* x0, int c0, const float* x1, int c1, const float* w, const float* bias,
                               int bias_img_stride, float* y, int cout, int B, int H, int W, int ksize, int relu,

@@ -36,7 +36,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TH = 8, TW = 32, TN = 64, CK = 8;
-constexpr int NUM_CU = 256;
+constexpr int WG_PER_CU = 2;  // persistent grid = one residency round (two workgroups per CU fit LDS and registers)
 
 struct ConvX6Args {
     const float* x0;
@@ -876,18 +876,7 @@ __global__ __launch_bounds__(256) void split_weights_x6_batch_kernel(const float
     }
 }
 
-int g_x6_wg_per_cu = 2;
-bool g_x6_shape16 = [] { const char* e = getenv("PUNET_X6_MFMA_SHAPE"); return !(e && e[0] == '3' && e[1] == '2'); }();  // default 16
 }  // namespace
-
-// shared with wgrad_x6.hip: bf16 planes per operand (3 = six products = the fp32-accurate parity arithmetic)
-int g_punet_x6_planes = 3;
-
-extern "C" int punet_set_x6_products(int n) {
-    PUNET_CHECK_ARG(n == 6 || n == 3 || n == 1, "punet_set_x6_products: 6 (fp32-accurate), 3 (16-bit significand) or 1 (bf16)");
-    g_punet_x6_planes = n == 6 ? 3 : (n == 3 ? 2 : 1);
-    return PUNET_OK;
-}
 
 extern "C" int punet_split_weights_x6(const float* w, void* planes, long plane_stride, int cin, int cout, int ksize, int mode,
                                       void* stream) {
@@ -921,37 +910,31 @@ extern "C" size_t punet_gate_dwords(int B, int H, int W, int C) {
 
 extern "C" int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
                                 int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out,
-                                const float* mask, int accumulate, int relu, int B, int H, int W, void* stream) {
+                                const float* mask, int accumulate, int relu, int B, int H, int W, int opts, void* stream) {
     return punet_conv3x3_x6_gated(x0, c0, x1, c1, wplanes, plane_stride, n_row, n_off, bias, bias_img_stride, y, n_out, mask,
-                                  nullptr, nullptr, accumulate, relu, B, H, W, stream);
+                                  nullptr, nullptr, accumulate, relu, B, H, W, opts, stream);
 }
 
 static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
                           int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
-                          const void* gate_bits, void* gate_out, int accumulate, int relu, int B, int H, int W, void* stream,
-                          float* pool_out = nullptr);
+                          const void* gate_bits, void* gate_out, int accumulate, int relu, int B, int H, int W, int opts,
+                          void* stream, float* pool_out = nullptr);
 
 extern "C" int punet_conv3x3_x6_gated(const float* x0, int c0, const float* x1, int c1, const void* wplanes,
                                       long plane_stride, int n_row, int n_off, const float* bias, int bias_img_stride,
                                       float* y, int n_out, const float* mask, const void* gate_bits, void* gate_out,
-                                      int accumulate, int relu, int B, int H, int W, void* stream) {
+                                      int accumulate, int relu, int B, int H, int W, int opts, void* stream) {
     return conv_x6_launch(3, x0, c0, x1, c1, wplanes, plane_stride, n_row, n_off, bias, bias_img_stride, y, n_out, mask, gate_bits,
-                          gate_out, accumulate, relu, B, H, W, stream);
-}
-
-extern "C" int punet_set_x6_mfma_shape(int shape) {
-    PUNET_CHECK_ARG(shape == 16 || shape == 32, "punet_set_x6_mfma_shape: 32 (v_mfma_f32_32x32x16_bf16) or 16 (16x16x32), got %d", shape);
-    g_x6_shape16 = shape == 16;
-    return PUNET_OK;
+                          gate_out, accumulate, relu, B, H, W, opts, stream);
 }
 
 extern "C" int punet_conv3x3_x6_pooled(const float* x0, int c0, const float* x1, int c1, const void* wplanes,
                                        long plane_stride, int n_row, int n_off, const float* bias, int bias_img_stride,
                                        float* y, int n_out, void* gate_out, float* pool_out, int relu, int B, int H, int W,
-                                       void* stream) {
+                                       int opts, void* stream) {
     PUNET_CHECK_ARG(pool_out, "punet_conv3x3_x6_pooled: null pool_out");
     return conv_x6_launch(3, x0, c0, x1, c1, wplanes, plane_stride, n_row, n_off, bias, bias_img_stride, y, n_out, nullptr, nullptr,
-                          gate_out, 0, relu, B, H, W, stream, pool_out);
+                          gate_out, 0, relu, B, H, W, opts, stream, pool_out);
 }
 
 extern "C" int punet_conv1x1_x6_gated(const float* x0, int c0, const float* x1, int c1, const void* wplanes,
@@ -959,14 +942,16 @@ extern "C" int punet_conv1x1_x6_gated(const float* x0, int c0, const float* x1, 
                                       float* y, int n_out, const float* mask, const void* gate_bits, void* gate_out,
                                       int accumulate, int relu, int B, int H, int W, void* stream) {
     return conv_x6_launch(1, x0, c0, x1, c1, wplanes, plane_stride, n_row, n_off, bias, bias_img_stride, y, n_out, mask, gate_bits,
-                          gate_out, accumulate, relu, B, H, W, stream);
+                          gate_out, accumulate, relu, B, H, W, 0, stream);
 }
 
 static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
                           int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
-                          const void* gate_bits, void* gate_out, int accumulate, int relu, int B, int H, int W, void* stream,
-                          float* pool_out) {
+                          const void* gate_bits, void* gate_out, int accumulate, int relu, int B, int H, int W, int opts,
+                          void* stream, float* pool_out) {
     PUNET_CHECK_ARG(x0 && wplanes && y, "punet_conv3x3_x6: null pointer");
+    const int planes = punet_x6_planes_of(opts), shape = punet_x6_shape_of(opts);
+    PUNET_CHECK_ARG(planes > 0 && shape > 0, "punet_conv3x3_x6: bad options word 0x%x (PUNET_X6_OPTS(products 6|3|1, shape 16|32))", opts);
     PUNET_CHECK_ARG(!pool_out || (H % 2 == 0 && W % 2 == 0 && !mask && !gate_bits && !accumulate),
                     "punet_conv3x3_x6_pooled: the fused 2x2 average needs even H and W (%dx%d) and the forward epilogue", H, W);
     PUNET_CHECK_ARG(c0 > 0 && c0 % CK == 0 && c1 >= 0 && c1 % CK == 0 && (c1 == 0 || x1),
@@ -990,7 +975,7 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
     a.gate_bits = (const unsigned*)gate_bits; a.gate_out = (unsigned*)gate_out; a.pool_out = pool_out;
     a.B = B; a.H = H; a.W = W;
     a.ntiles = B * ceil_div(H, TH) * ceil_div(W, TW) * ceil_div(n_out, TN);
-    const int cap = g_x6_wg_per_cu * NUM_CU;
+    const int cap = WG_PER_CU * punet_num_cus();
     const int grid = a.ntiles < cap ? a.ntiles : cap;
     // the input-gradient epilogue whenever one of its features is asked for; bias / ReLU / gate_out belong to the forward
     const bool dgrad = mask || gate_bits || accumulate;
@@ -1000,17 +985,17 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
     a.xcd_remap = grid % 8 == 0;  // same-process A/B: +0.5-0.8 % (the tensors of this workload fit the Infinity Cache)
     if (ksize == 1) {  // the two Fcomb layers: always the parity arithmetic (they are a rounding error of the step time)
         if (dgrad) conv3x3_x6_kernel<3, true, 1><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<3, false, 1><<<grid, 256, 0, st>>>(a);
-    } else if (g_x6_shape16 && (c0 + c1) % 32 == 0 && g_punet_x6_planes >= 2) {
+    } else if (shape == 16 && (c0 + c1) % 32 == 0 && planes >= 2) {
         // 16 x 16 x 32 MFMAs: four {tap, 8 channels} blocks per instruction.  (Not for the one-plane fast mode: that one is
         // bound by its staging, not by the matrix cores, and measured 15 % slower through this kernel.)
-        if (g_punet_x6_planes == 3) {
+        if (planes == 3) {
             if (dgrad) conv3x3_x6b_kernel<3, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6b_kernel<3, false><<<grid, 256, 0, st>>>(a);
         } else {
             if (dgrad) conv3x3_x6b_kernel<2, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6b_kernel<2, false><<<grid, 256, 0, st>>>(a);
         }
-    } else if (g_punet_x6_planes == 3) {
+    } else if (planes == 3) {
         if (dgrad) conv3x3_x6_kernel<3, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<3, false><<<grid, 256, 0, st>>>(a);
-    } else if (g_punet_x6_planes == 2) {
+    } else if (planes == 2) {
         if (dgrad) conv3x3_x6_kernel<2, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<2, false><<<grid, 256, 0, st>>>(a);
     } else {
         if (dgrad) conv3x3_x6_kernel<1, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<1, false><<<grid, 256, 0, st>>>(a);

@@ -161,7 +161,7 @@ extern "C" int punet_fcomb_sample(const float* feat, const float* w1, const floa
     a.upper = upper; a.lower = lower;
     const size_t shmem = ((size_t)CH * CH * (1 + nmid) + (size_t)nmid * CH + CH) * sizeof(float);
     int grid = (a.ntiles + 3) / 4;
-    if (grid > 512) grid = 512;
+    if (grid > 2 * punet_num_cus()) grid = 2 * punet_num_cus();
     if (shmem > 48 * 1024) {  // raise the dynamic-LDS cap (160 KiB per CU on gfx950)
         const void* fn = CH == 64 ? (const void*)fcomb_sampler_kernel<2> : (const void*)fcomb_sampler_kernel<1>;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {

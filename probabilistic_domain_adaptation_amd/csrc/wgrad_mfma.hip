@@ -159,8 +159,8 @@ extern "C" size_t punet_wgrad_workspace_floats(int cs, int cout, int ksize, int 
 extern "C" int punet_wgrad_slices(int cs, int cout, int B, int H, int W) {
     const int ntiles = B * ceil_div(H, WTH) * ceil_div(W, WTW);
     const int pairs = ceil_div(cs, WC) * ceil_div(cout, WC);
-    // 2 workgroups are resident per CU (244 VGPRs, 51 KB LDS): size the grid to ONE full residency round (512 WGs)
-    int ns = 512 / pairs;
+    // 2 workgroups are resident per CU (244 VGPRs, 51 KB LDS): size the grid to ONE full residency round
+    int ns = 2 * punet_num_cus() / pairs;
     if (ns > ntiles) ns = ntiles;
     if (ns < 1) ns = 1;
     return ns;

@@ -335,20 +335,20 @@ int launch_wgrad(const WgradX6Args& a, dim3 grid, hipStream_t stream) {
 
 }  // namespace
 
-extern int g_punet_x6_planes;  // conv_x6.hip (punet_set_x6_products)
-
 extern "C" int punet_wgrad_x6_slices(int cs, int cout, int B, int H, int W) {
     const int ntiles = B * ceil_div(H, WTH) * ceil_div(W, WTW);
     const int pairs = ceil_div(cs, WC) * ceil_div(cout, WC);
-    int ns = 256 / pairs;  // one resident workgroup per CU: one full round of the 256 CUs
+    int ns = punet_num_cus() / pairs;  // one resident workgroup per CU: one full round of the CUs
     if (ns > ntiles) ns = ntiles;
     return ns < 1 ? 1 : ns;
 }
 
 extern "C" int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off,
                                    float* dbias, float* workspace, int nslices, int B, int H, int W, int accumulate,
-                                   float scale, void* stream_) {
+                                   float scale, int opts, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const int planes = punet_x6_planes_of(opts);
+    PUNET_CHECK_ARG(planes > 0, "punet_conv_wgrad_x6: bad options word 0x%x", opts);
     PUNET_CHECK_ARG(x && dz && dw && workspace, "punet_conv_wgrad_x6: null pointer");
     PUNET_CHECK_ARG(cs > 0 && cs % 4 == 0 && cout > 0 && cout % 4 == 0,
                     "punet_conv_wgrad_x6: channels must be multiples of 4 (cs=%d cout=%d)", cs, cout);
@@ -362,8 +362,8 @@ extern "C" int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int 
     a.bias_partial = dbias ? workspace + (size_t)nslices * 9 * cs * cout : nullptr;
     a.B = B; a.H = H; a.W = W; a.nslices = nslices;
     dim3 grid(nslices, ceil_div(cs, WC) * ceil_div(cout, WC));
-    const int rc0 = g_punet_x6_planes == 3 ? launch_wgrad<3>(a, grid, stream)
-                    : g_punet_x6_planes == 2 ? launch_wgrad<2>(a, grid, stream) : launch_wgrad<1>(a, grid, stream);
+    const int rc0 = planes == 3 ? launch_wgrad<3>(a, grid, stream)
+                    : planes == 2 ? launch_wgrad<2>(a, grid, stream) : launch_wgrad<1>(a, grid, stream);
     if (rc0 != PUNET_OK) return rc0;
     PUNET_LAUNCH_CHECK("wgrad3x3_x6");
     const size_t n = (size_t)9 * cs * cout;
@@ -390,7 +390,7 @@ int main() {
     hipMemcpy(x, h.data(), n * 4, hipMemcpyHostToDevice);
     hipMemcpy(dz, h.data(), n * 4, hipMemcpyHostToDevice);
     for (int r = 0; r < 3; ++r) {
-        const int rc = punet_conv_wgrad_x6(x, C, dz, C, dw, C, 0, db, ws, ns, B, H, W, 0, 1.f, nullptr);
+        const int rc = punet_conv_wgrad_x6(x, C, dz, C, dw, C, 0, db, ws, ns, B, H, W, 0, 1.f, 0, nullptr);
         if (rc) { printf("error %d\n", rc); return 1; }
     }
     hipDeviceSynchronize();

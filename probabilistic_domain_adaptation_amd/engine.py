@@ -185,16 +185,8 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# bf16 products per fp32 product in the split-plane kernels; the library holds the current value as process state
+# bf16 products per fp32 product in the split-plane kernels; handed to the library with every call (options word)
 _X6_PRODUCTS = {"x6": 6, "x3": 3, "bf16": 1}
-_products_now = [None]
-
-
-def set_x6_products(n: int):
-    """The library keeps the product count as process state; route every change through here (tests too)."""
-    if _products_now[0] != n:
-        _lib.call("punet_set_x6_products", n)
-        _products_now[0] = n
 
 
 class Workspace:
@@ -234,6 +226,10 @@ class PUNetEngine:
         if self.conv_mode not in _X6_PRODUCTS and self.conv_mode != "f32":
             raise ValueError("PUNET_CONV_MODE must be one of 'x6', 'f32', 'x3', 'bf16'")
         self.x6 = self.conv_mode in _X6_PRODUCTS  # the split-plane kernel family
+        # per-call options word of the split-plane kernels: products of this mode, MFMA shape 16 ($PUNET_X6_MFMA_SHAPE=32
+        # selects the older 32x32x16 kernels, an A/B switch)
+        shape = 32 if os.environ.get("PUNET_X6_MFMA_SHAPE", "16") == "32" else 16
+        self.x6_opts = _lib.x6_opts(_X6_PRODUCTS.get(self.conv_mode, 6), shape)
         # the last conv of a contracting block also writes the next block's 2x2 average (PUNET_FUSE_POOL=0: separate kernel)
         self.fuse_pool = os.environ.get("PUNET_FUSE_POOL", "1") != "0"
         self._x6 = {}  # (flat.data_ptr(), mode) -> bf16 planes buffer [3 * numel]
@@ -245,8 +241,6 @@ class PUNetEngine:
 
     def _timed(self, kind, flops, name, *args):
         """Launch through the C ABI; with self.prof set, bracket the launch with HIP events on the launch stream."""
-        if self.x6:
-            set_x6_products(_X6_PRODUCTS[self.conv_mode])
         if self.prof is None or (self.prof_kinds is not None and kind not in self.prof_kinds):
             return _lib.call(name, *args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -309,12 +303,13 @@ class PUNetEngine:
                 self._timed("conv3x3_fwd", 2.0 * B * H * W * cin * c.cout * 9, "punet_conv3x3_x6_pooled", x0.ptr, x0.C,
                             x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0,
                             planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cout, 0, self._bptr(flat, c), 0, y.ptr, c.cout,
-                            y.bits.data_ptr() if y.bits is not None else None, q.ptr, int(relu), B, H, W, _stream())
+                            y.bits.data_ptr() if y.bits is not None else None, q.ptr, int(relu), B, H, W, self.x6_opts, _stream())
             else:
                 self._timed("conv3x3_fwd", 2.0 * B * H * W * cin * c.cout * 9, "punet_conv3x3_x6_gated", x0.ptr, x0.C,
                             x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0,
                             planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cout, 0, self._bptr(flat, c), 0, y.ptr, c.cout,
-                            None, None, y.bits.data_ptr() if y.bits is not None else None, 0, int(relu), B, H, W, _stream())
+                            None, None, y.bits.data_ptr() if y.bits is not None else None, 0, int(relu), B, H, W, self.x6_opts,
+                            _stream())
         elif self.x6 and c.k == 1 and x1 is None and name in self._x6_1x1.get((flat.data_ptr(), 0), {}):
             planes = self._x6_1x1[(flat.data_ptr(), 0)][name]
             if relu and tape_bits:
@@ -586,7 +581,7 @@ class PUNetEngine:
         if x6:
             self._timed("conv3x3_wgrad", 2.0 * B * H * W * x.C * c.cout * 9, "punet_conv_wgrad_x6", x.ptr, x.C, dz.data_ptr(),
                         c.cout, dw, c.cin, ci_off, db if with_bias else None, ws.data_ptr(), ns, B, H, W, int(accumulate), 1.0,
-                        _stream())
+                        self.x6_opts, _stream())
             return
         self._timed(f"conv{c.k}x{c.k}_wgrad", 2.0 * B * H * W * x.C * c.cout * c.k * c.k, "punet_conv_wgrad", x.ptr, x.C,
                     dz.data_ptr(), c.cout, dw, c.cin, ci_off, db if with_bias else None, ws.data_ptr(), ns, B, H, W, c.k,
@@ -662,7 +657,8 @@ class PUNetEngine:
             use_bits = bits is not None and mask_ptr is not None
             self._timed("conv3x3_dgrad", flops, "punet_conv3x3_x6_gated", dz.data_ptr(), c.cout, None, 0,
                         planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cin, cin_off, None, 0, dx.data_ptr(), cin,
-                        None if use_bits else mask_ptr, bits.data_ptr() if use_bits else None, None, acc, 0, B, H, W, _stream())
+                        None if use_bits else mask_ptr, bits.data_ptr() if use_bits else None, None, acc, 0, B, H, W, self.x6_opts,
+                        _stream())
         elif self.x6 and c.k == 1 and c.name in self._x6_1x1.get((flat.data_ptr(), 1), {}) and cin_off == 0:
             planes = self._x6_1x1[(flat.data_ptr(), 1)][c.name]  # built for the first `cin` rows of the slab
             use_bits = bits is not None and mask_ptr is not None

@@ -20,10 +20,9 @@ BANDS = {6: (3e-6, 0.0), 3: (1e-4, 2e-7), 1: (3e-2, 2e-4)}
 def L():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    from probabilistic_domain_adaptation_amd import _lib, engine
+    from probabilistic_domain_adaptation_amd import _lib
     _lib.load()
-    yield _lib
-    engine.set_x6_products(6)
+    return _lib
 
 
 def rel(a, b):
@@ -32,8 +31,8 @@ def rel(a, b):
 
 @pytest.mark.parametrize("products", [6, 3, 1])
 def test_kernels_error_bands(L, products):
-    from probabilistic_domain_adaptation_amd import engine
     S = torch.cuda.current_stream().cuda_stream
+    OPTS = lambda: L.x6_opts(products)  # the arithmetic travels with each call (no process state in the library)
     g = torch.Generator().manual_seed(3)
     B, H, W, cin, cout = 2, 24, 40, 96, 64
     x = torch.randn(B, cin, H, W, generator=g).requires_grad_(True)
@@ -56,15 +55,13 @@ def test_kernels_error_bands(L, products):
     db = torch.zeros(cout, device="cuda")
     ns = L.call("punet_wgrad_x6_slices", cin, cout, B, H, W)
     ws = torch.empty(L.call("punet_wgrad_workspace_floats", cin, cout, 3, ns), device="cuda")
-    engine.set_x6_products(products)
     L.call("punet_conv3x3_x6", X.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, b.detach().cuda().data_ptr(), 0, Y.data_ptr(),
-           cout, None, 0, 0, B, H, W, S)
+           cout, None, 0, 0, B, H, W, OPTS(), S)
     L.call("punet_conv3x3_x6", DZ.data_ptr(), cout, None, 0, pd.data_ptr(), nw, cin, 0, None, 0, DX.data_ptr(), cin, None, 0, 0,
-           B, H, W, S)
+           B, H, W, OPTS(), S)
     L.call("punet_conv_wgrad_x6", X.data_ptr(), cin, DZ.data_ptr(), cout, dw.data_ptr(), cin, 0, db.data_ptr(), ws.data_ptr(), ns,
-           B, H, W, 0, 1.0, S)
+           B, H, W, 0, 1.0, OPTS(), S)
     torch.cuda.synchronize()
-    engine.set_x6_products(6)
     hi, lo = BANDS[products]
     errs = {"fwd": rel(Y.permute(0, 3, 1, 2).cpu(), y.detach()), "dgrad": rel(DX.permute(0, 3, 1, 2).cpu(), x.grad),
             "wgrad": rel(dw.permute(3, 2, 0, 1).cpu(), w.grad)}
@@ -73,9 +70,50 @@ def test_kernels_error_bands(L, products):
     assert rel(db.cpu(), b.grad) < 5e-6  # the bias gradient is an exact fp32 column sum in every mode
 
 
-def test_set_products_rejects_other_values(L):
-    with pytest.raises(RuntimeError):
-        L.call("punet_set_x6_products", 2)
+def test_options_word_rejects_other_values(L):
+    """products must be 6, 3 or 1 and the MFMA shape 16 or 32; anything else is an argument error, not a silent default."""
+    S = torch.cuda.current_stream().cuda_stream
+    x = torch.zeros(1, 8, 32, 8, device="cuda")
+    pf = torch.zeros(3 * 9 * 8 * 8, dtype=torch.bfloat16, device="cuda")
+    for bad in (L.x6_opts(2, 16), L.x6_opts(6, 8)):
+        with pytest.raises(RuntimeError):
+            L.call("punet_conv3x3_x6", x.data_ptr(), 8, None, 0, pf.data_ptr(), 9 * 8 * 8, 8, 0, None, 0, x.clone().data_ptr(), 8, None,
+                   0, 0, 1, 8, 32, bad, S)
+
+
+def test_concurrent_threads_keep_their_own_arithmetic(L):
+    """Two host threads issue x6 and x3 convolutions at the same time, each on its own stream: with the options word per
+    call (instead of the process-wide setter of round 1) each gets its own arithmetic, identical to a serial run."""
+    import threading
+    g = torch.Generator().manual_seed(8)
+    B, H, W, cin, cout = 1, 32, 64, 64, 64
+    x = torch.randn(B, H, W, cin, generator=g).cuda()
+    w = (torch.randn(3, 3, cin, cout, generator=g) / 24.0).cuda()
+    nw = 9 * cin * cout
+    pf = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+    L.call("punet_split_weights_x6", w.data_ptr(), pf.data_ptr(), nw, cin, cout, 3, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+
+    def run(products, out, stream, reps):
+        for _ in range(reps):
+            L.call("punet_conv3x3_x6", x.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, None, 0, out.data_ptr(), cout, None, 0, 0,
+                   B, H, W, L.x6_opts(products), stream.cuda_stream)
+
+    serial = {}
+    for products in (6, 3):
+        serial[products] = torch.empty(B, H, W, cout, device="cuda")
+        run(products, serial[products], torch.cuda.current_stream(), 1)
+    torch.cuda.synchronize()
+    assert not torch.equal(serial[6], serial[3])  # the two arithmetics really differ on this input
+    outs = {6: torch.empty_like(serial[6]), 3: torch.empty_like(serial[3])}
+    streams = {6: torch.cuda.Stream(), 3: torch.cuda.Stream()}
+    th = [threading.Thread(target=run, args=(p_, outs[p_], streams[p_], 200)) for p_ in (6, 3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    assert torch.equal(outs[6], serial[6]) and torch.equal(outs[3], serial[3])
 
 
 @pytest.mark.parametrize("mode,logit_band", [("x3", (2e-2, 1e-6)), ("bf16", (2.0, 1e-4))])

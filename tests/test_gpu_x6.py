@@ -15,19 +15,26 @@ CASES = [(1, 8, 32, 8, 0, 32), (2, 16, 16, 64, 0, 64), (1, 24, 40, 32, 0, 96), (
 def L():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    from probabilistic_domain_adaptation_amd import _lib, engine
+    from probabilistic_domain_adaptation_amd import _lib
     _lib.load()
-    engine.set_x6_products(6)  # process state of the library: other test modules may have selected a fast mode
     return _lib
 
 
 @pytest.fixture(params=[32, 16], ids=["mfma32x32x16", "mfma16x16x32"], autouse=True)
 def mfma_shape(request, L):
-    """Every test of this module runs with both MFMA shapes of the 3x3 kernels (16 = the experimental conv3x3_x6b_kernel,
-    taken by layers whose contracted channel count is a multiple of 32; process state of the library)."""
-    L.call("punet_set_x6_mfma_shape", request.param)
+    """Every test of this module runs with both MFMA shapes of the 3x3 kernels (16 = conv3x3_x6b_kernel, taken by layers
+    whose contracted channel count is a multiple of 32); the shape travels in each call's options word (OPTS())."""
+    _SHAPE[0] = request.param
     yield request.param
-    L.call("punet_set_x6_mfma_shape", 16)  # the library default
+    _SHAPE[0] = 16
+
+
+_SHAPE = [16]
+
+
+def OPTS():
+    from probabilistic_domain_adaptation_amd import _lib
+    return _lib.x6_opts(6, _SHAPE[0])
 
 
 def S():
@@ -70,7 +77,7 @@ def test_conv_x6_fwd_and_dgrad(L, B, H, W, c0, c1, cout):
     Y = torch.full((B, H, W, cout), float("nan"), device="cuda")
     Bd = b.cuda()
     L.call("punet_conv3x3_x6", X0.data_ptr(), c0, X1.data_ptr() if c1 else None, c1, pf.data_ptr(), nw, cout, 0, Bd.data_ptr(), 0,
-           Y.data_ptr(), cout, None, 0, 1, B, H, W, S())
+           Y.data_ptr(), cout, None, 0, 1, B, H, W, OPTS(), S())
     torch.cuda.synchronize()
     assert rel_err(nchw(Y), F.relu(y.detach())) < 2e-6
     DZ = nhwc(dz)
@@ -80,7 +87,7 @@ def test_conv_x6_fwd_and_dgrad(L, B, H, W, c0, c1, cout):
         prev = torch.randn(B, cs, H, W, generator=g)
         M, DX = nhwc(mask), nhwc(prev)
         L.call("punet_conv3x3_x6", DZ.data_ptr(), cout, None, 0, pd.data_ptr(), nw, cin, off, None, 0, DX.data_ptr(), cs,
-               M.data_ptr(), 1, 0, B, H, W, S())
+               M.data_ptr(), 1, 0, B, H, W, OPTS(), S())
         torch.cuda.synchronize()
         ref = prev + x.grad[:, off:off + cs] * (mask > 0)
         assert rel_err(nchw(DX), ref) < 3e-6
@@ -129,10 +136,10 @@ def test_gate_bits_equal_fp32_gate(L, B, H, W, cin, cout):
     nb = L.call("punet_gate_dwords", B, H, W, cout)
     bits = torch.full((nb,), -1, dtype=torch.int32, device="cuda")
     L.call("punet_conv3x3_x6_gated", x.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, b1.data_ptr(), 0, y.data_ptr(), cout,
-           None, None, bits.data_ptr(), 0, 1, B, H, W, S())
+           None, None, bits.data_ptr(), 0, 1, B, H, W, OPTS(), S())
     y_plain = torch.empty_like(y)
     L.call("punet_conv3x3_x6", x.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, b1.data_ptr(), 0, y_plain.data_ptr(), cout,
-           None, 0, 1, B, H, W, S())
+           None, 0, 1, B, H, W, OPTS(), S())
     torch.cuda.synchronize()
     assert torch.equal(y, y_plain)
     # decode the documented layout on the host and compare with (y > 0)
@@ -152,14 +159,14 @@ def test_gate_bits_equal_fp32_gate(L, B, H, W, cin, cout):
     for acc in (0, 1):
         d_mask, d_bits = prev.clone(), prev.clone()
         L.call("punet_conv3x3_x6_gated", dz.data_ptr(), cin, None, 0, p2.data_ptr(), nw, cout, 0, None, 0, d_mask.data_ptr(), cout,
-               y.data_ptr(), None, None, acc, 0, B, H, W, S())
+               y.data_ptr(), None, None, acc, 0, B, H, W, OPTS(), S())
         L.call("punet_conv3x3_x6_gated", dz.data_ptr(), cin, None, 0, p2.data_ptr(), nw, cout, 0, None, 0, d_bits.data_ptr(), cout,
-               None, bits.data_ptr(), None, acc, 0, B, H, W, S())
+               None, bits.data_ptr(), None, acc, 0, B, H, W, OPTS(), S())
         torch.cuda.synchronize()
         assert torch.equal(d_mask, d_bits)
     with pytest.raises(RuntimeError):
         L.call("punet_conv3x3_x6_gated", dz.data_ptr(), cin, None, 0, p2.data_ptr(), nw, cout, 0, None, 0, d_bits.data_ptr(), cout,
-               y.data_ptr(), bits.data_ptr(), None, 0, 0, B, H, W, S())
+               y.data_ptr(), bits.data_ptr(), None, 0, 0, B, H, W, OPTS(), S())
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 64, 32, 64), (1, 24, 40, 64, 96)])
@@ -175,7 +182,7 @@ def test_pool_and_upsample_backward_take_the_gate_bits(L, B, H, W, cin, cout):
     y = torch.empty(B, H, W, cout, device="cuda")
     bits = torch.zeros(L.call("punet_gate_dwords", B, H, W, cout), dtype=torch.int32, device="cuda")
     L.call("punet_conv3x3_x6_gated", x.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, b1.data_ptr(), 0, y.data_ptr(), cout,
-           None, None, bits.data_ptr(), 0, 1, B, H, W, S())
+           None, None, bits.data_ptr(), 0, 1, B, H, W, OPTS(), S())
     dyp = torch.randn(B, (H + 1) // 2, (W + 1) // 2, cout, generator=g).cuda()
     dyu = torch.randn(B, 2 * H, 2 * W, cout, generator=g).cuda()
     prev = torch.randn(B, H, W, cout, generator=g).cuda()
@@ -249,10 +256,10 @@ def test_conv_x6_pooled_epilogue_is_bit_identical(L, B, H, W, c0, c1, cout):
     q1 = torch.empty(B, H // 2, W // 2, cout, device="cuda")
     q2 = torch.full((B, H // 2, W // 2, cout), float("nan"), device="cuda")
     L.call("punet_conv3x3_x6_gated", X0.data_ptr(), c0, X1.data_ptr() if c1 else None, c1, pf.data_ptr(), nw, cout, 0, b.data_ptr(), 0,
-           y1.data_ptr(), cout, None, None, g1.data_ptr(), 0, 1, B, H, W, S())
+           y1.data_ptr(), cout, None, None, g1.data_ptr(), 0, 1, B, H, W, OPTS(), S())
     L.call("punet_pool2x2_fwd", y1.data_ptr(), q1.data_ptr(), B, H, W, cout, S())
     L.call("punet_conv3x3_x6_pooled", X0.data_ptr(), c0, X1.data_ptr() if c1 else None, c1, pf.data_ptr(), nw, cout, 0, b.data_ptr(), 0,
-           y2.data_ptr(), cout, g2.data_ptr(), q2.data_ptr(), 1, B, H, W, S())
+           y2.data_ptr(), cout, g2.data_ptr(), q2.data_ptr(), 1, B, H, W, OPTS(), S())
     torch.cuda.synchronize()
     assert torch.equal(y1, y2) and torch.equal(g1, g2)
     assert torch.equal(q1, q2)
@@ -265,7 +272,7 @@ def test_conv_x6_pooled_rejects_odd_sizes(L):
     y, q = torch.empty(1, 5, 8, 8, device="cuda"), torch.empty(1, 2, 4, 8, device="cuda")
     with pytest.raises(RuntimeError, match="even H and W"):
         L.call("punet_conv3x3_x6_pooled", X.data_ptr(), 8, None, 0, pf.data_ptr(), 9 * 8 * 8, 8, 0, None, 0, y.data_ptr(), 8, None,
-               q.data_ptr(), 1, 1, 5, 8, S())
+               q.data_ptr(), 1, 1, 5, 8, OPTS(), S())
 
 
 def test_whole_model_agrees_between_mfma_shapes(L):
@@ -278,8 +285,8 @@ def test_whole_model_agrees_between_mfma_shapes(L):
     eps = torch.randn(4, 2, 6, generator=torch.Generator().manual_seed(1)).cuda()
     outs = []
     for shape in (32, 16):
-        L.call("punet_set_x6_mfma_shape", shape)
         eng = m.engine
+        eng.x6_opts = L.x6_opts(6, shape)
         with torch.no_grad():
             out = eng.forward_features(m.flat_params, eng.to_nhwc(x1))
             z = eng.reparam(out["prior_muls"], eps)

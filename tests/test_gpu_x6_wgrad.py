@@ -14,8 +14,8 @@ CASES = [(1, 8, 32, 8, 32), (2, 16, 16, 64, 64), (1, 24, 40, 32, 96), (2, 8, 8, 
 def test_wgrad_x6(B, H, W, cin, cout):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    from probabilistic_domain_adaptation_amd import _lib as L, engine
-    engine.set_x6_products(6)  # process state of the library: other test modules may have selected a fast mode
+    from probabilistic_domain_adaptation_amd import _lib as L
+    OPTS = lambda: 0  # the library defaults: six products
     S = torch.cuda.current_stream().cuda_stream
     g = torch.Generator().manual_seed(21)
     scale = torch.exp2(torch.randint(-8, 8, (B, cin, H, W), generator=g).float())
@@ -33,7 +33,7 @@ def test_wgrad_x6(B, H, W, cin, cout):
     ns = L.call("punet_wgrad_x6_slices", cin, cout, B, H, W)
     ws = torch.empty(L.call("punet_wgrad_workspace_floats", cin, cout, 3, ns), device="cuda")
     L.call("punet_conv_wgrad_x6", X.data_ptr(), cin, DZ.data_ptr(), cout, dw.data_ptr(), tot, off, db.data_ptr(), ws.data_ptr(), ns,
-           B, H, W, 0, 1.0, S)
+           B, H, W, 0, 1.0, OPTS(), S)
     torch.cuda.synchronize()
     got = dw[:, :, off:, :].permute(3, 2, 0, 1).cpu()
     rel = lambda a_, b_: (a_ - b_).abs().max().item() / (b_.abs().max().item() + 1e-12)
@@ -41,6 +41,6 @@ def test_wgrad_x6(B, H, W, cin, cout):
     assert rel(db.cpu(), b.grad) < 5e-6
     assert dw[:, :, :off, :].abs().max().item() == 0.0
     L.call("punet_conv_wgrad_x6", X.data_ptr(), cin, DZ.data_ptr(), cout, dw.data_ptr(), tot, off, None, ws.data_ptr(), ns, B, H, W,
-           1, 0.5, S)
+           1, 0.5, OPTS(), S)
     torch.cuda.synchronize()
     assert rel(dw[:, :, off:, :].permute(3, 2, 0, 1).cpu(), 1.5 * w.grad) < 5e-6

@@ -32,7 +32,7 @@ for c0, c1, cout, hw in SHAPES:
 
     def x6():
         L.call("punet_conv3x3_x6", x0.data_ptr(), c0, x1.data_ptr() if c1 else None, c1, pf.data_ptr(), nw, cout, 0, b.data_ptr(), 0,
-               y2.data_ptr(), cout, None, 0, 1, B, hw, hw, S)
+               y2.data_ptr(), cout, None, 0, 1, B, hw, hw, 0, S)
 
     best = {"f": 1e9, "x": 1e9}
     for r in range(6):

@@ -64,17 +64,17 @@ def main():
 
         def fwd():
             L.call("punet_conv3x3_x6", x0.data_ptr(), c0, x1.data_ptr() if c1 else None, c1, pf.data_ptr(), nw, cout, 0,
-                   b.data_ptr(), 0, y.data_ptr(), cout, None, 0, 1, B, hw, hw, S)
+                   b.data_ptr(), 0, y.data_ptr(), cout, None, 0, 1, B, hw, hw, 0, S)
 
         bits = torch.zeros(L.call("punet_gate_dwords", B, hw, hw, c0), dtype=torch.int32, device="cuda")
 
         def dgrad():  # gradient w.r.t. the first source, ReLU-gated (bit form of the gate, as the engine does)
             L.call("punet_conv3x3_x6_gated", dz.data_ptr(), cout, None, 0, pd.data_ptr(), nw, cin, 0, None, 0, dx.data_ptr(), c0,
-                   None if a.bits else x0.data_ptr(), bits.data_ptr() if a.bits else None, None, 0, 0, B, hw, hw, S)
+                   None if a.bits else x0.data_ptr(), bits.data_ptr() if a.bits else None, None, 0, 0, B, hw, hw, 0, S)
 
         def wgrad():
             L.call("punet_conv_wgrad_x6", x0.data_ptr(), c0, dz.data_ptr(), cout, dw.data_ptr(), cin, 0, db.data_ptr(),
-                   ws.data_ptr(), ns, B, hw, hw, 0, 1.0, S)
+                   ws.data_ptr(), ns, B, hw, hw, 0, 1.0, 0, S)
 
         fl = {"fwd": 2.0 * B * hw * hw * cin * cout * 9, "dgrad": 2.0 * B * hw * hw * c0 * cout * 9,
               "wgrad": 2.0 * B * hw * hw * c0 * cout * 9}

@@ -12,6 +12,6 @@ nw = 9 * cin * cout
 pf = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
 L.call("punet_split_weights_x6", w.data_ptr(), pf.data_ptr(), nw, cin, cout, 3, 0, S)
 for _ in range(3):
-    L.call("punet_conv3x3_x6", x.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, b.data_ptr(), 0, y.data_ptr(), cout, None, 0, 1, B, hw, hw, S)
+    L.call("punet_conv3x3_x6", x.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, b.data_ptr(), 0, y.data_ptr(), cout, None, 0, 1, B, hw, hw, 0, S)
     L.call("punet_conv_fwd", x.data_ptr(), cin, None, 0, w.data_ptr(), b.data_ptr(), 0, y.data_ptr(), cout, B, hw, hw, 3, 1, S)
 torch.cuda.synchronize()
