@@ -235,6 +235,14 @@ int punet_l2_reg_add_grad(const float* w, float* g, const int64_t* chunks, int n
  *      do_adam = 0 performs the EMA alone.  The gradient is read as g * gscale (1/world_size after all-reduce). */
 int punet_adam_ema(float* p, const float* g, float* m, float* v, float* teacher, long n, float gscale, float lr,
                    float beta1, float beta2, float eps, int step, float ema_momentum, int do_adam, void* stream);
+/* The same step with its step-dependent scalars taken from DEVICE memory, so that a step captured in a hipGraph replays
+ * correctly: punet_adam_hyper advances the state block hstate (double[8]: Adam steps taken, lr, beta1, beta2, EMA momentum,
+ * EMA rule 0 none | 1 constant (mean_teacher_trainer.py:52-55) | 2 warm-up min(1 - 1/(it+1), m) (adamt_trainer.py:41),
+ * trainer iteration it, gradient scale) and writes hyper (float[4]: gradient scale, lr / (1 - beta1^t), sqrt(1 - beta2^t),
+ * this step's EMA momentum); punet_adam_ema_dev reads hyper.  teacher == NULL: no EMA. */
+int punet_adam_hyper(double* hstate, float* hyper, void* stream);
+int punet_adam_ema_dev(float* p, const float* g, float* m, float* v, float* teacher, long n, const float* hyper, float beta1,
+                       float beta2, float eps, void* stream);
 int punet_scale(float* x, long n, float s, void* stream);
 
 /* ---- K13: weak / strong view generation on NCHW fp32 planes (the transform chains of LIVECell/livecell_fm.py:43-67 and

@@ -73,6 +73,8 @@ _SIGS = {
     "punet_l2_reg": (_i, [_p, _p, _i, _i, _p, _p, _p, _p]),
     "punet_l2_reg_add_grad": (_i, [_p, _p, _p, _i, _p, _f, _p]),
     "punet_adam_ema": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _f, _i, _p]),
+    "punet_adam_hyper": (_i, [_p, _p, _p]),
+    "punet_adam_ema_dev": (_i, [_p, _p, _p, _p, _p, _l, _p, _f, _f, _f, _p]),
     "punet_scale": (_i, [_p, _l, _f, _p]),
     "punet_standardize_workspace_doubles": (_sz, [_i]),
     "punet_standardize_stats": (_i, [_p, _p, _p, _i, _l, _p]),

@@ -814,6 +814,42 @@ __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__
 
 // backward of the folded z term of Fcomb's first 1x1 conv: S[b][co] = sum_pixels dZ1[b][.][co]
 //   dW1[(CH + d)][co] (+)= sum_b z[b][d] * S[b][co]          dz[b][d] = sum_co W1[(CH + d)][co] * S[b][co]
+// The step-dependent scalars of Adam + EMA computed ON THE DEVICE from a small state block, so that a step captured in a
+// hipGraph replays with the right bias corrections (host scalars would be frozen into the graph).
+// hs (double[8]): [0] Adam steps taken, [1] lr, [2] beta1, [3] beta2, [4] EMA momentum (cap), [5] EMA rule (0 none,
+// 1 constant - mean_teacher_trainer.py:52-55, 2 warm-up min(1 - 1/(it + 1), m) - adamt_trainer.py:41), [6] trainer iteration
+// `it` (advanced here), [7] gradient scale (1 / world_size).
+// hyper (float[4]): gscale, step_size = lr / (1 - beta1^t), sqrt(1 - beta2^t), EMA momentum of this step.
+__global__ void adam_hyper_kernel(double* __restrict__ hs, float* __restrict__ hyper) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double t = hs[0] + 1.0;
+    hs[0] = t;
+    const double bc1 = 1.0 - pow(hs[2], t), bc2 = 1.0 - pow(hs[3], t);
+    hyper[0] = (float)hs[7];
+    hyper[1] = (float)(hs[1] / bc1);
+    hyper[2] = (float)sqrt(bc2);
+    const double it = hs[6];
+    const double mw = 1.0 - 1.0 / (it + 1.0);
+    hyper[3] = hs[5] == 2.0 ? (float)(mw < hs[4] ? mw : hs[4]) : (float)hs[4];
+    hs[6] = it + 1.0;
+}
+
+__global__ void adam_ema_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                    float* __restrict__ v, float* __restrict__ teacher, size_t n,
+                                    const float* __restrict__ hyper, float beta1, float beta2, float eps) {
+    const float gscale = hyper[0], step_size = hyper[1], bc2_sqrt = hyper[2], ema_m = hyper[3];
+    GRID_STRIDE(i, n) {
+        const float gv = g[i] * gscale;
+        float pv = p[i], mv = m[i], vv = v[i];
+        mv = mv + (gv - mv) * (1.f - beta1);
+        vv = vv * beta2 + (1.f - beta2) * gv * gv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        pv = pv - step_size * (mv / denom);
+        m[i] = mv; v[i] = vv; p[i] = pv;
+        if (teacher) teacher[i] = teacher[i] * ema_m + pv * (1.f - ema_m);
+    }
+}
+
 __global__ void fcomb_z_bwd_kernel(const float* __restrict__ S, const float* __restrict__ z, const float* __restrict__ w1,
                                    float* __restrict__ dw1, float* __restrict__ dz, int B, int L, int CH, int accumulate) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
@@ -1215,6 +1251,21 @@ extern "C" int punet_adam_ema(float* p, const float* g, float* m, float* v, floa
     adam_ema_kernel<<<ew_grid((size_t)n, 8192), EW_BLOCK, 0, STREAM>>>(p, g, m, v, teacher, (size_t)n, gscale, step_size, beta1,
                                                                       beta2, bc2_sqrt, eps, ema_momentum, do_adam);
     PUNET_LAUNCH_CHECK("adam_ema");
+    return PUNET_OK;
+}
+
+extern "C" int punet_adam_hyper(double* hstate, float* hyper, void* stream) {
+    PUNET_CHECK_ARG(hstate && hyper, "punet_adam_hyper: null pointer");
+    adam_hyper_kernel<<<1, 64, 0, STREAM>>>(hstate, hyper);
+    PUNET_LAUNCH_CHECK("adam_hyper");
+    return PUNET_OK;
+}
+
+extern "C" int punet_adam_ema_dev(float* p, const float* g, float* m, float* v, float* teacher, long n, const float* hyper,
+                                  float beta1, float beta2, float eps, void* stream) {
+    PUNET_CHECK_ARG(p && g && m && v && hyper && n > 0, "punet_adam_ema_dev: bad args");
+    adam_ema_dev_kernel<<<ew_grid((size_t)n, 8192), EW_BLOCK, 0, STREAM>>>(p, g, m, v, teacher, (size_t)n, hyper, beta1, beta2, eps);
+    PUNET_LAUNCH_CHECK("adam_ema_dev");
     return PUNET_OK;
 }
 

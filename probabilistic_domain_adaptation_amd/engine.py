@@ -799,6 +799,13 @@ class PUNetEngine:
                   teacher.data_ptr() if teacher is not None else None, flat.numel(), float(gscale), float(lr),
                   float(betas[0]), float(betas[1]), float(eps), int(step), float(ema_momentum), int(do_adam), _stream())
 
+    def adam_ema_dev(self, flat, gflat, m, v, teacher, hstate, hyper, betas=(0.9, 0.999), eps=1e-8):
+        """Adam (+ EMA) with the step-dependent scalars computed on the device from `hstate` (graph-capturable)."""
+        _lib.call("punet_adam_hyper", hstate.data_ptr(), hyper.data_ptr(), _stream())
+        _lib.call("punet_adam_ema_dev", flat.data_ptr(), gflat.data_ptr(), m.data_ptr(), v.data_ptr(),
+                  teacher.data_ptr() if teacher is not None else None, flat.numel(), hyper.data_ptr(), float(betas[0]),
+                  float(betas[1]), float(eps), _stream())
+
     def dice_score(self, seg: torch.Tensor, gt: torch.Tensor, threshold_seg=None, threshold_gt=None) -> float:
         """dice_score (my_utils/util.py:17-44) on device tensors; returns a host float (one sync)."""
         sums = self._empty(3)

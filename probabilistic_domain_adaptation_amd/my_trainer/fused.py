@@ -21,7 +21,12 @@ from ..my_models import ProbabilisticUnet
 
 class FusedAdam(torch.optim.Optimizer):
     """Adam on a ProbabilisticUnet's flat buffer.  Usable (a) by the fused steps (gradients already in `grad_flat`) and
-    (b) as a drop-in `optimizer.step()` after `loss.backward()` (gradients gathered from `.grad`)."""
+    (b) as a drop-in `optimizer.step()` after `loss.backward()` (gradients gathered from `.grad`).
+
+    The step-dependent scalars (bias corrections, the EMA momentum of this step, 1 / world_size) are computed ON THE DEVICE
+    from a small state block (`punet_adam_hyper`), never passed as host scalars: a step captured in a hipGraph therefore
+    replays with the right values, and the eagerly launched step runs exactly the same kernels (bit-identical results).
+    `step_count` / `_iter_mirror` mirror the device counters on the host (for checkpoints)."""
 
     def __init__(self, model: ProbabilisticUnet, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps))
@@ -31,6 +36,10 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(flat)
         self.grad_flat = torch.zeros_like(flat)
         self.step_count = 0
+        self.hstate = torch.zeros(8, dtype=torch.float64, device=flat.device)  # layout: punet_adam_hyper
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=flat.device)
+        self._uploaded = None  # what the device state block was last written with
+        self._iter_mirror = 0
 
     @property
     def lr(self) -> float:
@@ -50,13 +59,39 @@ class FusedAdam(torch.optim.Optimizer):
                 else:
                     v.copy_(p.grad)
 
-    def fused_step(self, teacher: Optional[ProbabilisticUnet] = None, ema_momentum: float = 0.999, grad_scale: float = 1.0):
-        """One Adam step from grad_flat (+ EMA into `teacher` when given) - a single kernel launch."""
+    def sync_device_state(self, ema_momentum: float = 0.0, grad_scale: float = 1.0, warmup_iteration: Optional[int] = None):
+        """Write the device state block when anything it holds has changed on the host (lr from a scheduler, a loaded
+        checkpoint's step count, the EMA rule).  A blocking copy from pageable memory: rare, and safe to issue while earlier
+        steps are still in flight.  Never called while a graph is being captured."""
         g = self.param_groups[0]
+        mode = 0.0 if not ema_momentum and warmup_iteration is None else (2.0 if warmup_iteration is not None else 1.0)
+        it = float(warmup_iteration) if warmup_iteration is not None else float(self._iter_mirror)
+        want = (float(self.step_count), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(ema_momentum or 0.0),
+                mode, it, float(grad_scale))
+        if self._uploaded != want:
+            self.hstate.copy_(torch.tensor(want, dtype=torch.float64))
+            self._iter_mirror = int(it)
+        return want
+
+    def _advance_mirrors(self, want):
         self.step_count += 1
-        self.model.engine.adam_ema(self.model.flat_params, self.grad_flat, self.exp_avg, self.exp_avg_sq,
-                                   teacher.flat_params if teacher is not None else None, self.step_count, g["lr"],
-                                   g["betas"], g["eps"], grad_scale, ema_momentum, True)
+        self._iter_mirror += 1
+        self._uploaded = (float(self.step_count),) + want[1:6] + (float(self._iter_mirror),) + want[7:]
+
+    def fused_step(self, teacher: Optional[ProbabilisticUnet] = None, ema_momentum: float = 0.999, grad_scale: float = 1.0,
+                   warmup_iteration: Optional[int] = None):
+        """One Adam step from grad_flat (+ EMA into `teacher` when given): the hyper-parameter kernel and one fused update
+        kernel.  warmup_iteration: the trainer's iteration for AdaMT's momentum rule min(1 - 1/(it + 1), ema_momentum)."""
+        g = self.param_groups[0]
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            want = self.sync_device_state(ema_momentum if teacher is not None else 0.0, grad_scale,
+                                          warmup_iteration if teacher is not None else None)
+        eng = self.model.engine
+        eng.adam_ema_dev(self.model.flat_params, self.grad_flat, self.exp_avg, self.exp_avg_sq,
+                         teacher.flat_params if teacher is not None else None, self.hstate, self.hyper, g["betas"], g["eps"])
+        if not capturing:
+            self._advance_mirrors(want)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -121,6 +156,7 @@ class FusedAdam(torch.optim.Optimizer):
             self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         for g, s_ in zip(self.param_groups, sd["param_groups"]):
             g.update({k: v for k, v in s_.items() if k != "params"})
+        self._uploaded = None  # the device state block is rewritten before the next step
 
 
 def ema_update(model: ProbabilisticUnet, teacher: ProbabilisticUnet, momentum: float):
@@ -133,17 +169,27 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+_CAPTURE = None  # the GraphedStep being captured (module state of the capture in progress; captures are not re-entrant)
+
+
 def allreduce_grads(gflat: torch.Tensor, started: Optional[dict] = None) -> float:
     """Sum the flat gradient over ranks (RCCL ring all-reduce over xGMI); returns the scale to apply (1/world).
     `started` = what `elbo_grad_pass(..., overlap=True)` returned in st["allreduce"]: the U-Net slice is then already
-    in flight (launched under the encoders' backward) and only the remainder is reduced here."""
+    in flight (launched under the encoders' backward) and only the remainder is reduced here.
+    While a step is being captured into hipGraph segments the collective is not captured: the graph is cut here and the
+    all-reduce is replayed eagerly between the segments (GraphedStep)."""
     w = _world()
     if w > 1:
-        if started:
-            dist.all_reduce(gflat[started["numel"]:], op=dist.ReduceOp.SUM)
-            started["work"].wait()
+        def finish():
+            if started:
+                dist.all_reduce(gflat[started["numel"]:], op=dist.ReduceOp.SUM)
+                started["work"].wait()
+            else:
+                dist.all_reduce(gflat, op=dist.ReduceOp.SUM)
+        if _CAPTURE is not None:
+            _CAPTURE.cut(finish)
         else:
-            dist.all_reduce(gflat, op=dist.ReduceOp.SUM)
+            finish()
     return 1.0 / w
 
 
@@ -174,9 +220,15 @@ def elbo_grad_pass(model: ProbabilisticUnet, gflat, x, y, z, eps, gscale: float,
     if overlap and _world() > 1:
         n = model.layout.unet_numel
 
+        def launch():
+            started["work"] = dist.all_reduce(gflat[:n], op=dist.ReduceOp.SUM, async_op=True)
+
         def hook():
             started["numel"] = n
-            started["work"] = dist.all_reduce(gflat[:n], op=dist.ReduceOp.SUM, async_op=True)
+            if _CAPTURE is not None:
+                _CAPTURE.cut(launch)  # graph segment boundary: the async all-reduce runs eagerly between the replays
+            else:
+                launch()
     eng.elbo_backward(model.flat_params, gflat, st, accumulate, after_unet=hook)
     st["allreduce"] = started
     return st["rec"][0], st["kl"][0], st
@@ -212,9 +264,12 @@ def fused_self_training_step(model, teacher, opt: FusedAdam, x1, x2, n_samples: 
 
 
 def fused_joint_step(model, teacher, opt: FusedAdam, xs, ys, xt1, xt2, n_samples: int, masking: bool, eps_sup=None,
-                     eps_pl=None, eps_s=None, momentum: Optional[float] = None, use_consensus=True, reg_weight=1e-5):
+                     eps_pl=None, eps_s=None, momentum: Optional[float] = None, use_consensus=True, reg_weight=1e-5,
+                     warmup_iteration: Optional[int] = None):
     """AdaMT (adamt_trainer.py:89-128) / AdaMatch (adamatch_trainer.py:62-107) iteration:
-    loss = (supervised + target) / 2 with ONE optimizer step; two gradient passes at scale 0.5 accumulate."""
+    loss = (supervised + target) / 2 with ONE optimizer step; two gradient passes at scale 0.5 accumulate.
+    momentum = the EMA momentum (cap); warmup_iteration = the trainer's iteration `it` for AdaMT's rule
+    min(1 - 1/(it + 1), momentum) (adamt_trainer.py:41), evaluated on the device."""
     eng = model.engine
     rec_s, kl_s, _ = elbo_grad_pass(model, opt.grad_flat, xs, ys, None, eps_sup, 0.5, False)
     y, z = pseudo_labels(teacher, xt1, n_samples, masking, eps_pl)
@@ -223,9 +278,109 @@ def fused_joint_step(model, teacher, opt: FusedAdam, xs, ys, xt1, xt2, n_samples
     eng.l2_reg_add_grad(model.flat_params, opt.grad_flat, norms, reg_weight)  # (reg + reg) / 2
     scale = allreduce_grads(opt.grad_flat, st["allreduce"])
     ema = momentum is not None and teacher is not model
-    opt.fused_step(teacher if ema else None, ema_momentum=momentum if ema else 0.0, grad_scale=scale)
+    opt.fused_step(teacher if ema else None, ema_momentum=momentum if ema else 0.0, grad_scale=scale,
+                   warmup_iteration=warmup_iteration if ema else None)
     loss = 0.5 * (rec_s + model.beta * kl_s + rec_t + model.beta * kl_t) + reg_weight * reg[0]
     return loss, y, z
+
+
+class GraphedStep:
+    """A fused training step captured once into a hipGraph and replayed: ~500 kernel launches per step leave the host as
+    one graph launch (the Python graph walk of engine.py costs 10-30 ms of host time per step, which bounds the step as
+    soon as the kernels are faster than that - VERDICT r1 item 4).
+
+        body(inputs) -> outputs   a fused step (fused_self_training_step, ...) on the STATIC input tensors `inputs`
+                                  (dict name -> device tensor); every latent draw must be one of them.
+
+    `step(**new_inputs)` copies the new values into the static tensors, advances the optimizer's host mirrors and replays.
+    Outputs are static tensors too: valid until the next replay.  Everything a step computes from step-dependent scalars
+    (Adam bias corrections, EMA warm-up) comes from the optimizer's device state block, so replay == eager launch, bit
+    for bit (tests/test_gpu_graph.py).
+    Data parallel: collectives are not captured - the capture is CUT at each all-reduce (the U-Net slice as soon as it is
+    final, the remainder after the regulariser) into segments that share one memory pool, and the all-reduces run
+    eagerly between the segment replays, overlapped exactly as in the eager step."""
+
+    def __init__(self, body, inputs, opt: Optional[FusedAdam] = None, ema_momentum: float = 0.0,
+                 warmup_iteration: Optional[int] = None, ema: bool = False, extra_state=()):
+        """ema / ema_momentum / warmup_iteration: the EMA rule the body's optimizer step uses (written to the device state
+        block before capture and before every replay); extra_state: further tensors the body updates in place (the
+        teacher's flat buffer) - restored, with the optimizer's, after the sizing run."""
+        global _CAPTURE
+        if _CAPTURE is not None:
+            raise RuntimeError("a GraphedStep capture is already in progress")
+        self.inputs = inputs
+        self.opt = opt
+        self._extra = list(extra_state)
+        self._ema = (ema, ema_momentum, warmup_iteration is not None)
+        dev = next(iter(inputs.values())).device
+        # (1) one eager run to size every workspace / build every lazily built table; it must not change the training state
+        snap = self._snapshot()
+        body(inputs)
+        self._restore(snap)
+        torch.cuda.synchronize(dev)
+        if opt is not None:  # the device state block must be current before the capture (no uploads inside a graph)
+            opt.sync_device_state(ema_momentum if ema else 0.0, 1.0 / _world(), warmup_iteration if ema else None)
+        # (2) capture, cutting at collectives
+        self.segments, self.actions = [], []
+        self._pool = torch.cuda.graph_pool_handle()
+        self._stream = torch.cuda.Stream(dev)
+        self._stream.wait_stream(torch.cuda.current_stream(dev))
+        _CAPTURE = self
+        try:
+            with torch.cuda.stream(self._stream):
+                self._begin()
+                self.outputs = body(inputs)
+                self._end()
+        finally:
+            _CAPTURE = None
+        torch.cuda.current_stream(dev).wait_stream(self._stream)
+
+    # ---- capture plumbing
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self._pool, capture_error_mode="thread_local")
+        self.segments.append(g)
+
+    def _end(self):
+        self.segments[-1].capture_end()
+
+    def cut(self, action):
+        """End the current segment, remember `action` (eager work between segments, e.g. an all-reduce), begin the next."""
+        self._end()
+        self.actions.append(action)
+        self._begin()
+
+    def _snapshot(self):
+        o = self.opt
+        t = list(self._extra)
+        if o is not None:
+            t += [o.model.flat_params, o.exp_avg, o.exp_avg_sq, o.hstate, o.hyper]
+        return ([x.clone() for x in t], t, (o.step_count, o._iter_mirror, o._uploaded) if o is not None else None)
+
+    def _restore(self, snap):
+        clones, tensors, mirrors = snap
+        with torch.no_grad():
+            for c, x in zip(clones, tensors):
+                x.copy_(c)
+        if mirrors is not None:
+            self.opt.step_count, self.opt._iter_mirror, self.opt._uploaded = mirrors
+
+    # ---- replay
+    def step(self, warmup_iteration: Optional[int] = None, **new_inputs):
+        for k, v in new_inputs.items():
+            if v is not None:
+                self.inputs[k].copy_(v, non_blocking=True)
+        o = self.opt
+        if o is not None:
+            ema, mom, warm = self._ema
+            want = o.sync_device_state(mom if ema else 0.0, 1.0 / _world(), warmup_iteration if (ema and warm) else None)
+        for i, g in enumerate(self.segments):
+            g.replay()
+            if i < len(self.actions):
+                self.actions[i]()
+        if o is not None:
+            o._advance_mirrors(want)
+        return self.outputs
 
 
 def distribution_alignment(y: torch.Tensor, source_distribution: torch.Tensor, engine=None):

@@ -28,18 +28,42 @@ from .default_trainer import DefaultTrainer
 class _PUNetTrainerBase(DefaultTrainer):
     reg_weight = 1e-5  # mean_teacher_trainer.py:117
 
-    def __init__(self, fused=None, **kwargs):
+    def __init__(self, fused=None, graph=False, **kwargs):
+        """fused / graph are extensions: fused (default: the optimizer is a FusedAdam) runs the iteration as kernel launches
+        on flat buffers; graph=True additionally captures that iteration once per input shape into a hipGraph and replays it
+        (FU.GraphedStep: bit-identical results, ~1 ms of host time per step instead of 10-30 ms)."""
         super().__init__(**kwargs)
         self._kwargs = kwargs
         self.fused = isinstance(self.optimizer, FU.FusedAdam) if fused is None else fused
         if self.fused and not isinstance(self.optimizer, FU.FusedAdam):
             raise ValueError("fused=True needs a FusedAdam optimizer")
+        self.graph = bool(graph)
+        if self.graph and not self.fused:
+            raise ValueError("graph=True needs the fused execution mode (a FusedAdam optimizer)")
+        self._graphs = {}
         self.sigmoid = torch.nn.Sigmoid()
         self.eps_source = None  # callable(kind, n, batch) -> [n, batch, L] tensor, or None for fresh draws
         self.last_loss = None
 
     def _eps(self, kind, n, batch):
         return None if self.eps_source is None else self.eps_source(kind, n, batch)
+
+    def _eps_drawn(self, kind, n, batch):
+        """Like _eps, but never None: a graph replay takes its latent draws as inputs, so fresh ones are drawn here."""
+        e = self._eps(kind, n, batch)
+        m = self.model
+        if e is None:
+            return torch.randn(n, batch, m.latent_dim, device=m.device, generator=m.generator)
+        return e.to(device=m.device, dtype=torch.float32).reshape(n, batch, m.latent_dim)
+
+    def _graphed(self, kind, tensors, body, **ema):
+        """Replay (capturing first, once per kind / shapes / lr truthiness) the fused step `body` on `tensors`."""
+        key = (kind, bool(self._lr())) + tuple((k, tuple(v.shape)) for k, v in tensors.items())
+        gs = self._graphs.get(key)
+        if gs is None:
+            static = {k: v.to(device=self.model.device, dtype=torch.float32).clone() for k, v in tensors.items()}
+            gs = self._graphs[key] = FU.GraphedStep(body, static, self.optimizer, **ema)
+        return gs.step(warmup_iteration=ema.get("warmup_iteration"), **tensors)
 
     def _lr(self):
         return [pm["lr"] for pm in self.optimizer.param_groups][0]
@@ -83,7 +107,13 @@ class PUNetTrainer(_PUNetTrainerBase):
         n_iter, t0 = 0, time.time()
         for batch in self.train_loader:
             x, y, z = self._batch(batch)
-            if self.fused:
+            if self.fused and self.graph:
+                t = {"x": x, "y": y, "eps": self._eps_drawn("student", 1, x.shape[0])}
+                if z is not None:
+                    t["z"] = z
+                self.last_loss = self._graphed("supervised", t, lambda s: FU.fused_supervised_step(
+                    self.model, self.optimizer, s["x"], s["y"], s.get("z"), s["eps"], self.reg_weight))
+            elif self.fused:
                 self.last_loss = FU.fused_supervised_step(self.model, self.optimizer, x, y, z, self._eps("student", 1, x.shape[0]),
                                                           self.reg_weight)
             else:
@@ -212,7 +242,16 @@ class MeanTeacherTrainer(_SelfTrainingBase):
         for x, x1, x2, gt_ in self.train_loader:
             x1, x2 = x1.to(self.device), x2.to(self.device)
             B = x1.shape[0]
-            if self.fused:
+            if self.fused and self.graph:
+                t = {"x1": x1, "x2": x2, "eps_pl": self._eps_drawn("teacher", self.n_samples, B),
+                     "eps_s": self._eps_drawn("student", 1, B)}
+                n, masking, mom = self.n_samples, self.do_consensus_masking, self.momentum
+                self.last_loss, y, z, _ = self._graphed(("mean_teacher", n, masking, mom), t, lambda s: FU.fused_self_training_step(
+                    self.model, self.teacher, self.optimizer, s["x1"], s["x2"], n, masking, s["eps_pl"], s["eps_s"], mom,
+                    self.reg_weight), ema=bool(self._lr()), ema_momentum=mom, extra_state=[self.teacher.flat_params])
+                if self._lr():
+                    self.momentum_update_is_activated = True
+            elif self.fused:
                 self.last_loss, y, z, _ = FU.fused_self_training_step(
                     self.model, self.teacher, self.optimizer, x1, x2, self.n_samples, self.do_consensus_masking,
                     self._eps("teacher", self.n_samples, B), self._eps("student", 1, B), self.momentum, self.reg_weight)
@@ -259,7 +298,14 @@ class FixMatchTrainer(_SelfTrainingBase):
         for x, x1, x2, gt_ in self.train_loader:
             x1, x2 = x1.to(self.device), x2.to(self.device)
             B = x1.shape[0]
-            if self.fused:
+            if self.fused and self.graph:
+                t = {"x1": x1, "x2": x2, "eps_pl": self._eps_drawn("teacher", self.n_samples, B),
+                     "eps_s": self._eps_drawn("student", 1, B)}
+                n, masking = self.n_samples, self.do_consensus_masking
+                self.last_loss, y, z, _ = self._graphed(("fixmatch", n, masking), t, lambda s: FU.fused_self_training_step(
+                    self.model, self.model, self.optimizer, s["x1"], s["x2"], n, masking, s["eps_pl"], s["eps_s"], None,
+                    self.reg_weight, self.source_distribution))
+            elif self.fused:
                 self.last_loss, y, z, _ = FU.fused_self_training_step(
                     self.model, self.model, self.optimizer, x1, x2, self.n_samples, self.do_consensus_masking,
                     self._eps("teacher", self.n_samples, B), self._eps("student", 1, B), None, self.reg_weight,
@@ -296,6 +342,10 @@ class _JointBase(_SelfTrainingBase):
     def _ema_momentum(self):
         return None
 
+    def _ema_rule(self):
+        """(momentum cap, iteration for the warm-up rule) of the fused step; (None, None) = no EMA."""
+        return None, None
+
     def _train_epoch_impl(self, progress, forward_context, backprop):
         self.model.train()
         n_iter, t0 = 0, time.time()
@@ -305,11 +355,22 @@ class _JointBase(_SelfTrainingBase):
             B = xt1.shape[0]
             use_z = self._use_consensus()
             mom = self._ema_momentum()
-            if self.fused:
+            cap, warm = self._ema_rule()  # fused: the momentum rule is evaluated on the device
+            net = self._pseudo_label_net()
+            if self.fused and self.graph:
+                t = {"xs": xs, "ys": ys, "xt1": xt1, "xt2": xt2, "eps_sup": self._eps_drawn("sup", 1, xs.shape[0]),
+                     "eps_pl": self._eps_drawn("teacher", self.n_samples, B), "eps_s": self._eps_drawn("student", 1, B)}
+                n, masking = self.n_samples, self.do_consensus_masking
+                extra = [net.flat_params] if net is not self.model else []
+                self.last_loss, y, z = self._graphed(("joint", n, masking, use_z, cap), t, lambda s: FU.fused_joint_step(
+                    self.model, net, self.optimizer, s["xs"], s["ys"], s["xt1"], s["xt2"], n, masking, s["eps_sup"], s["eps_pl"],
+                    s["eps_s"], cap, use_z, self.reg_weight, warm), ema=cap is not None, ema_momentum=cap or 0.0,
+                    warmup_iteration=warm, extra_state=extra)
+            elif self.fused:
                 self.last_loss, y, z = FU.fused_joint_step(
-                    self.model, self._pseudo_label_net(), self.optimizer, xs, ys, xt1, xt2, self.n_samples,
+                    self.model, net, self.optimizer, xs, ys, xt1, xt2, self.n_samples,
                     self.do_consensus_masking, self._eps("sup", 1, xs.shape[0]), self._eps("teacher", self.n_samples, B),
-                    self._eps("student", 1, B), mom, use_z, self.reg_weight)
+                    self._eps("student", 1, B), cap, use_z, self.reg_weight, warm)
             else:
                 self.optimizer.zero_grad()
                 with forward_context():
@@ -349,6 +410,9 @@ class AdaMTTrainer(_JointBase):
 
     def _ema_momentum(self):
         return min(1 - 1 / (self._iteration + 1), self.momentum)  # adamt_trainer.py:41
+
+    def _ema_rule(self):
+        return self.momentum, self._iteration
 
     def _momentum_update(self):
         FU.ema_update(self.model, self.teacher, self._ema_momentum())

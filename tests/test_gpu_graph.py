@@ -1,0 +1,220 @@
+"""GPU: a fused step captured into a hipGraph (my_trainer/fused.py::GraphedStep) replays bit-identically to the same step
+launched eagerly from Python - weights, teacher, Adam moments, loss, pseudo-labels - over several steps with fresh inputs,
+a learning-rate change in between, AdaMT's iteration-dependent EMA momentum, and under 2-rank data parallelism (graph
+segments cut at the all-reduces)."""
+import contextlib
+import copy
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import punet_oracle as O
+
+pytestmark = pytest.mark.gpu
+NF = [32, 64, 64, 96]
+LR = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _model(dev):
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    cfg = O.PUNetConfig(1, 1, NF, 6, 3, 1.0, True, False)
+    m = ProbabilisticUnet(1, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in O.synth_params(cfg.spec(), 4).items()})
+    return m
+
+
+class _P:
+    def update(self, n):
+        pass
+
+
+def _eps_stream(seed):
+    """Deterministic per-call latent draws, the same sequence for the eager and the graphed trainer."""
+    g = torch.Generator().manual_seed(seed)
+    return lambda kind, n, b: torch.randn(n, b, 6, generator=g)
+
+
+def _batches(n, B=2, H=32, W=32):
+    return [O.synth_batch(B, 1, H, W, 60 + i) for i in range(n)]
+
+
+def _same(a, b):
+    assert torch.equal(a.model.flat_params, b.model.flat_params)
+    assert torch.equal(a.optimizer.exp_avg, b.optimizer.exp_avg) and torch.equal(a.optimizer.exp_avg_sq, b.optimizer.exp_avg_sq)
+    assert a.optimizer.step_count == b.optimizer.step_count
+    if hasattr(a, "teacher"):
+        assert torch.equal(a.teacher.flat_params, b.teacher.flat_params)
+    assert float(a.last_loss) == float(b.last_loss)
+
+
+def _pair(make):
+    out = []
+    for graph in (False, True):
+        tr = make(graph)
+        tr.eps_source = _eps_stream(11)
+        out.append(tr)
+    return out
+
+
+def test_mean_teacher_graph_equals_eager_with_lr_change(dev):
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam, MeanTeacherTrainer
+    data = _batches(5)
+
+    def make(graph):
+        m = _model(dev)
+        tr = MeanTeacherTrainer(name=None, train_loader=data[:3], val_loader=None, model=m, optimizer=FusedAdam(m, lr=LR), device=dev,
+                                do_consensus_masking=True, graph=graph)
+        tr.n_samples = 4
+        return tr
+
+    a, b = _pair(make)
+    for tr in (a, b):
+        tr._train_epoch_impl(_P(), contextlib.nullcontext, None)  # three steps, three different batches
+    torch.cuda.synchronize()
+    _same(a, b)
+    assert len(b._graphs) == 1 and len(next(iter(b._graphs.values())).segments) == 1
+    assert not torch.equal(a.teacher.flat_params, a.model.flat_params)  # the EMA really ran
+    for tr in (a, b):  # a scheduler lowers the learning rate: the device state block follows, no re-capture needed
+        tr.optimizer.param_groups[0]["lr"] = LR * 0.5
+        tr.train_loader = data[3:]
+        tr._train_epoch_impl(_P(), contextlib.nullcontext, None)
+    torch.cuda.synchronize()
+    _same(a, b)
+    assert len(b._graphs) == 1 and a.optimizer.step_count == 5
+
+
+def test_adamt_graph_equals_eager_with_warmup_momentum(dev):
+    """AdaMT: momentum min(1 - 1/(it + 1), 0.999) changes every iteration; in the graph it comes from the device counter."""
+    from probabilistic_domain_adaptation_amd.my_trainer import AdaMTTrainer, FusedAdam
+    tgt = _batches(3)
+    src = [(x, y) for (x, _, _, y) in [O.synth_batch(2, 1, 32, 32, 90 + i) for i in range(3)]]
+
+    def make(graph):
+        m = _model(dev)
+        tr = AdaMTTrainer(source_train_loader=src, target_train_loader=tgt, name=None, val_loader=None, model=m,
+                          optimizer=FusedAdam(m, lr=LR), device=dev, do_consensus_masking=True, graph=graph)
+        tr.n_samples = 4
+        tr._iteration = 2  # not the first iteration: the rule gives 2/3, 3/4, 4/5
+        with torch.no_grad():
+            tr.teacher.flat_params.mul_(0.5)
+        return tr
+
+    a, b = _pair(make)
+    for tr in (a, b):
+        tr._train_epoch_impl(_P(), contextlib.nullcontext, None)
+    torch.cuda.synchronize()
+    _same(a, b)
+    # and the rule itself: against the drop-in path's host-side momentum on one more iteration
+    assert a._iteration == 5 and abs(a._ema_momentum() - 5.0 / 6.0) < 1e-12
+
+
+def test_supervised_and_fixmatch_graph_equal_eager(dev):
+    from probabilistic_domain_adaptation_amd.my_trainer import FixMatchTrainer, FusedAdam, PUNetTrainer
+    data = _batches(2)
+
+    def make_fm(graph):
+        m = _model(dev)
+        tr = FixMatchTrainer(name=None, train_loader=data, val_loader=None, model=m, optimizer=FusedAdam(m, lr=LR), device=dev,
+                             do_consensus_masking=False, source_distribution=[0.6, 0.4], graph=graph)
+        tr.n_samples = 3
+        return tr
+
+    def make_su(graph):
+        m = _model(dev)
+        return PUNetTrainer(name=None, train_loader=[(x, y) for (x, _, _, y) in data], val_loader=None, model=m,
+                            optimizer=FusedAdam(m, lr=LR), device=dev, graph=graph)
+
+    for make in (make_fm, make_su):
+        a, b = _pair(make)
+        for tr in (a, b):
+            tr._train_epoch_impl(_P(), contextlib.nullcontext, None)
+        torch.cuda.synchronize()
+        _same(a, b)
+
+
+def test_graph_capture_leaves_the_training_state_untouched(dev):
+    """Building a GraphedStep runs the step once for sizing and captures it once: neither may move the weights."""
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    m = _model(dev)
+    t = copy.deepcopy(m)
+    with torch.no_grad():
+        t.flat_params.mul_(0.9)
+    opt = FusedAdam(m, lr=LR)
+    x, x1, x2, y = [v.to(dev) for v in O.synth_batch(2, 1, 32, 32, 3)]
+    w0, t0 = m.flat_params.clone(), t.flat_params.clone()
+    inp = {"x1": x1.clone(), "x2": x2.clone(), "eps_pl": torch.randn(4, 2, 6, device=dev), "eps_s": torch.randn(1, 2, 6, device=dev)}
+    gs = FU.GraphedStep(lambda s: FU.fused_self_training_step(m, t, opt, s["x1"], s["x2"], 4, True, s["eps_pl"], s["eps_s"], 0.99, 1e-5),
+                        inp, opt, ema=True, ema_momentum=0.99, extra_state=[t.flat_params])
+    torch.cuda.synchronize()
+    assert torch.equal(m.flat_params, w0) and torch.equal(t.flat_params, t0) and opt.step_count == 0
+    assert float(opt.exp_avg.abs().max()) == 0.0
+    gs.step()
+    torch.cuda.synchronize()
+    assert opt.step_count == 1 and not torch.equal(m.flat_params, w0) and not torch.equal(t.flat_params, t0)
+
+
+# ------------------------------------------------------------------------------------------------- data parallel
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q, graph):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam, MeanTeacherTrainer
+    m = _model(dev)
+    data = [O.synth_batch(2, 1, 32, 32, 70 + 10 * rank + i) for i in range(3)]  # every rank its own shard
+    tr = MeanTeacherTrainer(name=None, train_loader=data, val_loader=None, model=m, optimizer=FusedAdam(m, lr=LR), device=dev,
+                            do_consensus_masking=True, graph=graph)
+    tr.n_samples = 4
+    tr.eps_source = _eps_stream(20 + rank)
+    tr._train_epoch_impl(_P(), contextlib.nullcontext, None)
+    torch.cuda.synchronize()
+    nseg = len(next(iter(tr._graphs.values())).segments) if graph else 0
+    q.put((rank, m.flat_params.cpu().numpy(), tr.teacher.flat_params.cpu().numpy(), nseg))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_dp(graph):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, graph)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_graph_segments_under_data_parallelism_equal_eager_dp():
+    """Two ranks on the one GPU (gloo carries the all-reduce): the graphed step is cut into three segments at the two
+    all-reduces; replicas stay bit-identical and equal to the eagerly launched data-parallel run."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    eager, graphed = _run_dp(False), _run_dp(True)
+    assert np.array_equal(graphed[0][1], graphed[1][1]) and np.array_equal(graphed[0][2], graphed[1][2])
+    assert np.array_equal(graphed[0][1], eager[0][1]) and np.array_equal(graphed[0][2], eager[0][2])
+    assert graphed[0][3] == 3
