@@ -15,10 +15,11 @@ bf16 MFMAs with fp32 accumulation, logits within 1e-3 of the reference, masks bi
 reduced-precision fast modes (the reference scripts' mixed_precision=True analogue) - their lines say so in `dtype`
 and are NOT the headline number.
 
+The timed steps are replays of the step captured once into a hipGraph (`--no-graph`: launched eagerly from Python).
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel = the 3x3 MFMA
-convolution, algorithmic FLOPs / HIP-event duration measured live in the timed region, against the matrix peak of the
-arithmetic in use) and `cpu_baseline` (the CPU oracle = a port of the reference's path, timed on the host cores,
-rank 0, N=1).
+convolution, algorithmic FLOPs / HIP-event duration measured live in this run - in K eagerly launched steps right after
+the timed region, because events cannot sit inside a captured graph - against the matrix peak of the arithmetic in use)
+and `cpu_baseline` (the CPU oracle = a port of the reference's path, timed on the host cores, rank 0, N=1).
 """
 import argparse
 import json
@@ -68,8 +69,9 @@ def host_cores():
     return int(os.environ.get("PUNET_CPU_THREADS", min(n, 16)))
 
 
-def cpu_baseline(workload, n_samples, H, W, budget_s=12.0):
-    """The CPU oracle (own restatement of the reference path, pinned by golden fixtures) on the host cores."""
+def cpu_baseline(workload, n_samples, H, W, min_iters=3):
+    """The CPU oracle (own restatement of the reference path, pinned by golden fixtures) on the host cores: 1 warm-up +
+    `min_iters` timed iterations at batch 1 (~20-25 s of CPU work at 512x512)."""
     from oracle import punet_oracle as O
     torch.set_num_threads(host_cores())
     cfg = O.PUNetConfig(1, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
@@ -82,22 +84,115 @@ def cpu_baseline(workload, n_samples, H, W, budget_s=12.0):
         g = torch.Generator().manual_seed(2)
         et, es = torch.randn(n_samples, 1, 6, generator=g), torch.randn(1, 6, generator=g)
         t0 = time.time()
-        if workload == "mean_teacher":
+        if workload in ("mean_teacher", "fixmatch"):
             O.mean_teacher_step(Ps, Pt, cfg, opt, x1, x2, et, es, True)
         elif workload == "punet_source":
             O.punet_step(Ps, cfg, opt, x2, y, es)
+        elif workload in ("adamt", "adamatch"):
+            O.adamt_step(Ps, Pt, cfg, opt, x, y, x1, x2, es, et, es, True, 0)
         else:
             O.mc_prediction(Ps, cfg, x1, et)
         return time.time() - t0
 
-    one(64, 64)  # warm-up (page-in, thread pools)
+    one(64, 64)  # page-in, thread pools
+    one(H, W)    # the warm-up iteration at size
     times = []
-    while sum(times) < budget_s and len(times) < 2:
+    while len(times) < min_iters:
         times.append(one(H, W))
     per = sum(times) / len(times)
+    pinfo = " | ".join(l.strip() for l in torch.__config__.parallel_info().splitlines()
+                       if any(k in l for k in ("ATen parallel backend", "OpenMP", "omp_get_max_threads", "MKL", "mkl_get_max_threads")))
     return {"value": round(1.0 / per, 5), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} x (batch 1, {H}x{W}, N={n_samples}) {workload} step of the CPU oracle "
-                      f"(torch {torch.__version__} CPU fp32, {torch.get_num_threads()} threads), {per:.2f} s each"}
+            "sample": f"1 warm-up + {len(times)} timed x (batch 1, {H}x{W}, N={n_samples}) {workload} step of the CPU oracle "
+                      f"(torch {torch.__version__} CPU fp32, {torch.get_num_threads()} threads), "
+                      f"{', '.join(f'{t:.2f}' for t in times)} s; parallel_info: {pinfo}"}
+
+
+class Runner:
+    """One workload on one rank: the fused step on static synthetic tensors, launched eagerly from Python or replayed from a
+    hipGraph (FU.GraphedStep); fresh latent draws every step either way."""
+
+    def __init__(self, workload, a, dev, rank, B, H, W, N, channels, conv_mode):
+        import copy
+        from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+        from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
+        from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+        self.FU, self.workload, self.N, self.B = FU, workload, N, B
+        self.model = ProbabilisticUnet(channels, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=1,
+                                       conv_mode=conv_mode)
+        self.teacher = copy.deepcopy(self.model) if workload in ("mean_teacher", "adamt") else None
+        self.opt = FusedAdam(self.model, lr=1e-5)
+        x, x1, x2, y = synth(B, H, W, 100 + rank, dev, channels)  # every rank its own shard of the synthetic stream
+        xs, _, _, ys = synth(B, H, W, 500 + rank, dev, channels)  # source-domain batch of the joint trainers
+        self.t = {"x1": x1, "x2": x2, "y": y, "xs": xs, "ys": ys,
+                  "eps_pl": torch.empty(N, B, 6, device=dev), "eps_s": torch.empty(1, B, 6, device=dev),
+                  "eps_sup": torch.empty(1, B, 6, device=dev)}
+        self.gen = torch.Generator(device=dev).manual_seed(7 + rank)
+        self.graphed = None
+        self.it = 0
+        self.engines = [self.model.engine] + ([self.teacher.engine] if self.teacher is not None else [])
+
+    def body(self, s):
+        FU, m, t, o, N = self.FU, self.model, self.teacher, self.opt, self.N
+        w = self.workload
+        if w == "mean_teacher":
+            return FU.fused_self_training_step(m, t, o, s["x1"], s["x2"], N, True, s["eps_pl"], s["eps_s"], 0.999, 1e-5)
+        if w == "punet_source":
+            return FU.fused_supervised_step(m, o, s["x2"], s["y"], None, s["eps_s"], 1e-5)
+        if w == "fixmatch":  # fixmatch_trainer.py:67-95 (no EMA, pseudo-labels from the model itself)
+            return FU.fused_self_training_step(m, m, o, s["x1"], s["x2"], N, True, s["eps_pl"], s["eps_s"], None, 1e-5)
+        if w == "adamt":  # adamt_trainer.py:89-128: one source + one target patch per "patch"
+            return FU.fused_joint_step(m, t, o, s["xs"], s["ys"], s["x1"], s["x2"], N, True, s["eps_sup"], s["eps_pl"], s["eps_s"],
+                                       0.999, True, 1e-5, self.it)
+        if w == "adamatch":  # adamatch_trainer.py:62-107
+            return FU.fused_joint_step(m, m, o, s["xs"], s["ys"], s["x1"], s["x2"], N, True, s["eps_sup"], s["eps_pl"], s["eps_s"],
+                                       None, True, 1e-5)
+        return FU.pseudo_labels(m, s["x1"], N, True, s["eps_pl"])
+
+    def capture(self):
+        w = self.workload
+        ema = w in ("mean_teacher", "adamt")
+        self.graphed = self.FU.GraphedStep(self.body, self.t, self.opt if w != "inference" else None, ema=ema,
+                                           ema_momentum=0.999 if ema else 0.0, warmup_iteration=self.it if w == "adamt" else None,
+                                           extra_state=[self.teacher.flat_params] if self.teacher is not None else [])
+
+    def step(self, graph):
+        for k in ("eps_pl", "eps_s", "eps_sup"):  # fresh latent draws every step (device RNG, no host sync)
+            self.t[k].normal_(generator=self.gen)
+        if graph:
+            self.graphed.step(warmup_iteration=self.it if self.workload == "adamt" else None)
+        else:
+            self.body(self.t)
+        self.it += 1
+
+
+def timed_region(runner, steps, graph, sync, world, dev):
+    """EXACTLY `steps` steps between two barriers + synchronisations; returns (seconds, max over ranks; host enqueue
+    seconds; per-step GPU milliseconds)."""
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]  # per-step GPU timeline (diagnostic)
+    sync()
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(steps):
+        runner.step(graph)
+        marks[i + 1].record()
+    t_enq = time.perf_counter() - t0  # host time to enqueue the K steps (the GPU runs behind; must stay below dt)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    return dt, t_enq, [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(steps)]
+
+
+def gflop_per_patch(workload, N, H, W, channels):
+    exact = (H, W, channels) == (704, 704, 3)
+    gf = (GFLOP_704x3 if exact else GFLOP)[workload]
+    gf = gf[N] if isinstance(gf, dict) else gf
+    if not exact and (H, W) != (512, 512):
+        gf = gf * (H * W) / (512 * 512)
+    return gf
 
 
 def main():
@@ -112,10 +207,14 @@ def main():
     ap.add_argument("--samples", type=int, default=8)
     ap.add_argument("--conv-mode", default=None, choices=["x6", "f32", "x3", "bf16"],
                     help="3x3 conv arithmetic (default: $PUNET_CONV_MODE or x6); x3/bf16 are reduced-precision fast modes")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch the timed steps eagerly from Python instead of replaying the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of BASELINE.json configs[2] (AdaMT) and configs[3] (AdaMatch 704x704x3) after the headline")
     ap.add_argument("--kernel-timing", default="roofline", choices=["roofline", "all"],
-                    help="HIP-event brackets inside the timed region: only the roofline kernel's launches (default; 73 per "
+                    help="HIP-event brackets in the instrumented region: only the roofline kernel's launches (default; 73 per "
                          "step) or every MFMA launch (adds ~1 ms of bubbles per step)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI; the default) or gloo (rehearsal on one GPU)")
     a = ap.parse_args()
@@ -140,38 +239,7 @@ def main():
         ge.build()
     if world > 1:
         dist.barrier()
-    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
-    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
     from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
-
-    B, H, W, N = a.batch, a.size, a.size, a.samples
-    model = ProbabilisticUnet(a.channels, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=1,
-                              conv_mode=a.conv_mode)
-    teacher = None
-    if a.workload in ("mean_teacher", "adamt"):
-        import copy
-        teacher = copy.deepcopy(model)
-    opt = FusedAdam(model, lr=1e-5)
-    x, x1, x2, y = synth(B, H, W, 100 + rank, dev, a.channels)  # every rank its own shard of the synthetic stream
-    xs, _, _, ys = synth(B, H, W, 500 + rank, dev, a.channels)  # source-domain batch of the joint trainers
-    gen = torch.Generator(device=dev).manual_seed(7 + rank)
-    model.generator = gen
-    if teacher is not None:
-        teacher.generator = gen
-
-    def step():
-        if a.workload == "mean_teacher":
-            FU.fused_self_training_step(model, teacher, opt, x1, x2, N, True, None, None, 0.999, 1e-5)
-        elif a.workload == "punet_source":
-            FU.fused_supervised_step(model, opt, x2, y, None, None, 1e-5)
-        elif a.workload == "fixmatch":  # fixmatch_trainer.py:67-95 (no EMA, pseudo-labels from the model itself)
-            FU.fused_self_training_step(model, model, opt, x1, x2, N, True, None, None, None, 1e-5)
-        elif a.workload == "adamt":  # adamt_trainer.py:89-128: one source + one target patch per "patch"
-            FU.fused_joint_step(model, teacher, opt, xs, ys, x1, x2, N, True, None, None, None, 0.999, True, 1e-5)
-        elif a.workload == "adamatch":  # adamatch_trainer.py:62-107
-            FU.fused_joint_step(model, model, opt, xs, ys, x1, x2, N, True, None, None, None, None, True, 1e-5)
-        else:
-            FU.pseudo_labels(model, x1, N, True)
 
     def sync():
         torch.cuda.synchronize()
@@ -179,40 +247,43 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    eng = model.engine
-    engines = [eng] + ([teacher.engine] if teacher is not None else [])
-    prof = None if a.no_kernel_timing else []
-    for e in engines:  # the warm-up runs with the same HIP-event brackets as the timed steps: the first use of ~1000 events
-        e.prof = prof  # in a process costs tens of ms (seen as one 124 ms step in an otherwise flat 59 ms series)
-        e.prof_kinds = {"conv3x3_fwd"} if a.kernel_timing == "roofline" else None
+    B, H, W, N = a.batch, a.size, a.size, a.samples
+    use_graph = not a.no_graph
+    run = Runner(a.workload, a, dev, rank, B, H, W, N, a.channels, a.conv_mode)
+    eng = run.model.engine
+    if use_graph:
+        run.capture()
     for _ in range(a.warmup):
-        step()
-    sync()
-    if prof is not None:
+        run.step(use_graph)
+    comm = [] if world > 1 else None
+    FU.COMM_EVENTS = comm  # HIP events around the exposed part of the gradient all-reduce (rank-local)
+    # ---- the timed region: K steps, barrier + synchronize on both sides, max over ranks
+    dt, t_enq, ms_each = timed_region(run, a.steps, use_graph, sync, world, dev)
+    FU.COMM_EVENTS = None
+    exposed_ms = None
+    if comm:
+        exposed_ms = round(sum(e0.elapsed_time(e1) for e0, e1 in comm) / a.steps, 3)
+
+    # ---- the instrumented region: the same K steps launched eagerly with HIP events around the roofline kernel's launches
+    # on the launch stream (events cannot be recorded inside a captured hipGraph on this ROCm - hipErrorInvalidHandle,
+    # profiles/r02/graph_event_probe.txt - so the kernel is timed in the eagerly launched twin of the replayed step; the
+    # kernels and their order are the same, tests/test_gpu_graph.py shows the results are bit-identical)
+    prof, dt_eager, ms_each_eager, t_enq_eager = None, None, None, None
+    if not a.no_kernel_timing:
+        prof = []
+        for e in run.engines:
+            e.prof = prof
+            e.prof_kinds = {"conv3x3_fwd"} if a.kernel_timing == "roofline" else None
+        run.step(False)  # the first use of ~1000 events in a process costs tens of ms: not in the measured steps
+        sync()
         prof.clear()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]  # per-step GPU timeline (diagnostic)
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(a.steps):
-        step()
-        marks[i + 1].record()
-    t_enq = time.perf_counter() - t0  # host time to enqueue the K steps (the GPU runs behind; must stay below dt)
-    sync()
-    dt = time.perf_counter() - t0
-    for e in engines:
-        e.prof = None
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        dt_eager, t_enq_eager, ms_each_eager = timed_region(run, a.steps, False, sync, world, dev)
+        for e in run.engines:
+            e.prof = None
 
     if rank == 0:
         patches = world * B * a.steps
-        exact = (H, W, a.channels) == (704, 704, 3)
-        gf = (GFLOP_704x3 if exact else GFLOP)[a.workload]
-        gf = gf[N] if isinstance(gf, dict) else gf
-        if not exact and (H, W) != (512, 512):
-            gf = gf * (H * W) / (512 * 512)
+        gf = gflop_per_patch(a.workload, N, H, W, a.channels)
         out = {
             "metric": "training patches/sec (512x512, N=8 MC samples)" if a.workload != "inference" else "inference patches/sec",
             "value": round(patches / dt, 4), "unit": "patches/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -222,11 +293,20 @@ def main():
             "config": {"workload": f"PUNet {a.workload} step: nf={NF}, latent 6, fcomb 3, BCE+KL, consensus masking, "
                                    f"{H}x{W}x{a.channels} patches, batch {B}/GPU, N={N} MC samples, Adam lr 1e-5, EMA 0.999",
                        "global_batch": world * B, "parallelism": f"dp{world}",
+                       "launch": "hipGraph replay of the captured fused step (one graph launch per step)" if use_graph
+                                 else "eager: ~500 kernel launches per step from Python",
                        "algorithmic_gflop_per_patch": gf,
                        "model_tflops_per_gpu": round(gf * patches / dt / world / 1e3, 2),
                        "host_enqueue_ms_per_step": round(1e3 * t_enq / a.steps, 2),
-                       "ms_each_step": [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(a.steps)]},
+                       "ms_each_step": ms_each},
         }
+        if world > 1:
+            out["config"]["distributed"] = {
+                "world_size_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                "allreduce": "flat fp32 gradient, U-Net slice launched under the encoders' backward + remainder after the regulariser",
+                "exposed_allreduce_ms_per_step_rank0": exposed_ms,
+                "exposed_note": "HIP events on the launch stream around the point where the step waits for the gradient all-reduce "
+                                "(remainder + whatever of the overlapped U-Net slice is still in flight)"}
         out["config"]["conv_arithmetic"] = {
             "x6": "3x3 convs fwd+dgrad+wgrad: fp32 operands split into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 "
                   "accumulate (fp32-accurate); 1x1 convs: fp32-input MFMA",
@@ -236,6 +316,10 @@ def main():
             "bf16": "REDUCED PRECISION fast mode: 3x3 convs in plain bf16 (1 MFMA per product), fp32 accumulate and "
                     "storage; 1x1 convs fp32-input MFMA"}[eng.conv_mode]
         if prof:
+            out["config"]["instrumented_eager_region"] = {
+                "ms_per_step": round(1e3 * dt_eager / a.steps, 3), "host_enqueue_ms_per_step": round(1e3 * t_enq_eager / a.steps, 2),
+                "ms_each_step": ms_each_eager,
+                "note": "the same K steps launched eagerly right after the timed region, with HIP events around the roofline kernel"}
             agg = {}
             for kind, fl, e0, e1 in prof:
                 d = agg.setdefault(kind, [0.0, 0.0, 0])
@@ -243,19 +327,21 @@ def main():
                 d[1] += e0.elapsed_time(e1) * 1e-3
                 d[2] += 1
             kernels = {k: {"launches": v[2], "avg_ms": round(1e3 * v[1] / v[2], 4), "tflops": round(v[0] / v[1] / 1e12, 2),
-                           "share_of_step": round(v[1] / dt, 3)} for k, v in agg.items()}
+                           "share_of_step": round(v[1] / dt_eager, 3)} for k, v in agg.items()}
             k3 = agg.get("conv3x3_fwd")
-            traffic, traffic_note = None, "not collected"
+            traffic, traffic_note = None, "not collected for this workload / shape"
             try:  # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.py)
                 if a.workload == "mean_teacher" and (B, H, W, N) == (4, 512, 512, 8) and eng.conv_mode in ("x6", "f32"):
                     fn, key = {"x6": ("pmc_hbm_traffic_x6.json", "conv3x3_x6b_kernel<3, false>"),
                                "f32": ("pmc_hbm_traffic.json", "conv_mfma_kernel<3, false>")}[eng.conv_mode]
-                    pm = json.load(open(os.path.join(ROOT, "profiles", "r01", fn)))
+                    rdir = "r02" if os.path.exists(os.path.join(ROOT, "profiles", "r02", fn)) else "r01"
+                    pm = json.load(open(os.path.join(ROOT, "profiles", rdir, fn)))
                     traffic = round(pm["kernels"][key]["hbm_bytes_per_launch"])
-                    traffic_note = ("bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE in separate "
-                                    f"passes of this same workload (profiles/r01/{fn}), mean over the launches of the forward "
-                                    "instantiation (algorithmic mean over the forward launches: 265 MB = 144 MB activations in + "
-                                    "weight planes, 121 MB out); FETCH_SIZE includes the 1.33x halo re-reads of the 8x32-pixel tiles")
+                    traffic_note = (f"NOT measured in this run: read from profiles/{rdir}/{fn} = rocprofv3 --pmc FETCH_SIZE (x2, gfx950 "
+                                    "correction) + WRITE_SIZE in separate passes of this same command, bytes per launch, mean over the "
+                                    "launches of the forward instantiation (algorithmic mean over the forward launches: 265 MB = 144 MB "
+                                    "activations in + weight planes, 121 MB out); FETCH_SIZE includes the 1.33x halo re-reads of the "
+                                    "8x32-pixel tiles")
             except Exception:
                 pass
             if k3:
@@ -279,8 +365,31 @@ def main():
                 out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
                                    "kernel": kname, "flops_per_launch_avg": k3[0] / k3[2],
-                                   "avg_launch_ms": round(1e3 * k3[1] / k3[2], 4), "peak_note": pnote}
+                                   "avg_launch_ms": round(1e3 * k3[1] / k3[2], 4), "peak_note": pnote,
+                                   "timing": "HIP events on the launch stream around every launch of the kernel, live in this run, "
+                                             "over the K eagerly launched steps of config.instrumented_eager_region"}
             out["kernels"] = kernels
+        if not a.no_other_configs and world == 1 and a.workload == "mean_teacher" and (B, H, W, a.channels) == (4, 512, 512, 1):
+            # BASELINE.json configs[2] / configs[3] per GPU, timed in this same process (short: 2 warm-up + 5 steps each)
+            others = []
+            del run
+            torch.cuda.empty_cache()
+            for wl, ch, size in (("adamt", 1, 512), ("adamatch", 3, 704)):
+                r2 = Runner(wl, a, dev, rank, B, size, size, N, ch, a.conv_mode)
+                if use_graph:
+                    r2.capture()
+                for _ in range(2):
+                    r2.step(use_graph)
+                d2, e2, each2 = timed_region(r2, 5, use_graph, sync, world, dev)
+                g2 = gflop_per_patch(wl, N, size, size, ch)
+                others.append({"workload": f"{wl} (BASELINE.json configs[{2 if wl == 'adamt' else 3}], per GPU): {B} source + {B} target "
+                                           f"patches {size}x{size}x{ch} per step, N={N}",
+                               "ms_per_step": round(1e3 * d2 / 5, 3), "pairs_per_s": round(B * 5 / d2, 3),
+                               "model_tflops": round(g2 * B * 5 / d2 / 1e3, 2), "host_enqueue_ms_per_step": round(1e3 * e2 / 5, 2),
+                               "ms_each_step": each2})
+                del r2
+                torch.cuda.empty_cache()
+            out["config"]["other_configs"] = others
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.workload, N, H, W)
         print(json.dumps(out))

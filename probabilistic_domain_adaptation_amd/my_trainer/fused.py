@@ -170,6 +170,7 @@ def _world():
 
 
 _CAPTURE = None  # the GraphedStep being captured (module state of the capture in progress; captures are not re-entrant)
+COMM_EVENTS = None  # when a list (bench.py): (start, end) HIP events around the exposed part of every gradient all-reduce
 
 
 def allreduce_grads(gflat: torch.Tensor, started: Optional[dict] = None) -> float:
@@ -181,11 +182,18 @@ def allreduce_grads(gflat: torch.Tensor, started: Optional[dict] = None) -> floa
     w = _world()
     if w > 1:
         def finish():
+            ev = COMM_EVENTS
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             if started:
                 dist.all_reduce(gflat[started["numel"]:], op=dist.ReduceOp.SUM)
                 started["work"].wait()
             else:
                 dist.all_reduce(gflat, op=dist.ReduceOp.SUM)
+            if ev is not None:  # the launch stream now waits for the collective: e1 - e0 = what the overlap did not hide
+                e1.record()
+                ev.append((e0, e1))
         if _CAPTURE is not None:
             _CAPTURE.cut(finish)
         else:
