@@ -10,10 +10,13 @@
 
 namespace {
 
+// grid = (ceil(W / (ppb * XITER)), rows <= 65535): a block walks XITER strips of ppb pixels of ONE image row, so the
+// row / batch decomposition is block-uniform and the per-pixel index arithmetic is a handful of 32-bit adds (two 32-bit
+// divisions per pixel had made this store-bound kernel ALU-bound: 3.0 TB/s of stores, r02)
 template <int CIN>
 __global__ __launch_bounds__(256) void conv3x3_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ y,
-                                                               int cout, int B, int H, int W, int relu, int pix_per_block) {
+                                                               int cout, int B, int H, int W, int relu, int xiter) {
     const int groups = cout / 4;
     const int ppb = 256 / groups;
     const int g = threadIdx.x % groups, pl = threadIdx.x / groups;
@@ -22,39 +25,36 @@ __global__ __launch_bounds__(256) void conv3x3_small_fwd_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < 9 * CIN; ++i) wr[i] = *reinterpret_cast<const float4*>(w + (size_t)i * cout + g * 4);
     const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const size_t P = (size_t)B * H * W;
-    const size_t base = (size_t)blockIdx.x * pix_per_block;
-    for (int it = 0; it < pix_per_block; it += ppb) {
-        const size_t p = base + it + pl;
-        if (p >= P) break;
-        // 32-bit index arithmetic (P < 2^31 is checked on the host): 64-bit divisions had made this HBM-bound kernel
-        // VALU-bound
-        const unsigned pu = (unsigned)p, row = pu / (unsigned)W;
-        const int px = (int)(pu - row * (unsigned)W);
-        const unsigned bu = row / (unsigned)H;
-        const int py = (int)(row - bu * (unsigned)H);
-        const size_t b = bu;
-        float4 o = bv;
-        // branch-free taps: all 9 * CIN loads are issued together (clamped address, zero weight outside the image); a
-        // `continue` per tap had serialised them into nine load -> wait -> fma rounds
-        float xin[9 * CIN];
+    for (unsigned row = blockIdx.y; row < (unsigned)(B * H); row += gridDim.y) {  // b * H + py
+        const int py = (int)(row % (unsigned)H);
+        const float* xrow = x + (size_t)row * W * CIN;  // 64-bit base per row, 32-bit offsets inside
+        float* yrow = y + (size_t)row * W * cout + g * 4;
+        const bool up = py > 0, down = py < H - 1;
+        for (int it = 0; it < xiter; ++it) {
+            const int px = ((int)blockIdx.x * xiter + it) * ppb + pl;
+            if (px >= W) break;
+            float4 o = bv;
+            // branch-free taps: all 9 * CIN loads are issued together (clamped address, zero outside the image); a
+            // `continue` per tap had serialised them into nine load -> wait -> fma rounds
+            float xin[9 * CIN];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int gy = py + t / 3 - 1, gx = px + t % 3 - 1;
-            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const float* xp = x + ((b * H + (in ? gy : py)) * W + (in ? gx : px)) * CIN;
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                const bool in = (dy < 0 ? up : (dy > 0 ? down : true)) && px + dx >= 0 && px + dx < W;
+                const float* xp = xrow + (in ? (dy * W + px + dx) * CIN : px * CIN);
 #pragma unroll
-            for (int c = 0; c < CIN; ++c) xin[t * CIN + c] = in ? xp[c] : 0.f;
+                for (int c = 0; c < CIN; ++c) xin[t * CIN + c] = in ? xp[c] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 9 * CIN; ++i) {
+                const float xv = xin[i];
+                const float4 ww = wr[i];
+                o.x = fmaf(xv, ww.x, o.x); o.y = fmaf(xv, ww.y, o.y);
+                o.z = fmaf(xv, ww.z, o.z); o.w = fmaf(xv, ww.w, o.w);
+            }
+            if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            *reinterpret_cast<float4*>(yrow + (size_t)px * cout) = o;
         }
-#pragma unroll
-        for (int i = 0; i < 9 * CIN; ++i) {
-            const float xv = xin[i];
-            const float4 ww = wr[i];
-            o.x = fmaf(xv, ww.x, o.x); o.y = fmaf(xv, ww.y, o.y);
-            o.z = fmaf(xv, ww.z, o.z); o.w = fmaf(xv, ww.w, o.w);
-        }
-        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        *reinterpret_cast<float4*>(y + p * cout + g * 4) = o;
     }
 }
 
@@ -131,16 +131,15 @@ extern "C" int punet_conv3x3_small_fwd(const float* x, int cin, const float* w, 
     PUNET_CHECK_ARG(cin >= 1 && cin <= 4, "punet_conv3x3_small_fwd: cin must be 1..4 (got %d)", cin);
     PUNET_CHECK_ARG(cout >= 4 && cout % 4 == 0 && 256 % (cout / 4) == 0 && cout <= 1024,
                     "punet_conv3x3_small_fwd: cout/4 must divide 256 (got cout=%d)", cout);
-    const size_t P = (size_t)B * H * W;
-    PUNET_CHECK_ARG(P < (1ull << 31), "punet_conv3x3_small_fwd: more than 2^31 pixels");
+    PUNET_CHECK_ARG((unsigned long long)W * (cin > cout ? cin : cout) < (1ull << 31), "punet_conv3x3_small_fwd: image row too long");
     const int ppb = 256 / (cout / 4);
-    const int pix_per_block = ppb * 16;
-    const int grid = (int)((P + pix_per_block - 1) / pix_per_block);
+    const int xiter = 8;
+    const dim3 grid(ceil_div(W, ppb * xiter), B * H < 65535 ? B * H : 65535);
     switch (cin) {
-        case 1: conv3x3_small_fwd_kernel<1><<<grid, 256, 0, stream>>>(x, w, bias, y, cout, B, H, W, relu, pix_per_block); break;
-        case 2: conv3x3_small_fwd_kernel<2><<<grid, 256, 0, stream>>>(x, w, bias, y, cout, B, H, W, relu, pix_per_block); break;
-        case 3: conv3x3_small_fwd_kernel<3><<<grid, 256, 0, stream>>>(x, w, bias, y, cout, B, H, W, relu, pix_per_block); break;
-        default: conv3x3_small_fwd_kernel<4><<<grid, 256, 0, stream>>>(x, w, bias, y, cout, B, H, W, relu, pix_per_block); break;
+        case 1: conv3x3_small_fwd_kernel<1><<<grid, 256, 0, stream>>>(x, w, bias, y, cout, B, H, W, relu, xiter); break;
+        case 2: conv3x3_small_fwd_kernel<2><<<grid, 256, 0, stream>>>(x, w, bias, y, cout, B, H, W, relu, xiter); break;
+        case 3: conv3x3_small_fwd_kernel<3><<<grid, 256, 0, stream>>>(x, w, bias, y, cout, B, H, W, relu, xiter); break;
+        default: conv3x3_small_fwd_kernel<4><<<grid, 256, 0, stream>>>(x, w, bias, y, cout, B, H, W, relu, xiter); break;
     }
     PUNET_LAUNCH_CHECK("conv3x3_small_fwd");
     return PUNET_OK;

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     // selects.  With the loads inside divergent branches the compiler's waitcnt insertion loses track of the vmcnt order
     // across the joins and falls back to s_waitcnt vmcnt(0) - i.e. it waited for the loads it had just issued for the
     // NEXT chunk, three exposed memory latencies per commit.
-    int xpix[XITER];       // (b * H + clamped y) * W + clamped x of the unit's pixel
+    int xpix[XITER];       // clamped y * W + clamped x of the unit's pixel inside its image
+    int xb = 0;            // image of the tile the staging registers are being loaded for (block-uniform)
     bool xin[XITER];       // pixel inside the image
     unsigned wbase[WITER];  // plane, tap and output-channel part of the weight offset (chunk part added per chunk)
     auto retarget = [&](const TileInfo& ti) __attribute__((always_inline)) {
@@ -156,8 +157,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
             const int py = pix / HTW, px = pix % HTW;
             const int gy = ti.ty0 + py - PAD, gx = ti.tx0 + px - PAD;
             xin[it] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            xpix[it] = (ti.b * a.H + min(max(gy, 0), a.H - 1)) * a.W + min(max(gx, 0), a.W - 1);
-        }
+            xpix[it] = min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1);  // inside image xb (32-bit); the image
+        }                                                                          // base is a uniform 64-bit term
+        xb = ti.b;
 #pragma unroll
         for (int it = 0; it < WITER; ++it) {
             const int u = min(tid + it * 256, WUNITS - 1);
@@ -168,8 +170,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     };
     auto load_x = [&](int ch, int it) __attribute__((always_inline)) -> float4 {
         const int kbase = ch * CK;
-        const float* src = kbase < a.c0 ? a.x0 : a.x1;
         const int cs = kbase < a.c0 ? a.c0 : a.c1, coff = kbase < a.c0 ? kbase : kbase - a.c0;
+        // uniform 64-bit image base + 32-bit offset inside the image: B * H * W * C may exceed 2^31 elements, H * W * C not
+        const float* src = (kbase < a.c0 ? a.x0 : a.x1) + (size_t)xb * ((size_t)(a.H * a.W) * cs);
         const int q = min(tid + it * 256, XUNITS - 1) % (CK / 4);  // the same clamped unit index as in retarget / commit
         // raw value: the out-of-image zeroing happens where the register is consumed (split_unit) - a select right here
         // would make the wave wait for the load it has just issued
@@ -242,6 +245,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     // comparisons into one register per row; the input gradient loads its dword once per row.
     auto epilogue = [&](const TileInfo& ti) __attribute__((always_inline)) {
         const int gx = ti.tx0 + l31;
+        // uniform 64-bit base of image ti.b in the output-shaped tensors; offsets inside the image stay 32-bit
+        const size_t img = (size_t)ti.b * ((size_t)(a.H * a.W) * N);
+        float* const yb = a.y + img;
+        const float* const mb = a.mask ? a.mask + img : nullptr;
         // all eight bias quads first (one latency; per-quad loads inside the store loop had been a chain of 16 dependent L2
         // round trips per tile - 16k cycles, 17 % of a 64-channel layer's tile)
         float4 bq4[2][4];
@@ -263,9 +270,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
             const bool in0 = gy0 < a.H && gx < a.W, in1 = gy0 + 1 < a.H && gx < a.W;
             const unsigned gd0 = (unsigned)(((((ti.b * a.H + gy0) * tiles_x + (ti.tx0 / TW)) * ntn + (ti.n0 / TN)) << 6) + lane);
             const unsigned gd1 = gd0 + (unsigned)((tiles_x * ntn) << 6);
-            const unsigned pbase0 = (unsigned)(((ti.b * a.H + gy0) * a.W + gx) * N + ti.n0 + 4 * half);
+            const unsigned pbase0 = (unsigned)((gy0 * a.W + gx) * N + ti.n0 + 4 * half);
             const unsigned pbase1 = pbase0 + (unsigned)(a.W * N);
-            const unsigned qbase = (unsigned)(((ti.b * (a.H >> 1) + (gy0 >> 1)) * (a.W >> 1) + (gx >> 1)) * N + ti.n0 + 4 * half);
+            const unsigned qbase = (unsigned)(((gy0 >> 1) * (a.W >> 1) + (gx >> 1)) * N + ti.n0 + 4 * half);
+            float* const qb = a.pool_out ? a.pool_out + (img >> 2) : nullptr;  // the pooled image has a quarter of the pixels
             unsigned gout0 = 0u, gout1 = 0u;
             auto partner = [](float v) __attribute__((always_inline)) {  // value of lane ^ 1 (quad_perm [1, 0, 3, 2])
                 return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
@@ -286,12 +294,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                         v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
                     }
                     if (in0 && okc) {
-                        *reinterpret_cast<float4*>(a.y + pbase0 + ch) = v0;
+                        *reinterpret_cast<float4*>(yb + pbase0 + ch) = v0;
                         gout0 |= ((v0.x > 0.f ? 1u : 0u) | (v0.y > 0.f ? 2u : 0u) | (v0.z > 0.f ? 4u : 0u) | (v0.w > 0.f ? 8u : 0u))
                                  << (16 * nb + 4 * rg);
                     }
                     if (in1 && okc) {
-                        *reinterpret_cast<float4*>(a.y + pbase1 + ch) = v1;
+                        *reinterpret_cast<float4*>(yb + pbase1 + ch) = v1;
                         gout1 |= ((v1.x > 0.f ? 1u : 0u) | (v1.y > 0.f ? 2u : 0u) | (v1.z > 0.f ? 4u : 0u) | (v1.w > 0.f ? 8u : 0u))
                                  << (16 * nb + 4 * rg);
                     }
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                         q.y = (((v0.y + partner(v0.y)) + v1.y) + partner(v1.y)) * 0.25f;
                         q.z = (((v0.z + partner(v0.z)) + v1.z) + partner(v1.z)) * 0.25f;
                         q.w = (((v0.w + partner(v0.w)) + v1.w) + partner(v1.w)) * 0.25f;
-                        if (!(lane & 1) && in0 && okc) *reinterpret_cast<float4*>(a.pool_out + qbase + ch) = q;
+                        if (!(lane & 1) && in0 && okc) *reinterpret_cast<float4*>(qb + qbase + ch) = q;
                     }
                 }
             if (a.gate_out) {  // forward with ReLU: (y > 0), for the consumers' backward
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
             const int gy = ti.ty0 + 2 * wave + m;
             const bool pix_in = gy < a.H && gx < a.W;
             const unsigned gd = (unsigned)(((((ti.b * a.H + gy) * tiles_x + (ti.tx0 / TW)) * ntn + (ti.n0 / TN)) << 6) + lane);
-            const unsigned pbase = (unsigned)(((ti.b * a.H + gy) * a.W + gx) * N + ti.n0 + 4 * half);
+            const unsigned pbase = (unsigned)((gy * a.W + gx) * N + ti.n0 + 4 * half);
             unsigned gin = 0u, gout = 0u;
             if (DGRAD && a.gate_bits && pix_in) gin = a.gate_bits[gd];
 #pragma unroll
@@ -333,17 +341,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                         v.x = g4 & 1u ? v.x : 0.f; v.y = g4 & 2u ? v.y : 0.f; v.z = g4 & 4u ? v.z : 0.f; v.w = g4 & 8u ? v.w : 0.f;
                     } else if (a.mask) {
                         if (ok) {
-                            const float4 g = *reinterpret_cast<const float4*>(a.mask + pbase + ch);
+                            const float4 g = *reinterpret_cast<const float4*>(mb + pbase + ch);
                             v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f;
                             v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
                         }
                     }
                     if (ok) {
                         if (DGRAD && a.accumulate) {
-                            const float4 o = *reinterpret_cast<const float4*>(a.y + pbase + ch);
+                            const float4 o = *reinterpret_cast<const float4*>(yb + pbase + ch);
                             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                         }
-                        *reinterpret_cast<float4*>(a.y + pbase + ch) = v;
+                        *reinterpret_cast<float4*>(yb + pbase + ch) = v;
                         if (!DGRAD)
                             gout |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u))
                                     << (16 * nb + 4 * rg);
@@ -537,6 +545,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     // kept 7 x 16 bytes + 7 offsets per thread across the K-steps, which is what the fragments of this kernel need).
     float4 rx[XITER];
     int xpix[XITER];
+    int xb = 0;  // image of the tile the staging registers are being loaded for (block-uniform)
     bool xin[XITER];
     unsigned wlane = 0;  // this lane's output-channel offset (elements) inside a weight row
     auto retarget = [&](const TileInfo& ti) __attribute__((always_inline)) {
@@ -547,14 +556,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
             const int py = pix / HTW, px = pix % HTW;
             const int gy = ti.ty0 + py - PAD, gx = ti.tx0 + px - PAD;
             xin[it] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            xpix[it] = (ti.b * a.H + min(max(gy, 0), a.H - 1)) * a.W + min(max(gx, 0), a.W - 1);
-        }
+            xpix[it] = min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1);  // inside image xb (32-bit); the image
+        }                                                                          // base is a uniform 64-bit term
+        xb = ti.b;
         wlane = (unsigned)((a.n_off + min(ti.n0 + lane, N - 1)) * 8);  // columns beyond N copy column N - 1 (never stored)
     };
     auto load_x = [&](int ch, int it) __attribute__((always_inline)) -> float4 {
         const int kbase = ch * CK;
-        const float* src = kbase < a.c0 ? a.x0 : a.x1;
         const int cs = kbase < a.c0 ? a.c0 : a.c1, coff = kbase < a.c0 ? kbase : kbase - a.c0;
+        const float* src = (kbase < a.c0 ? a.x0 : a.x1) + (size_t)xb * ((size_t)(a.H * a.W) * cs);  // uniform image base
         const int q = min(tid + it * 256, XUNITS - 1) % (CK / 4);
         return *reinterpret_cast<const float4*>(src + (unsigned)(xpix[it] * cs + coff + q * 4));
     };
@@ -663,6 +673,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     };
     auto epilogue = [&](const TileInfo& ti) __attribute__((always_inline)) {
         const int cq = ti.n0 + 4 * g;  // + 16 cb: first of this lane's four consecutive channels
+        // uniform 64-bit base of image ti.b in the output-shaped tensors; offsets inside the image stay 32-bit
+        const size_t img = (size_t)ti.b * ((size_t)(a.H * a.W) * N);
+        float* const yb = a.y + img;
+        const float* const mb = a.mask ? a.mask + img : nullptr;
         f32x4 bq[4];
         if (!DGRAD) {
 #pragma unroll
@@ -685,7 +699,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
                 // dword of (pixel, channel) in the punet_gate_dwords layout: (x % 32) + 32 * ((c % 8) / 4) = 16 h + l16 + 32 (g & 1)
                 const unsigned gd = (unsigned)(((((ti.b * a.H + gy) * tiles_x + (ti.tx0 / TW)) * ntn + (ti.n0 / TN)) << 6) +
                                                16 * h + l16 + 32 * (g & 1));
-                const unsigned pbase = (unsigned)(((ti.b * a.H + gy) * a.W + gx) * N + cq);
+                const unsigned pbase = (unsigned)((gy * a.W + gx) * N + cq);
                 unsigned gin = 0u, gout = 0u;
                 if (DGRAD && a.gate_bits && pix_in) gin = a.gate_bits[gd];
 #pragma unroll
@@ -701,14 +715,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
                         v[0] = g4 & 1u ? v[0] : 0.f; v[1] = g4 & 2u ? v[1] : 0.f; v[2] = g4 & 4u ? v[2] : 0.f; v[3] = g4 & 8u ? v[3] : 0.f;
                     } else if (a.mask) {
                         if (ok) {
-                            const f32x4 gm = *reinterpret_cast<const f32x4*>(a.mask + pbase + 16 * cb);
+                            const f32x4 gm = *reinterpret_cast<const f32x4*>(mb + pbase + 16 * cb);
                             v[0] = gm[0] > 0.f ? v[0] : 0.f; v[1] = gm[1] > 0.f ? v[1] : 0.f;
                             v[2] = gm[2] > 0.f ? v[2] : 0.f; v[3] = gm[3] > 0.f ? v[3] : 0.f;
                         }
                     }
                     if (ok) {
-                        if (DGRAD && a.accumulate) v += *reinterpret_cast<const f32x4*>(a.y + pbase + 16 * cb);
-                        *reinterpret_cast<f32x4*>(a.y + pbase + 16 * cb) = v;
+                        if (DGRAD && a.accumulate) v += *reinterpret_cast<const f32x4*>(yb + pbase + 16 * cb);
+                        *reinterpret_cast<f32x4*>(yb + pbase + 16 * cb) = v;
                         if (!DGRAD) gout |= nibble(v) << sh;
                     }
                 }
@@ -721,7 +735,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
             if (!DGRAD && a.pool_out) {  // uniform: AvgPool2d(2, 2) of the output, order ((y00 + y01) + y10) + y11
                 const int gy0 = ti.ty0 + 2 * wave;
                 const bool ok0 = gy0 < a.H && gx < a.W;
-                const unsigned qbase = (unsigned)(((ti.b * (a.H >> 1) + (gy0 >> 1)) * (a.W >> 1) + (gx >> 1)) * N + cq);
+                const unsigned qbase = (unsigned)(((gy0 >> 1) * (a.W >> 1) + (gx >> 1)) * N + cq);
+                float* const qb = a.pool_out + (img >> 2);  // the pooled image has a quarter of the pixels
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
                     f32x4 v0 = acc[h][cb] + bq[cb], v1 = acc[2 + h][cb] + bq[cb], q;  // recomputed: no live copies of the rows
@@ -730,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
                         if (a.relu) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
                         q[e] = (((v0[e] + partner(v0[e])) + v1[e]) + partner(v1[e])) * 0.25f;
                     }
-                    if (!(lane & 1) && ok0 && cq + 16 * cb < N) *reinterpret_cast<f32x4*>(a.pool_out + qbase + 16 * cb) = q;
+                    if (!(lane & 1) && ok0 && cq + 16 * cb < N) *reinterpret_cast<f32x4*>(qb + qbase + 16 * cb) = q;
                 }
             }
         }
@@ -959,11 +974,13 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
     PUNET_CHECK_ARG(n_out > 0 && n_out % 4 == 0 && n_off >= 0 && n_off + n_out <= n_row,
                     "punet_conv3x3_x6: bad output-channel window (n_out must be a multiple of 4)");
     PUNET_CHECK_ARG(B > 0 && H > 0 && W > 0, "punet_conv3x3_x6: bad shape");
-    {   // the kernel does its index arithmetic in 32 bits
-        const unsigned long long px = (unsigned long long)B * H * W;
+    {   // 64-bit image base + 32-bit offsets inside an image: ONE image (not the batch) must stay below 2^31 elements
+        const unsigned long long px = (unsigned long long)H * W;
         const int cmax = c0 > c1 ? (c0 > n_out ? c0 : n_out) : (c1 > n_out ? c1 : n_out);
         PUNET_CHECK_ARG(px * cmax < (1ull << 31) && 3ull * (unsigned long long)plane_stride < (1ull << 31),
-                        "punet_conv3x3_x6: tensor too large for 32-bit indexing (%llu pixels x %d channels)", px, cmax);
+                        "punet_conv3x3_x6: one image is too large for 32-bit offsets (%llu pixels x %d channels)", px, cmax);
+        PUNET_CHECK_ARG((unsigned long long)B * H * ceil_div(W, TW) * ceil_div(n_out, TN) * 64ull < (1ull << 32) &&
+                        (unsigned long long)B * px < (1ull << 31), "punet_conv3x3_x6: too many pixels for the tile / gate indices");
     }
     ConvX6Args a{};
     a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1;

@@ -14,6 +14,9 @@ inline int ew_grid(size_t n, int cap = 4096) {
     if (g < 1) g = 1;
     return (int)g;
 }
+inline int pow2_shift(int v) {  // log2(v) when v is a power of two, else -1
+    return v > 0 && (v & (v - 1)) == 0 ? __builtin_ctz((unsigned)v) : -1;
+}
 #define GRID_STRIDE(i, n) \
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (size_t)gridDim.x * blockDim.x)
 
@@ -103,19 +106,22 @@ __global__ void pool2x2_fwd_kernel(const float4* __restrict__ x, float4* __restr
 }
 
 // dx[b][iy][ix] (+)= (x > 0) * dy[b][iy/2][ix/2] / window
-__global__ void pool2x2_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ xmask,
-                                   const unsigned* __restrict__ xbits, float4* __restrict__ dx, int B, int H, int W, int C4,
-                                   int accumulate) {
+// grid = (ceil(W * C4 / 256), B * H): the row-wise index arithmetic is block-uniform, a thread does one division (a shift
+// when C4 is a power of two) instead of three per element of a grid-stride loop - these kernels were ALU-bound on the
+// index arithmetic, not HBM-bound (2.8 TB/s; r02: see profiles/r02/README.md)
+__global__ __launch_bounds__(256) void pool2x2_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ xmask,
+                                                          const unsigned* __restrict__ xbits, float4* __restrict__ dx, int B,
+                                                          int H, int W, int C4, int c4_shift, int accumulate) {
     const int OH = (H + 1) / 2, OW = (W + 1) / 2;
-    const size_t n = (size_t)B * H * W * C4;
-    GRID_STRIDE(i, n) {
-        unsigned p = (unsigned)i / (unsigned)C4;  // 32-bit index arithmetic (n < 2^31 checked on the host)
-        const int c = (int)((unsigned)i - p * (unsigned)C4);
-        unsigned q = p / (unsigned)W;
-        const int ix = (int)(p - q * (unsigned)W);
-        const unsigned bu = q / (unsigned)H;
-        const int iy = (int)(q - bu * (unsigned)H);
+    for (unsigned row = blockIdx.y; row < (unsigned)(B * H); row += gridDim.y) {  // b * rows + y
+        const unsigned bu = row / (unsigned)H;
+        const int iy = (int)(row - bu * (unsigned)H);
+        const unsigned e = blockIdx.x * 256u + threadIdx.x;
+        if (e >= (unsigned)(W * C4)) return;
+        const int ix = c4_shift >= 0 ? (int)(e >> c4_shift) : (int)(e / (unsigned)C4);
+        const int c = (int)e - ix * C4;
         const size_t b = bu;
+        const size_t i = (size_t)row * W * C4 + e;
         const int oy = iy / 2, ox = ix / 2;
         const int wh = min(oy * 2 + 2, H) - oy * 2, ww = min(ox * 2 + 2, W) - ox * 2;
         const float inv = 1.f / (float)(wh * ww);
@@ -152,18 +158,19 @@ __device__ __forceinline__ void up_src(int o, float scale, int in_size, int& i0,
     l1 = src - (float)i0;
 }
 
-__global__ void upsample2x_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ y, int B, int H, int W, int C4) {
+// grid = (ceil(OW * C4 / 256), B * OH): the source row, its neighbour and the row weight are block-uniform
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ y, int B, int H,
+                                                             int W, int C4, int c4_shift) {
     const int OH = 2 * H, OW = 2 * W;
     const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
     const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
-    const size_t n = (size_t)B * OH * OW * C4;
-    GRID_STRIDE(i, n) {
-        unsigned p = (unsigned)i / (unsigned)C4;  // 32-bit index arithmetic (n < 2^31 checked on the host)
-        const int c = (int)((unsigned)i - p * (unsigned)C4);
-        unsigned q = p / (unsigned)OW;
-        const int ox = (int)(p - q * (unsigned)OW);
-        const unsigned bu = q / (unsigned)OH;
-        const int oy = (int)(q - bu * (unsigned)OH);
+    for (unsigned row = blockIdx.y; row < (unsigned)(B * OH); row += gridDim.y) {  // b * rows + y
+        const unsigned bu = row / (unsigned)OH;
+        const int oy = (int)(row - bu * (unsigned)OH);
+        const unsigned e = blockIdx.x * 256u + threadIdx.x;
+        if (e >= (unsigned)(OW * C4)) return;
+        const int ox = c4_shift >= 0 ? (int)(e >> c4_shift) : (int)(e / (unsigned)C4);
+        const int c = (int)e - ox * C4;
         const size_t b = bu;
         int h1, hp, w1, wp;
         float hl1, wl1;
@@ -179,7 +186,7 @@ __global__ void upsample2x_fwd_kernel(const float4* __restrict__ x, float4* __re
         o.y = hl0 * (wl0 * v00.y + wl1 * v01.y) + hl1 * (wl0 * v10.y + wl1 * v11.y);
         o.z = hl0 * (wl0 * v00.z + wl1 * v01.z) + hl1 * (wl0 * v10.z + wl1 * v11.z);
         o.w = hl0 * (wl0 * v00.w + wl1 * v01.w) + hl1 * (wl0 * v10.w + wl1 * v11.w);
-        y[i] = o;
+        y[(size_t)row * OW * C4 + e] = o;
     }
 }
 
@@ -194,33 +201,39 @@ __device__ __forceinline__ float up_weight(int o, int i, float scale, int in_siz
     return w;
 }
 
-// dx[b][iy][ix] = (x > 0) * sum_{oy, ox} wy(oy, iy) * wx(ox, ix) * dy[b][oy][ox]
-__global__ void upsample2x_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ xmask,
-                                      const unsigned* __restrict__ xbits, float4* __restrict__ dx, int B, int H, int W,
-                                      int C4) {
+// dx[b][iy][ix] = (x > 0) * sum_{oy, ox} wy(oy, iy) * wx(ox, ix) * dy[b][oy][ox]   (gather form: deterministic)
+// grid = (ceil(W * C4 / 256), B * H); the (up to 7) row weights are block-uniform, the column weights are computed once
+// per thread instead of once per (oy, ox) pair; summation order (oy outer, ox inner, zero weights skipped) as before
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ xmask,
+                                                             const unsigned* __restrict__ xbits, float4* __restrict__ dx, int B,
+                                                             int H, int W, int C4, int c4_shift) {
     const int OH = 2 * H, OW = 2 * W;
     const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
     const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
-    const size_t n = (size_t)B * H * W * C4;
-    GRID_STRIDE(i, n) {
-        unsigned p = (unsigned)i / (unsigned)C4;  // 32-bit index arithmetic (n < 2^31 checked on the host)
-        const int c = (int)((unsigned)i - p * (unsigned)C4);
-        unsigned q = p / (unsigned)W;
-        const int ix = (int)(p - q * (unsigned)W);
-        const unsigned bu = q / (unsigned)H;
-        const int iy = (int)(q - bu * (unsigned)H);
+    for (unsigned row = blockIdx.y; row < (unsigned)(B * H); row += gridDim.y) {  // b * rows + y
+        const unsigned bu = row / (unsigned)H;
+        const int iy = (int)(row - bu * (unsigned)H);
+        const unsigned e = blockIdx.x * 256u + threadIdx.x;
+        if (e >= (unsigned)(W * C4)) return;
+        const int ix = c4_shift >= 0 ? (int)(e >> c4_shift) : (int)(e / (unsigned)C4);
+        const int c = (int)e - ix * C4;
         const size_t b = bu;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        const size_t i = (size_t)row * W * C4 + e;
         const int oy0 = max(0, 2 * iy - 2), oy1 = min(OH - 1, 2 * iy + 4);
         const int ox0 = max(0, 2 * ix - 2), ox1 = min(OW - 1, 2 * ix + 4);
+        float wx[7];
+    #pragma unroll
+        for (int k = 0; k < 7; ++k) wx[k] = ox0 + k <= ox1 ? up_weight(ox0 + k, ix, sw, W) : 0.f;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int oy = oy0; oy <= oy1; ++oy) {
             const float wy = up_weight(oy, iy, sh, H);
             if (wy == 0.f) continue;
-            for (int ox = ox0; ox <= ox1; ++ox) {
-                const float wx = up_weight(ox, ix, sw, W);
-                if (wx == 0.f) continue;
-                const float4 g = dy[((b * OH + oy) * OW + ox) * C4 + c];
-                const float wgt = wy * wx;
+            const float4* drow = dy + ((b * OH + oy) * OW + ox0) * C4 + c;
+    #pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                if (wx[k] == 0.f) continue;
+                const float4 g = drow[(size_t)k * C4];
+                const float wgt = wy * wx[k];
                 s.x += wgt * g.x; s.y += wgt * g.y; s.z += wgt * g.z; s.w += wgt * g.w;
             }
         }
@@ -975,8 +988,8 @@ extern "C" int punet_pool2x2_bwd_gated(const float* dy, const float* xmask, cons
     PUNET_CHECK_ARG(dy && dx && C % 4 == 0 && B > 0 && H > 0 && W > 0, "punet_pool2x2_bwd: bad args (C=%d)", C);
     const size_t n = (size_t)B * H * W * (C / 4);
     PUNET_CHECK_ARG(n < (1ull << 31), "punet_pool2x2_bwd: more than 2^31 float4 elements");
-    pool2x2_bwd_kernel<<<ew_grid(n), EW_BLOCK, 0, STREAM>>>((const float4*)dy, (const float4*)xmask, (const unsigned*)xbits,
-                                                            (float4*)dx, B, H, W, C / 4, accumulate);
+    pool2x2_bwd_kernel<<<dim3(ceil_div(W * (C / 4), 256), B * H < 65535 ? B * H : 65535), 256, 0, STREAM>>>(
+        (const float4*)dy, (const float4*)xmask, (const unsigned*)xbits, (float4*)dx, B, H, W, C / 4, pow2_shift(C / 4), accumulate);
     PUNET_LAUNCH_CHECK("pool2x2_bwd");
     return PUNET_OK;
 }
@@ -985,7 +998,8 @@ extern "C" int punet_upsample2x_fwd(const float* x, float* y, int B, int H, int 
     PUNET_CHECK_ARG(x && y && C % 4 == 0 && B > 0 && H > 0 && W > 0, "punet_upsample2x_fwd: bad args (C=%d)", C);
     const size_t n = (size_t)B * 4 * H * W * (C / 4);
     PUNET_CHECK_ARG(n < (1ull << 31), "punet_upsample2x_fwd: more than 2^31 float4 elements");
-    upsample2x_fwd_kernel<<<ew_grid(n), EW_BLOCK, 0, STREAM>>>((const float4*)x, (float4*)y, B, H, W, C / 4);
+    upsample2x_fwd_kernel<<<dim3(ceil_div(2 * W * (C / 4), 256), B * 2 * H < 65535 ? B * 2 * H : 65535), 256, 0, STREAM>>>((const float4*)x, (float4*)y, B, H, W,
+                                                                                              C / 4, pow2_shift(C / 4));
     PUNET_LAUNCH_CHECK("upsample2x_fwd");
     return PUNET_OK;
 }
@@ -1000,8 +1014,8 @@ extern "C" int punet_upsample2x_bwd_gated(const float* dy, const float* xmask, c
     PUNET_CHECK_ARG(dy && dx && C % 4 == 0 && B > 0 && H > 0 && W > 0, "punet_upsample2x_bwd: bad args (C=%d)", C);
     const size_t n = (size_t)B * H * W * (C / 4);
     PUNET_CHECK_ARG(n < (1ull << 31), "punet_upsample2x_bwd: more than 2^31 float4 elements");
-    upsample2x_bwd_kernel<<<ew_grid(n), EW_BLOCK, 0, STREAM>>>((const float4*)dy, (const float4*)xmask, (const unsigned*)xbits,
-                                                               (float4*)dx, B, H, W, C / 4);
+    upsample2x_bwd_kernel<<<dim3(ceil_div(W * (C / 4), 256), B * H < 65535 ? B * H : 65535), 256, 0, STREAM>>>(
+        (const float4*)dy, (const float4*)xmask, (const unsigned*)xbits, (float4*)dx, B, H, W, C / 4, pow2_shift(C / 4));
     PUNET_LAUNCH_CHECK("upsample2x_bwd");
     return PUNET_OK;
 }

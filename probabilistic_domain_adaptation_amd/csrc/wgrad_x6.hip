@@ -37,6 +37,15 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WTH = 2, WTW = 32, WC = 64;
+// experiment knobs (tools/ab_variants.sh builds one library per setting): taps owned by waves 0-3 (the rest go to waves
+// 4-7) and a static s_setprio for one half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+#ifndef PUNET_WGRAD_T0
+#define PUNET_WGRAD_T0 5
+#endif
+#ifndef PUNET_WGRAD_PRIO
+#define PUNET_WGRAD_PRIO 0  // 0: none, 1: waves 4-7 at priority 1, 2: waves 0-3 at priority 1
+#endif
+constexpr int GT0 = PUNET_WGRAD_T0, GT1 = 9 - GT0, GTMAX = GT0 > GT1 ? GT0 : GT1;
 constexpr int HTH = WTH + 2, HTW = WTW + 2;
 constexpr int NPX = HTH * HTW;   // 136 halo pixels
 constexpr int NPD = WTH * WTW;   // 64 pixels
@@ -76,7 +85,7 @@ __device__ __forceinline__ s16x4 tr_read(const char* lds_base, int byte_off) {
 // LDS writes into the other image set), i.e. in the same instruction stream as the MFMAs - a wave's own VALU / LDS work
 // issues in the shadow of its own MFMAs, whereas a separate staging phase leaves the matrix pipe idle.
 template <int NP, int T0, int NT, typename F>
-__device__ __forceinline__ void tile_mfma(f32x16 (&acc)[5], const char* sX, const char* sD, int cib, int cob, int aoff, int boff,
+__device__ __forceinline__ void tile_mfma(f32x16 (&acc)[GTMAX], const char* sX, const char* sD, int cib, int cob, int aoff, int boff,
                                           F&& between) {
     constexpr int P1 = NP > 1 ? 1 : 0, P2 = NP > 2 ? 2 : 0;  // plane indices that exist for this NP
 #pragma unroll
@@ -116,7 +125,7 @@ __device__ __forceinline__ void tile_mfma(f32x16 (&acc)[5], const char* sX, cons
 }
 
 template <int T0, int NT>
-__device__ __forceinline__ void store_partial(const f32x16 (&acc)[5], const WgradX6Args& a, int slice, int ci_base, int co, int half) {
+__device__ __forceinline__ void store_partial(const f32x16 (&acc)[GTMAX], const WgradX6Args& a, int slice, int ci_base, int co, int half) {
     if (co >= a.cout) return;
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt)
@@ -153,9 +162,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
     const int tiles_x = (a.W + WTW - 1) / WTW, tiles_y = (a.H + WTH - 1) / WTH;
     const int ntiles = a.B * tiles_x * tiles_y;
 
-    f32x16 acc[5];
+    f32x16 acc[GTMAX];
 #pragma unroll
-    for (int t = 0; t < 5; ++t)
+    for (int t = 0; t < GTMAX; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -172,7 +181,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
         const int tyi = sid % tiles_y;
         const int b = sid / tiles_y;
         const int ty0 = tyi * WTH, tx0 = txi * WTW;
-        // branch-free (clamped address + select) with 32-bit offsets: one basic block, exact vmcnt waits
+        // branch-free (clamped address + select) with 32-bit offsets: one basic block, exact vmcnt waits.  The image base is
+        // a uniform 64-bit term, so only ONE image (not the batch) has to stay below 2^31 elements.
+        const float* const xb = a.x + (size_t)b * ((size_t)(a.H * a.W) * a.cs);
+        const float* const db = a.dz + (size_t)b * ((size_t)(a.H * a.W) * a.cout);
         inmask = 0u;
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
             const int c = ci0 + c4 * 4;
             const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < a.cs;
             const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1), cc = min(c, a.cs - 4);
-            rx[it] = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * a.H + cy) * a.W + cx) * a.cs + cc));
+            rx[it] = *reinterpret_cast<const float4*>(xb + (unsigned)((cy * a.W + cx) * a.cs + cc));
             inmask = in ? inmask | (1u << it) : inmask;  // zeroing happens at the consumer: no wait on the load just issued
         }
 #pragma unroll
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
             const int c = co0 + c4 * 4;
             const bool in = gy < a.H && gx < a.W && c < a.cout;
             const int cy = min(gy, a.H - 1), cx = min(gx, a.W - 1), cc = min(c, a.cout - 4);
-            rd[it] = *reinterpret_cast<const float4*>(a.dz + (unsigned)(((b * a.H + cy) * a.W + cx) * a.cout + cc));
+            rd[it] = *reinterpret_cast<const float4*>(db + (unsigned)((cy * a.W + cx) * a.cout + cc));
             inmask = in ? inmask | (1u << (XIT + it)) : inmask;
         }
     };
@@ -248,6 +260,11 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
 #ifdef PUNET_WGRAD_TRACE
     int trace_iter = 0;
 #endif
+#if PUNET_WGRAD_PRIO == 1
+    if (__builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_setprio(1);
+#elif PUNET_WGRAD_PRIO == 2
+    if (__builtin_amdgcn_readfirstlane(tid) < 256) __builtin_amdgcn_s_setprio(1);
+#endif
     if (slice < ntiles) {
         prefetch(slice);
         commit(0);
@@ -275,15 +292,15 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
         static_assert(XIT >= 4 && NPD / 16 == 4, "staging schedule assumes four pixel groups and at least four X units");
         if (has_next) {
             if (group == 0)
-                tile_mfma<NP, 0, 5>(acc, sX, sD, cib, cob, lane_off, lane_off, between);
+                tile_mfma<NP, 0, GT0>(acc, sX, sD, cib, cob, lane_off, lane_off, between);
             else
-                tile_mfma<NP, 5, 4>(acc, sX, sD, cib, cob, lane_off, lane_off, between);
+                tile_mfma<NP, GT0, GT1>(acc, sX, sD, cib, cob, lane_off, lane_off, between);
         } else {  // last tile of this slice: nothing to stage (and the dZ column sums must not count a tile twice)
             auto nothing = [](int) {};
             if (group == 0)
-                tile_mfma<NP, 0, 5>(acc, sX, sD, cib, cob, lane_off, lane_off, nothing);
+                tile_mfma<NP, 0, GT0>(acc, sX, sD, cib, cob, lane_off, lane_off, nothing);
             else
-                tile_mfma<NP, 5, 4>(acc, sX, sD, cib, cob, lane_off, lane_off, nothing);
+                tile_mfma<NP, GT0, GT1>(acc, sX, sD, cib, cob, lane_off, lane_off, nothing);
         }
         WGT(10);
         __syncthreads();
@@ -296,9 +313,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
 
     const int co = co0 + cob * 32 + l31;
     if (group == 0)
-        store_partial<0, 5>(acc, a, slice, ci0 + cib * 32, co, half);
+        store_partial<0, GT0>(acc, a, slice, ci0 + cib * 32, co, half);
     else
-        store_partial<5, 4>(acc, a, slice, ci0 + cib * 32, co, half);
+        store_partial<GT0, GT1>(acc, a, slice, ci0 + cib * 32, co, half);
 
     if (a.bias_partial && ci_tile == 0) {  // block-uniform
         __syncthreads();
@@ -354,8 +371,8 @@ extern "C" int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int 
                     "punet_conv_wgrad_x6: channels must be multiples of 4 (cs=%d cout=%d)", cs, cout);
     PUNET_CHECK_ARG(ci_off >= 0 && ci_off + cs <= cin_total, "punet_conv_wgrad_x6: bad channel window");
     PUNET_CHECK_ARG(nslices >= 1, "punet_conv_wgrad_x6: nslices must be >= 1");
-    PUNET_CHECK_ARG((unsigned long long)B * H * W * (cs > cout ? cs : cout) < (1ull << 31),
-                    "punet_conv_wgrad_x6: tensor too large for 32-bit indexing");
+    PUNET_CHECK_ARG((unsigned long long)H * W * (cs > cout ? cs : cout) < (1ull << 31) && (unsigned long long)B * H * W < (1ull << 31),
+                    "punet_conv_wgrad_x6: one image is too large for 32-bit offsets");
     WgradX6Args a{};
     a.x = x; a.cs = cs; a.dz = dz; a.cout = cout;
     a.partial = workspace;

@@ -65,8 +65,9 @@ class ParamLayout:
         pre = "unet." if kind == "punet" else ""
         if num_classes != 1:
             raise ValueError("the HIP path implements num_classes == 1 (every reference script uses 1)")
-        if nf[0] not in (32, 64) or any(f % 32 for f in nf):
-            raise ValueError("num_filters must be multiples of 32 with num_filters[0] in {32, 64}")
+        if nf[0] not in (32, 64) or any(f % 8 for f in nf):
+            raise ValueError("num_filters must be multiples of 8 (the MFMA kernels contract 8 channels per K block) with "
+                             "num_filters[0] in {32, 64} (the Fcomb sampler keeps one pixel's channels in registers)")
         if not 1 <= input_channels <= 3:
             raise ValueError("input_channels must be 1..3")
         if no_convs_fcomb < 2:

@@ -69,3 +69,45 @@ def test_smallest_and_ragged_shapes_match_oracle(model, B, H, W, n):
     safe = ((probs - 0.9).abs().min(0).values > 1e-5) & ((probs - 0.1).abs().min(0).values > 1e-5)
     assert torch.equal(cz.cpu()[safe], ref_mask[safe])
     assert (ym.cpu() - probs.mean(0)).abs().max() < 1e-4
+
+
+def test_filters_that_are_multiples_of_8_not_32():
+    """num_filters = [32, 40, 72, 104]: widths that are multiples of 8 but not of 32 go through the 32x32x16 kernels (the
+    16x16x32 kernel needs a multiple of 32) - whole training path (logits, loss scalars, all gradients) against the oracle."""
+    import numpy as np
+    import torch
+    from oracle import punet_oracle as O
+    from probabilistic_domain_adaptation_amd.engine import ParamLayout, PUNetEngine
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda:0")
+    nf, B, H, W = [32, 40, 72, 104], 2, 40, 56
+    cfg = O.PUNetConfig(1, 1, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    Pnp = O.synth_params(cfg.spec(), 6)
+    lay = ParamLayout(1, 1, nf, 6, 3)
+    eng = PUNetEngine(lay, dev)
+    flat = torch.zeros(lay.numel, device=dev)
+    for k, v in lay.views(flat).items():
+        v.copy_(torch.from_numpy(Pnp[k]))
+    x, x1, x2, y = O.synth_batch(B, 1, H, W, 8)
+    eps = torch.randn(1, 6, generator=torch.Generator().manual_seed(9)).expand(B, 6).contiguous()
+    consm = (torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(3)) > 0.3).float()
+    taps = {}
+    st = eng.elbo_forward(flat, eng.to_nhwc(x2.to(dev)), y.to(dev), consm.to(dev), eps.to(dev), "bce", 1.0, 1.0, True, taps)
+    g = torch.full((lay.numel,), float("nan"), device=dev)
+    eng.elbo_backward(flat, g, st, False)
+    torch.cuda.synchronize()
+    gates = {k[5:]: (v.t > 0).permute(0, 3, 1, 2).cpu() for k, v in taps.items() if k.startswith("conv:")}
+    P = O.to_torch(Pnp, requires_grad=True)
+    O.RELU_GATES = gates
+    try:
+        lo, aux = O.training_loss(P, cfg, x2, y, consm, eps, reg_weight=0.0)
+        go = O.grads_of(lo, P)
+    finally:
+        O.RELU_GATES = None
+    assert (st["logits"].cpu() - aux["reconstruction"].detach()).abs().max().item() < 1e-3
+    np.testing.assert_allclose([st["rec"].item(), st["kl"].item()], [aux["reconstruction_loss"].item(), aux["kl"].item()], rtol=2e-4)
+    gv = lay.views(g)
+    for k, ref in go.items():
+        e = (gv[k].cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-8)
+        assert e < 5e-4, (k, e)

@@ -209,3 +209,68 @@ def test_conv_kernels_are_exactly_linear_in_powers_of_two(dev):
         xsh[:, y0:y1_, x0:x1_] = xs[:, y0 + ky - 1:y1_ + ky - 1, x0 + kx - 1:x1_ + kx - 1, ci]
         ref = (xsh * ds[..., co]).sum().item()
         assert abs(dw1[ky, kx, ci, co].item() - ref) < 2e-5 * (xsh.abs() * ds[..., co].abs()).sum().item() ** 0.5 + 1e-3 * abs(ref)
+
+
+def test_batch_tensors_beyond_2e31_elements(dev):
+    """The split-plane kernels address with a uniform 64-bit image base + 32-bit offsets inside the image (round 1 refused
+    tensors of 2^31 elements or more): a [9, 1024, 1024, 256] input (2.36e9 elements, 9.4 GB) through forward conv (incl.
+    gate bits + fused pooling), gated input gradient and weight gradient - against the same kernels run image by image."""
+    from probabilistic_domain_adaptation_amd import _lib as L
+    S = torch.cuda.current_stream().cuda_stream
+    B, H, W, cin, cout = 9, 1024, 1024, 256, 64
+    assert B * H * W * cin >= 2 ** 31
+    g = torch.Generator(device=dev).manual_seed(12)
+    x = torch.randn(B, H, W, cin, device=dev, generator=g)
+    w = (torch.randn(3, 3, cin, cout, generator=torch.Generator().manual_seed(1)) / 48.0).to(dev)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(2)).to(dev)
+    nw = 9 * cin * cout
+    pf, pd = [torch.empty(3 * nw, dtype=torch.bfloat16, device=dev) for _ in range(2)]
+    L.call("punet_split_weights_x6", w.data_ptr(), pf.data_ptr(), nw, cin, cout, 3, 0, S)
+    L.call("punet_split_weights_x6", w.data_ptr(), pd.data_ptr(), nw, cin, cout, 3, 1, S)
+    gd = L.call("punet_gate_dwords", B, H, W, cout)
+    gd1 = L.call("punet_gate_dwords", 1, H, W, cout)
+    assert gd == B * gd1
+
+    def fwd(xx, b):
+        y = torch.empty(b, H, W, cout, device=dev)
+        q = torch.empty(b, H // 2, W // 2, cout, device=dev)
+        bits = torch.empty(b * gd1, dtype=torch.int32, device=dev)
+        L.call("punet_conv3x3_x6_pooled", xx.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, bias.data_ptr(), 0, y.data_ptr(), cout,
+               bits.data_ptr(), q.data_ptr(), 1, b, H, W, 0, S)
+        return y, q, bits
+
+    y, q, bits = fwd(x, B)
+    for b in (0, B - 1):  # the first image and the one whose elements start beyond 2^31
+        y1, q1, bits1 = fwd(x[b:b + 1], 1)
+        torch.cuda.synchronize()
+        assert torch.equal(y[b:b + 1], y1) and torch.equal(q[b:b + 1], q1) and torch.equal(bits[b * gd1:(b + 1) * gd1], bits1)
+    # gated, accumulating input gradient of a conv cout -> cin (dz has `cout` channels, dx `cin`): dx beyond 2^31 elements
+    dz = torch.randn(B, H, W, cout, device=dev, generator=g)
+    xb = torch.empty(B * L.call("punet_gate_dwords", 1, H, W, cin), dtype=torch.int32, device=dev)
+    xb.random_(generator=g)  # some gate pattern of the [B,H,W,cin] tensor
+    ngx = xb.numel() // B
+    dx = torch.ones(B, H, W, cin, device=dev)
+    L.call("punet_conv3x3_x6_gated", dz.data_ptr(), cout, None, 0, pd.data_ptr(), nw, cin, 0, None, 0, dx.data_ptr(), cin, None,
+           xb.data_ptr(), None, 1, 0, B, H, W, 0, S)
+    for b in (0, B - 1):
+        d1 = torch.ones(1, H, W, cin, device=dev)
+        L.call("punet_conv3x3_x6_gated", dz[b:b + 1].data_ptr(), cout, None, 0, pd.data_ptr(), nw, cin, 0, None, 0, d1.data_ptr(), cin,
+               None, xb[b * ngx:(b + 1) * ngx].data_ptr(), None, 1, 0, 1, H, W, 0, S)
+        torch.cuda.synchronize()
+        assert torch.equal(dx[b:b + 1], d1)
+    del dx
+    # weight gradient over all nine images == sum of the per-image weight gradients (split-K orders differ: tolerance)
+    ns = L.call("punet_wgrad_x6_slices", cin, cout, B, H, W)
+    ws = torch.empty(L.call("punet_wgrad_workspace_floats", cin, cout, 3, ns), device=dev)
+    dw, db = torch.empty(3, 3, cin, cout, device=dev), torch.empty(cout, device=dev)
+    L.call("punet_conv_wgrad_x6", x.data_ptr(), cin, dz.data_ptr(), cout, dw.data_ptr(), cin, 0, db.data_ptr(), ws.data_ptr(), ns, B, H, W,
+           0, 1.0, 0, S)
+    acc_w, acc_b = torch.zeros_like(dw), torch.zeros_like(db)
+    ns1 = L.call("punet_wgrad_x6_slices", cin, cout, 1, H, W)
+    ws1 = torch.empty(L.call("punet_wgrad_workspace_floats", cin, cout, 3, ns1), device=dev)
+    for b in range(B):
+        L.call("punet_conv_wgrad_x6", x[b:b + 1].data_ptr(), cin, dz[b:b + 1].data_ptr(), cout, acc_w.data_ptr(), cin, 0, acc_b.data_ptr(),
+               ws1.data_ptr(), ns1, 1, H, W, 1, 1.0, 0, S)
+    torch.cuda.synchronize()
+    assert (dw - acc_w).abs().max().item() <= 2e-5 * acc_w.abs().max().item()
+    assert (db - acc_b).abs().max().item() <= 2e-5 * acc_b.abs().max().item()
