@@ -251,8 +251,15 @@ def main():
     use_graph = not a.no_graph
     run = Runner(a.workload, a, dev, rank, B, H, W, N, a.channels, a.conv_mode)
     eng = run.model.engine
+    graph_note = None
     if use_graph:
-        run.capture()
+        try:
+            run.capture()
+        except Exception as ex:  # never lose the measurement to the capture: fall back to eager launches and say so
+            graph_note = f"graph capture failed ({type(ex).__name__}: {ex}); the timed steps were launched eagerly"
+            print("[bench] " + graph_note, file=sys.stderr)
+            use_graph = False
+            FU._CAPTURE = None
     for _ in range(a.warmup):
         run.step(use_graph)
     comm = [] if world > 1 else None
@@ -293,8 +300,9 @@ def main():
             "config": {"workload": f"PUNet {a.workload} step: nf={NF}, latent 6, fcomb 3, BCE+KL, consensus masking, "
                                    f"{H}x{W}x{a.channels} patches, batch {B}/GPU, N={N} MC samples, Adam lr 1e-5, EMA 0.999",
                        "global_batch": world * B, "parallelism": f"dp{world}",
-                       "launch": "hipGraph replay of the captured fused step (one graph launch per step)" if use_graph
-                                 else "eager: ~500 kernel launches per step from Python",
+                       "launch": "hipGraph replay of the captured fused step (one graph launch per step"
+                                 + (f"; {len(run.graphed.segments)} segments cut at the gradient all-reduces)" if world > 1 else ")")
+                                 if use_graph else (graph_note or "eager: ~500 kernel launches per step from Python"),
                        "algorithmic_gflop_per_patch": gf,
                        "model_tflops_per_gpu": round(gf * patches / dt / world / 1e3, 2),
                        "host_enqueue_ms_per_step": round(1e3 * t_enq / a.steps, 2),
@@ -376,11 +384,15 @@ def main():
             torch.cuda.empty_cache()
             for wl, ch, size in (("adamt", 1, 512), ("adamatch", 3, 704)):
                 r2 = Runner(wl, a, dev, rank, B, size, size, N, ch, a.conv_mode)
-                if use_graph:
-                    r2.capture()
+                g2ok = use_graph
+                if g2ok:
+                    try:
+                        r2.capture()
+                    except Exception:
+                        g2ok, FU._CAPTURE = False, None
                 for _ in range(2):
-                    r2.step(use_graph)
-                d2, e2, each2 = timed_region(r2, 5, use_graph, sync, world, dev)
+                    r2.step(g2ok)
+                d2, e2, each2 = timed_region(r2, 5, g2ok, sync, world, dev)
                 g2 = gflop_per_patch(wl, N, size, size, ch)
                 others.append({"workload": f"{wl} (BASELINE.json configs[{2 if wl == 'adamt' else 3}], per GPU): {B} source + {B} target "
                                            f"patches {size}x{size}x{ch} per step, N={N}",

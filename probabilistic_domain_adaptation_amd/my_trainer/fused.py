@@ -337,8 +337,10 @@ class GraphedStep:
         try:
             with torch.cuda.stream(self._stream):
                 self._begin()
-                self.outputs = body(inputs)
-                self._end()
+                try:
+                    self.outputs = body(inputs)
+                finally:
+                    self._end()  # also on failure: never leave a stream in capture mode behind
         finally:
             _CAPTURE = None
         torch.cuda.current_stream(dev).wait_stream(self._stream)
