@@ -207,6 +207,23 @@ int punet_fcomb_sample(const float* feat, const float* w1, const float* zb, cons
                        float* logits, int N, int B, int HW, int CH, int nmid, float upper, float lower, int masking,
                        void* stream);
 
+/* ---- K7t: the single-sample Fcomb of the TRAINING path in one persistent kernel: forward (probabilistic_unet.py:200-214 with
+ *      the z term folded into zb[B][CH]), BCE criterion with the consensus mask (:360-369) and the whole backward - dfeat
+ *      (gated by feat > 0, i.e. the gradient w.r.t. the pre-activation of the U-Net's last conv) and, as per-workgroup slabs in
+ *      `workspace`, every weight / bias gradient.  punet_fcomb_train_reduce then sums the slabs into the gradient tensors
+ *      (w1 has w1_rows = CH + latent_dim rows, rows [0, CH) are written) and produces S[B][CH], the per-image column sums
+ *      that punet_fcomb_z_bwd takes.  Supported: CH in {32, 64}, at most one middle layer (no_convs_fcomb <= 3), H*W % 32 == 0;
+ *      otherwise (and for the Dice criterion) the caller uses the per-op entry points above. */
+int punet_fcomb_train_supported(int CH, int nmid, int HW);
+size_t punet_fcomb_train_workspace_floats(int B, int HW, int CH, int nmid);
+int punet_fcomb_train_fwd_bwd(const float* feat, const float* w1, const float* zb, const float* wmid, const float* bmid,
+                              const float* w3, const float* b3, const float* target, const float* consm, float gscale,
+                              float* logits, float* dfeat, float* loss_sum, float* workspace, int B, int HW, int CH, int nmid,
+                              void* stream);
+int punet_fcomb_train_reduce(const float* workspace, float* dw1, int w1_rows, float* db1, float* dwmid, float* dbmid, float* dw3,
+                             float* db3, float* S, float* chan_workspace, int B, int HW, int CH, int nmid, int accumulate,
+                             void* stream);
+
 /* ---- K8: the reduction half of K7 on given logits[N][P] (unit parity of the consensus rule) */
 int punet_consensus(const float* logits, int N, long P, float upper, float lower, int masking, float* y, float* z,
                     void* stream);

@@ -65,6 +65,10 @@ _SIGS = {
     "punet_dot_bwd_workspace_floats": (_sz, [_i]),
     "punet_dot_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _p]),
     "punet_fcomb_sample": (_i, [_p, _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
+    "punet_fcomb_train_supported": (_i, [_i, _i, _i]),
+    "punet_fcomb_train_workspace_floats": (_sz, [_i, _i, _i, _i]),
+    "punet_fcomb_train_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "punet_fcomb_train_reduce": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "punet_consensus": (_i, [_p, _i, _l, _f, _f, _i, _p, _p, _p]),
     "punet_loss_workspace_floats": (_sz, []),
     "punet_bce_fwd_bwd": (_i, [_p, _p, _p, _f, _p, _p, _p, _l, _p]),
@@ -83,7 +87,8 @@ _SIGS = {
 
 _NO_WRAP = {"punet_last_error", "punet_build_info", "punet_device_ok", "punet_compute_units", "punet_wgrad_workspace_floats", "punet_gate_dwords",
             "punet_wgrad_slices", "punet_wgrad_x6_slices", "punet_small_wgrad_workspace_floats", "punet_chan_sum_workspace_floats",
-            "punet_dot_bwd_workspace_floats", "punet_loss_workspace_floats", "punet_standardize_workspace_doubles"}
+            "punet_dot_bwd_workspace_floats", "punet_loss_workspace_floats", "punet_fcomb_train_supported",
+            "punet_fcomb_train_workspace_floats", "punet_standardize_workspace_doubles"}
 
 _lib = None
 _fn = {}

@@ -233,6 +233,8 @@ class PUNetEngine:
         self.x6_opts = _lib.x6_opts(_X6_PRODUCTS.get(self.conv_mode, 6), shape)
         # the last conv of a contracting block also writes the next block's 2x2 average (PUNET_FUSE_POOL=0: separate kernel)
         self.fuse_pool = os.environ.get("PUNET_FUSE_POOL", "1") != "0"
+        # training path: Fcomb forward + BCE + backward in one kernel (K7t) where it applies (PUNET_FUSE_FCOMB=0: per-op path)
+        self.fuse_fcomb = os.environ.get("PUNET_FUSE_FCOMB", "1") != "0"
         self._x6 = {}  # (flat.data_ptr(), mode) -> bf16 planes buffer [3 * numel]
         self._x6_table = None  # (device int64 [nconv+1, 4], nconv, total_units) for punet_split_weights_x6_batch
         self._x6_1x1 = {}  # (flat.data_ptr(), mode) -> {conv name: bf16 planes} for the Fcomb 1x1 layers
@@ -519,11 +521,28 @@ class PUNetEngine:
         _lib.call("punet_latent_kl_rows", muls_q.data_ptr(), muls_p.data_ptr(), None if analytic_kl else z.data_ptr(),
                   kl_rows.data_ptr(), kl.data_ptr(), B, Ld, _stream())
         zf = self.reparam(muls_q, torch.zeros_like(eps3)) if posterior_mean else z  # what Fcomb sees
-        # Fcomb, single sample, activations materialised for the backward
         c1, c3 = L.convs["fcomb.layers.0"], L.convs["fcomb.last_layer"]
         zb = self._empty(B, CH)
         _lib.call("punet_fcomb_zbias", zf.data_ptr(), self._wptr(flat, c1), self._bptr(flat, c1), zb.data_ptr(), B, Ld, CH,
                   _stream())
+        nmid = len(L.fcomb_mid)
+        if (record and loss_kind == "bce" and taps is None and self.fuse_fcomb
+                and _lib.call("punet_fcomb_train_supported", CH, nmid, H * W)):
+            # K7t: forward, criterion and the whole Fcomb backward in one kernel; the weight-gradient slabs wait in `ws` for
+            # elbo_backward (a fresh buffer per pass: the joint trainers hold two passes' worth between forward and backward)
+            cm_ = L.convs[L.fcomb_mid[0]] if nmid else None
+            ws = self._empty(_lib.call("punet_fcomb_train_workspace_floats", B, H * W, CH, nmid))
+            logits, dfeat, rec = self._empty(B, 1, H, W), self._empty(B, H, W, CH), self._empty(1)
+            self._timed("fcomb_train", 2.0 * 3 * B * H * W * CH * (CH * (1 + nmid) + 1), "punet_fcomb_train_fwd_bwd", feat.ptr,
+                        self._wptr(flat, c1), zb.data_ptr(), self._wptr(flat, cm_) if nmid else None,
+                        self._bptr(flat, cm_) if nmid else None, self._wptr(flat, c3), self._bptr(flat, c3), y_tgt.data_ptr(),
+                        consm.data_ptr() if consm is not None else None, float(gscale), logits.data_ptr(), dfeat.data_ptr(),
+                        rec.data_ptr(), ws.data_ptr(), B, H * W, CH, nmid, _stream())
+            st.update(z=zf, z_posterior=z, eps=eps3, kl=kl, kl_rows=kl_rows, rec=rec, logits=logits, dlogit=None, hs=None,
+                      loss_kind=loss_kind, kl_sampled=not analytic_kl, z_is_mean=bool(posterior_mean), recorded=record,
+                      fused_fcomb=ws, dfeat=dfeat)
+            return st
+        # Fcomb, single sample, activations materialised for the backward
         h = Act(self._empty(B, H, W, CH), B, H, W, CH, relu_out=True)
         p1 = self._x6_1x1.get((flat.data_ptr(), 0), {}).get(c1.name) if self.x6 else None
         if p1 is not None:
@@ -730,6 +749,37 @@ class PUNetEngine:
         P = B * H * W
         self.prepare_dgrad_weights(flat)
         c1, c3 = L.convs["fcomb.layers.0"], L.convs["fcomb.last_layer"]
+        feat: Act = st["feat"]
+        if st.get("fused_fcomb") is not None:  # K7t ran in elbo_head: only the slab reduction and the z term are left
+            nmid = len(L.fcomb_mid)
+            cm_ = L.convs[L.fcomb_mid[0]] if nmid else None
+            g = gflat.data_ptr()
+            S = self._empty(B, CH)
+            wsc = self.ws.get("chan", _lib.call("punet_chan_sum_workspace_floats", B, H * W // 32, CH))
+            _lib.call("punet_fcomb_train_reduce", st["fused_fcomb"].data_ptr(), g + 4 * c1.w_off, c1.cin, g + 4 * c1.b_off,
+                      g + 4 * cm_.w_off if nmid else None, g + 4 * cm_.b_off if nmid else None, g + 4 * c3.w_off,
+                      g + 4 * c3.b_off, S.data_ptr(), wsc.data_ptr(), B, H * W, CH, nmid, acc, _stream())
+            dz = self._empty(B, Ld)
+            _lib.call("punet_fcomb_z_bwd", S.data_ptr(), st["z"].data_ptr(), self._wptr(flat, c1), g + 4 * c1.w_off,
+                      dz.data_ptr(), B, Ld, CH, acc, _stream())
+            gm_u = {id(feat): st["dfeat"]}
+        else:
+            dz, gm_u = self._fcomb_backward_ops(flat, gflat, st, accumulate)
+        tq, tp, tu = st["tapes"]
+        self._backward_tape(flat, gflat, tu, gm_u, accumulate)
+        if after_unet is not None:
+            after_unet()
+        self._latent_backward(flat, gflat, st, dz, accumulate)
+
+    def _fcomb_backward_ops(self, flat, gflat, st, accumulate):
+        """The per-op Fcomb backward (Dice criterion, more than one middle layer, taps requested): returns (dz [B, L], the
+        gradient map holding d loss / d features)."""
+        L = self.L
+        B, H, W = st["B"], st["H"], st["W"]
+        Ld, CH = L.latent_dim, L.nf[0]
+        acc = int(accumulate)
+        P = B * H * W
+        c1, c3 = L.convs["fcomb.layers.0"], L.convs["fcomb.last_layer"]
         hs: List[Act] = st["hs"]
         feat: Act = st["feat"]
         # last layer C -> 1
@@ -756,11 +806,15 @@ class PUNetEngine:
         gm_u = {}
         dfeat, _ = self._grad_into(gm_u, feat)
         self._dgrad(flat, c1, dz_h, 0, CH, dfeat, feat.ptr, 0, B, H, W, bits=feat.bits)
-        del dz_h
+        return dz, gm_u
+
+    def _latent_backward(self, flat, gflat, st, dz, accumulate):
+        """KL + reparameterisation gradients into the two latent heads, then the encoders' backward."""
+        L = self.L
+        B = st["B"]
+        Ld = L.latent_dim
+        acc = int(accumulate)
         tq, tp, tu = st["tapes"]
-        self._backward_tape(flat, gflat, tu, gm_u, accumulate)
-        if after_unet is not None:
-            after_unet()
         # latent heads: KL + reparameterisation
         dq = self._empty(B, 2 * Ld)
         dp = self._empty(B, 2 * Ld)

@@ -111,3 +111,29 @@ def test_filters_that_are_multiples_of_8_not_32():
     for k, ref in go.items():
         e = (gv[k].cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-8)
         assert e < 5e-4, (k, e)
+
+
+def test_init_families_match_the_reference(model):
+    """M12: reset_parameters() draws from the reference's init families (utils.py:8-29): He-normal (fan_in, relu) weights and
+    truncated-normal(0, 1e-3) biases within +-2 sigma for the 3x3 stacks; orthogonal weights for Fcomb and the latent heads."""
+    import math
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    for k, v in sd.items():
+        if k.endswith(".bias"):
+            assert v.abs().max().item() <= 0.002 + 1e-9, k                      # truncated at 2 sigma
+            if v.numel() >= 64:
+                assert 4e-4 < v.std().item() < 1.1e-3, (k, v.std().item())      # sigma 1e-3, truncation shrinks it to ~0.88e-3
+        elif k.startswith("fcomb.") or k.endswith("conv_layer.weight"):
+            w = v.reshape(v.shape[0], -1)                                        # nn.init.orthogonal_: rows or columns orthonormal
+            g = w @ w.t() if w.shape[0] <= w.shape[1] else w.t() @ w
+            assert (g - torch.eye(g.shape[0])).abs().max().item() < 1e-4, k
+        else:
+            fan_in = v.shape[1] * v.shape[2] * v.shape[3]
+            if v.numel() >= 4096:
+                assert abs(v.std().item() / math.sqrt(2.0 / fan_in) - 1.0) < 0.05, k
+                assert abs(v.mean().item()) < 0.05 * math.sqrt(2.0 / fan_in), k
+    # a different seed gives different weights, the same seed the same
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    a = ProbabilisticUnet(1, 1, NF, 6, 3, 1.0, device="cuda:0", seed=3)
+    b = ProbabilisticUnet(1, 1, NF, 6, 3, 1.0, device="cuda:0", seed=4)
+    assert torch.equal(a.flat_params, model.flat_params) and not torch.equal(a.flat_params, b.flat_params)
