@@ -22,6 +22,12 @@
 
 #include <math.h>
 
+// timing-only knob (tools/ab_variants.sh): bit 0 skips the two weight-gradient MFMA loops, bit 1 the dW3 reductions, bit 2 the
+// input-gradient MFMAs, bit 3 the forward middle layer - WRONG results, used to see where a tile's time goes
+#ifndef PUNET_FT_SKIP
+#define PUNET_FT_SKIP 0
+#endif
+
 namespace {
 
 struct TrainArgs {
@@ -44,6 +50,20 @@ struct TrainArgs {
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+// sum over the 32 lanes of a half-wave: four DPP steps inside each 16-lane row (quad swaps, half-row mirror, row mirror) and one
+// cross-row exchange (a butterfly of five ds_bpermutes per value had cost more than the tile's MFMAs)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float half32_sum(float v) {
+    v = dpp_add<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+    v = dpp_add<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+    v = dpp_add<0x141>(v);  // row_half_mirror
+    v = dpp_add<0x140>(v);  // row_mirror
+    return v + __shfl_xor(v, 16);
+}
 
 template <bool FIRST, typename A, typename B>
 __device__ __forceinline__ auto& pick(A& a, B& b) {
@@ -83,7 +103,7 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
     f32x16 accW1[NBLK][NBLK];                     // dW1f[k][co]: reg r <-> k = 32 kb + row(r, half), lane <-> co = 32 cb + l31
     f32x16 accWm[NMID ? NBLK : 1][NMID ? NBLK : 1];
     // channel sums kept ONE register per 32-channel block: lane (l31, half) owns channel 32 cb + l31; the two halves hold
-    // partial sums over the pixels they saw (accBm: pixels of their parity; accW3: whole tiles) and are combined at the end
+    // partial sums over the pixels of their parity and are combined at the end
     float accBm[NBLK], accW3[NBLK];
     float accB3 = 0.f, accLoss = 0.f;
 #pragma unroll
@@ -111,14 +131,20 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
                     make_float4(v[cb][4 * q + 0], v[cb][4 * q + 1], v[cb][4 * q + 2], v[cb][4 * q + 3]);
     };
 
-    // every wave runs the same number of iterations (workgroup barriers inside); a wave without a tile computes on the last
-    // tile and stores nothing
-    for (int t0 = blockIdx.x * 4; t0 < a.ntiles; t0 += gridDim.x * 4) {
-        const bool active = t0 + wave < a.ntiles;
-        const int tile = active ? t0 + wave : a.ntiles - 1;
+    // waves are independent inside this loop (their LDS tiles are private, no workgroup barrier): each strides over its tiles
+    for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += gridDim.x * 4) {
         const size_t pix = (size_t)tile * 32 + l31;
         const int b = (int)(((size_t)tile * 32) / a.HW);
-        const float* zbp = a.zb + (size_t)b * CH;
+        // everything the tile reads from global memory is issued here, before the first MFMA (one wave per SIMD: a load issued
+        // where its value is needed is a fully exposed round trip)
+        float4 zq[NBLK][4];
+#pragma unroll
+        for (int cb = 0; cb < NBLK; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                zq[cb][q] = *reinterpret_cast<const float4*>(a.zb + (size_t)b * CH + cb * 32 + 8 * q + 4 * half);
+        const float cm = a.consm ? a.consm[pix] : 1.f;
+        const float tgt = a.target[pix];
 
         // ---------------- forward: h0 = relu(W1f^T F + zb)
         float4 fr[CH / 8];
@@ -144,7 +170,11 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
 #pragma unroll
         for (int cb = 0; cb < NBLK; ++cb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h0[cb][r] = fmaxf(h0[cb][r] + zbp[cb * 32 + mfma32_row(r, half)], 0.f);
+            for (int r = 0; r < 16; ++r) {
+                const float4 zv = zq[cb][r >> 2];  // channel 32 cb + 8 (r >> 2) + 4 half + (r & 3) = row(r, half)
+                const float zb_ = (r & 3) == 0 ? zv.x : (r & 3) == 1 ? zv.y : (r & 3) == 2 ? zv.z : zv.w;
+                h0[cb][r] = fmaxf(h0[cb][r] + zb_, 0.f);
+            }
 
         __builtin_amdgcn_sched_barrier(0);  // phase boundary: LDS reads of the next phase must not be hoisted (registers)
         // ---------------- middle layer: h1 = relu(Wm^T h0 + bm)
@@ -158,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
                 for (int cb = 0; cb < NBLK; ++cb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        h1[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(sWm[(cb * 32 + mfma32_row(r, half)) * WP + ob * 32 + l31],
+                        if (!(PUNET_FT_SKIP & 8)) h1[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(sWm[(cb * 32 + mfma32_row(r, half)) * WP + ob * 32 + l31],
                                                                       h0[cb][r], h1[ob], 0, 0, 0);
                         if (r == 7 || r == 15) __builtin_amdgcn_sched_barrier(0);
                     }
@@ -178,37 +208,42 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) part = fmaf(hl[cb][r], sW3[cb * 32 + mfma32_row(r, half)], part);
         const float logit = part + __shfl_xor(part, 32) + b3;
-        const float cm = a.consm ? a.consm[pix] : 1.f;
-        const float x = logit * cm, t = a.target[pix] * cm;
+        const float x = logit * cm, t = tgt * cm;
         const float dlogit = a.gscale * (sigm(x) - t) * cm;  // both halves hold the pixel's value
-        if (active && half == 0) {
+        if (half == 0) {
             a.logits[pix] = logit;
             accLoss += (1.f - t) * x - (fminf(x, 0.f) - log1pf(expf(-fabsf(x))));
             accB3 += dlogit;
         }
-        const float dl = active ? dlogit : 0.f;  // an inactive wave contributes exact zeros to every gradient sum
+        const float dl = dlogit;
 
         __builtin_amdgcn_sched_barrier(0);  // phase boundary: LDS reads of the next phase must not be hoisted (registers)
         // ---------------- last layer backward: dW3 += dlogit * h_last, dZ_last = dlogit * w3 gated by (h_last > 0)
+        // dW3[c] += sum_pix dlogit[pix] * h_last[c][pix]: the sum runs over the LANES of the accumulator layout; instead of 32
+        // cross-lane reductions per tile the h_last tile goes through LDS ([pixel][channel] rows, as for the weight gradients)
+        // and lane (c, half) adds up its 16 pixels
         f32x16 dz[NBLK];
+        if (!(PUNET_FT_SKIP & 2)) {
+            put_tile(TB, hl);
+            if (half == 0) TA[l31] = dl;  // TA is free until the middle layer's backward
+#pragma unroll
+            for (int sidx = 0; sidx < 16; ++sidx) {
+                const float dlv = TA[2 * sidx + half];
+#pragma unroll
+                for (int cb = 0; cb < NBLK; ++cb) accW3[cb] = fmaf(dlv, TB[(2 * sidx + half) * TP + cb * 32 + l31], accW3[cb]);
+            }
+        }
 #pragma unroll
         for (int cb = 0; cb < NBLK; ++cb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                // sum over the tile's 32 pixels (butterfly over l31), kept by the lane that owns channel row(r, half)
-                float v = dl * hl[cb][r];
-                for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                accW3[cb] += l31 == mfma32_row(r, half) ? v : 0.f;
-                dz[cb][r] = hl[cb][r] > 0.f ? dl * sW3[cb * 32 + mfma32_row(r, half)] : 0.f;
-            }
+            for (int r = 0; r < 16; ++r) dz[cb][r] = hl[cb][r] > 0.f ? dl * sW3[cb * 32 + mfma32_row(r, half)] : 0.f;
 
         __builtin_amdgcn_sched_barrier(0);  // phase boundary: LDS reads of the next phase must not be hoisted (registers)
         // ---------------- middle layer backward: dWm += h0 (x) dZ1 over the pixels, dbm += dZ1, dZ0 = (Wm dZ1) gated by (h0 > 0)
         if constexpr (NMID > 0) {
-            __syncthreads();  // the previous iteration's tile reads are done
+            // (no barrier: TA / TB are private to this wave, whose LDS operations execute in program order)
             put_tile(TA, h0);
             put_tile(TB, dz);
-            __syncthreads();
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 float av[NBLK], bv[NBLK];
@@ -222,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
                 for (int kb = 0; kb < NBLK; ++kb)
 #pragma unroll
                     for (int cb = 0; cb < NBLK; ++cb)
-                        accWm[kb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb], bv[cb], accWm[kb][cb], 0, 0, 0);
+                        if (!(PUNET_FT_SKIP & 1)) accWm[kb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb], bv[cb], accWm[kb][cb], 0, 0, 0);
                 if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -235,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
                 for (int cb = 0; cb < NBLK; ++cb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        d0[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(sWm[(kb * 32 + l31) * WP + cb * 32 + mfma32_row(r, half)], dz[cb][r],
+                        if (!(PUNET_FT_SKIP & 4)) d0[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(sWm[(kb * 32 + l31) * WP + cb * 32 + mfma32_row(r, half)], dz[cb][r],
                                                                       d0[kb], 0, 0, 0);
                         if (r == 7 || r == 15) __builtin_amdgcn_sched_barrier(0);
                     }
@@ -249,9 +284,7 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
         __builtin_amdgcn_sched_barrier(0);  // phase boundary: LDS reads of the next phase must not be hoisted (registers)
         // ---------------- first layer backward: dW1f += F (x) dZ0 over the pixels (feature rows straight from memory), per-tile
         // column sums of dZ0 (-> z gradient and b1 gradient), dF = (W1f dZ0) gated by (F > 0)
-        __syncthreads();
         put_tile(TB, dz);
-        __syncthreads();
         float ssum[NBLK];
 #pragma unroll
         for (int i = 0; i < NBLK; ++i) ssum[i] = 0.f;
@@ -268,14 +301,14 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
             for (int kb = 0; kb < NBLK; ++kb)
 #pragma unroll
                 for (int cb = 0; cb < NBLK; ++cb)
-                    accW1[kb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(active ? av[kb] : 0.f, bv[cb], accW1[kb][cb], 0, 0, 0);
+                    if (!(PUNET_FT_SKIP & 1)) accW1[kb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb], bv[cb], accW1[kb][cb], 0, 0, 0);
             if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NBLK; ++i) {
             const float s2 = ssum[i] + __shfl_xor(ssum[i], 32);  // even + odd pixels
-            if (active && half == 0) a.stile[(size_t)tile * CH + i * 32 + l31] = s2;
+            if (half == 0) a.stile[(size_t)tile * CH + i * 32 + l31] = s2;
         }
 #pragma unroll
         for (int kb = 0; kb < NBLK; ++kb) {
@@ -287,10 +320,10 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
             for (int cb = 0; cb < NBLK; ++cb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    df = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[(kb * 32 + l31) * WP + cb * 32 + mfma32_row(r, half)], dz[cb][r], df, 0, 0, 0);
+                    if (!(PUNET_FT_SKIP & 4)) df = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[(kb * 32 + l31) * WP + cb * 32 + mfma32_row(r, half)], dz[cb][r], df, 0, 0, 0);
                     if (r == 7 || r == 15) __builtin_amdgcn_sched_barrier(0);
                 }
-            if (active) {
+            {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     // channels 32 kb + 8 q + 4 half .. + 3 of this pixel, re-read (L1/L2 hit) rather than kept in 32 registers
