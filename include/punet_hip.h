@@ -207,6 +207,13 @@ int punet_fcomb_sample(const float* feat, const float* w1, const float* zb, cons
                        float* logits, int N, int B, int HW, int CH, int nmid, float upper, float lower, int masking,
                        void* stream);
 
+/* The same kernel in the split-plane arithmetic of K1x6 (three bf16 planes per operand, six products on
+ * v_mfma_f32_32x32x16_bf16, fp32 accumulation: fp32-accurate): 2.67x less matrix-pipe time.  Same arguments. */
+int punet_fcomb_sample_x6(const float* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
+                          const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z,
+                          float* logits, int N, int B, int HW, int CH, int nmid, float upper, float lower, int masking,
+                          void* stream);
+
 /* ---- K7t: the single-sample Fcomb of the TRAINING path in one persistent kernel: forward (probabilistic_unet.py:200-214 with
  *      the z term folded into zb[B][CH]), BCE criterion with the consensus mask (:360-369) and the whole backward - dfeat
  *      (gated by feat > 0, i.e. the gradient w.r.t. the pre-activation of the U-Net's last conv) and, as per-workgroup slabs in

@@ -65,6 +65,7 @@ _SIGS = {
     "punet_dot_bwd_workspace_floats": (_sz, [_i]),
     "punet_dot_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _p]),
     "punet_fcomb_sample": (_i, [_p, _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
+    "punet_fcomb_sample_x6": (_i, [_p, _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "punet_fcomb_train_supported": (_i, [_i, _i, _i]),
     "punet_fcomb_train_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "punet_fcomb_train_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

@@ -144,11 +144,179 @@ __global__ __launch_bounds__(256) void fcomb_sampler_kernel(SamplerArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The same kernel in the split-plane arithmetic of conv_x6.hip (round 2): every fp32 operand = three bf16 planes, every
+// product = hh + hm + mh + hl + lh + mm on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (fp32-accurate, dropped terms
+// <= 2^-26 relative).  Six bf16 MFMAs of 32 cycles contract K = 16 where the fp32 kernel needs eight MFMAs of 64 cycles:
+// 2.67x less matrix-pipe time, and this kernel is matrix-pipe-bound (76 % busy).
+// K ordering: an accumulator register block holds, per lane half h, the channels row(r, h) = (r & 3) + 8 (r >> 2) + 4 h; a
+// K block of 16 is {registers 8 jj .. 8 jj + 7 of both halves} = channels 32 cbk + 16 jj .. + 15 in a fixed permutation, so
+// the B operand of the next layer is just 8 consecutive accumulator registers split into planes - still no data movement
+// between layers.  The weights are split once per workgroup into LDS in the matching order: [layer][plane][K block][half][co]
+// x 8 bf16 (one conflict-free ds_read_b128 per fragment).  The feature rows (global, 8 g + 4 h + e) follow the same map.
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3s(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    l = (__bf16)r2;
+}
+
+struct Planes {
+    bf16x8s p[3];
+};
+
+__device__ __forceinline__ Planes split8(const float (&v)[8]) {
+    Planes o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __bf16 h, m, l;
+        split3s(v[i], h, m, l);
+        o.p[0][i] = h; o.p[1][i] = m; o.p[2][i] = l;
+    }
+    return o;
+}
+
+// acc += W (planes wa, as A) x act (planes xb, as B): the six products, smallest terms first
+__device__ __forceinline__ f32x16 mfma6(const bf16x8s (&wa)[3], const Planes& xb, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1], xb.p[1], c, 0, 0, 0);  // mm
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], xb.p[2], c, 0, 0, 0);  // hl
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[2], xb.p[0], c, 0, 0, 0);  // lh
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], xb.p[1], c, 0, 0, 0);  // hm
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1], xb.p[0], c, 0, 0, 0);  // mh
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], xb.p[0], c, 0, 0, 0);  // hh
+    return c;
+}
+
+#ifndef PUNET_K7X_WGS
+#define PUNET_K7X_WGS 2  // workgroups per CU the register allocation aims at (tools/ab_variants.sh experiment knob)
+#endif
+template <int NBLK>
+__global__ __launch_bounds__(256, PUNET_K7X_WGS) void fcomb_sampler_x6_kernel(SamplerArgs a) {
+    constexpr int CH = 32 * NBLK, KB = CH / 16;
+    constexpr int LAYER = 3 * KB * 2 * CH;  // uint4 (8 x bf16) units per layer: [plane][K block][half][co]
+    extern __shared__ __attribute__((aligned(16))) char smem_x6[];
+    uint4* sA = reinterpret_cast<uint4*>(smem_x6);                       // [1 + nmid][LAYER]
+    float* sBm = reinterpret_cast<float*>(sA + (1 + a.nmid) * LAYER);    // [nmid][CH]
+    float* sW3 = sBm + a.nmid * CH;                                      // [CH]
+
+    const int tid = threadIdx.x;
+    // split the weights into planes, K-permuted as described above: unit u = ((j * 2 + h) * CH + co), slot i <-> channel
+    // 16 j + 8 (i >> 2) + 4 h + (i & 3)
+    for (int l = 0; l <= a.nmid; ++l) {
+        const float* w = l == 0 ? a.w1 : a.wmid + (size_t)(l - 1) * a.wmid_stride;  // [k][co], k = input channel
+        for (int u = tid; u < KB * 2 * CH; u += 256) {
+            const int co = u % CH, h = (u / CH) & 1, j = u / (2 * CH);
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = w[(size_t)(16 * j + 8 * (i >> 2) + 4 * h + (i & 3)) * CH + co];
+            const Planes pl = split8(v);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) sA[l * LAYER + p * (KB * 2 * CH) + u] = __builtin_bit_cast(uint4, pl.p[p]);
+        }
+    }
+    for (int l = 0; l < a.nmid; ++l)
+        for (int i = tid; i < CH; i += 256) sBm[l * CH + i] = a.bmid[l * a.bmid_stride + i];
+    for (int i = tid; i < CH; i += 256) sW3[i] = a.w3[i];
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const float b3 = a.b3[0];
+    const size_t P = (size_t)a.B * a.HW;
+    auto afrag = [&](int layer, int j, int ob, bf16x8s (&wa)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            wa[p] = __builtin_bit_cast(bf16x8s, sA[layer * LAYER + p * (KB * 2 * CH) + (j * 2 + half) * CH + ob * 32 + l31]);
+    };
+
+    for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += gridDim.x * 4) {
+        const size_t pix = (size_t)tile * 32 + l31;
+        const int b = (int)(((size_t)tile * 32) / a.HW);
+
+        // ---- feature term, once per pixel: T1[co][pix] = sum_k W1[k][co] * F[pix][k]
+        f32x16 t1[NBLK];
+#pragma unroll
+        for (int cb = 0; cb < NBLK; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t1[cb][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const float4 f0 = *reinterpret_cast<const float4*>(a.feat + pix * CH + 16 * j + 4 * half);
+            const float4 f1 = *reinterpret_cast<const float4*>(a.feat + pix * CH + 16 * j + 8 + 4 * half);
+            const float fv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+            const Planes xb = split8(fv);
+#pragma unroll
+            for (int cb = 0; cb < NBLK; ++cb) {
+                bf16x8s wa[3];
+                afrag(0, j, cb, wa);
+                t1[cb] = mfma6(wa, xb, t1[cb]);
+            }
+        }
+
+        float ysum = 0.f, cnt = 0.f;
+        for (int n = 0; n < a.N; ++n) {
+            const float* zbp = a.zb + ((size_t)n * a.B + b) * CH;
+            f32x16 ha[NBLK], hb[NBLK];
+#pragma unroll
+            for (int cb = 0; cb < NBLK; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ha[cb][r] = fmaxf(t1[cb][r] + zbp[cb * 32 + mfma32_row(r, half)], 0.f);
+
+            for (int l = 0; l < a.nmid; ++l) {
+                const float* bl = sBm + l * CH;
+#pragma unroll
+                for (int ob = 0; ob < NBLK; ++ob)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hb[ob][r] = 0.f;
+#pragma unroll
+                for (int cbk = 0; cbk < NBLK; ++cbk)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        float v[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = ha[cbk][8 * jj + i];
+                        const Planes xb = split8(v);
+#pragma unroll
+                        for (int ob = 0; ob < NBLK; ++ob) {
+                            bf16x8s wa[3];
+                            afrag(1 + l, 2 * cbk + jj, ob, wa);
+                            hb[ob] = mfma6(wa, xb, hb[ob]);
+                        }
+                    }
+#pragma unroll
+                for (int ob = 0; ob < NBLK; ++ob)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ha[ob][r] = fmaxf(hb[ob][r] + bl[ob * 32 + mfma32_row(r, half)], 0.f);
+            }
+
+            float part = 0.f;
+#pragma unroll
+            for (int cb = 0; cb < NBLK; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part = fmaf(ha[cb][r], sW3[cb * 32 + mfma32_row(r, half)], part);
+            const float logit = part + __shfl_xor(part, 32) + b3;
+            if (a.logits && half == 0) a.logits[(size_t)n * P + pix] = logit;
+            const float s = 1.f / (1.f + expf(-logit));
+            ysum += s;
+            cnt += (s >= a.upper || s <= a.lower) ? 1.f : 0.f;
+        }
+        if (half == 0) {
+            if (a.y) a.y[pix] = ysum / (float)a.N;
+            if (a.z) {
+                const float c = cnt / (float)a.N;
+                a.z[pix] = a.masking ? (c == 1.f ? 1.f : 0.f) : c;
+            }
+        }
+    }
+}
+
 }  // namespace
 
-extern "C" int punet_fcomb_sample(const float* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
-                                  const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z, float* logits, int N, int B, int HW,
-                                  int CH, int nmid, float upper, float lower, int masking, void* stream) {
+static int fcomb_sample_launch(bool x6, const float* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
+                               const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z, float* logits,
+                               int N, int B, int HW, int CH, int nmid, float upper, float lower, int masking, void* stream) {
     PUNET_CHECK_ARG(feat && w1 && zb && w3 && b3, "punet_fcomb_sample: null pointer");
     PUNET_CHECK_ARG(CH == 32 || CH == 64, "punet_fcomb_sample: num_filters[0] must be 32 or 64 (got %d)", CH);
     PUNET_CHECK_ARG(nmid >= 0 && nmid <= 4 && (nmid == 0 || (wmid && bmid)), "punet_fcomb_sample: bad nmid %d", nmid);
@@ -159,20 +327,40 @@ extern "C" int punet_fcomb_sample(const float* feat, const float* w1, const floa
     a.N = N; a.B = B; a.HW = HW; a.nmid = nmid; a.masking = masking;
     a.ntiles = (int)(((size_t)B * HW) / 32);
     a.upper = upper; a.lower = lower;
-    const size_t shmem = ((size_t)CH * CH * (1 + nmid) + (size_t)nmid * CH + CH) * sizeof(float);
+    // fp32 kernel: fp32 weights in LDS; x6 kernel: three bf16 planes per weight (6 B instead of 4 B per element)
+    const size_t shmem = x6 ? ((size_t)CH * CH * (1 + nmid) * 6 + ((size_t)nmid * CH + CH) * sizeof(float))
+                            : ((size_t)CH * CH * (1 + nmid) + (size_t)nmid * CH + CH) * sizeof(float);
     int grid = (a.ntiles + 3) / 4;
     if (grid > 2 * punet_num_cus()) grid = 2 * punet_num_cus();
+    const void* fn = x6 ? (CH == 64 ? (const void*)fcomb_sampler_x6_kernel<2> : (const void*)fcomb_sampler_x6_kernel<1>)
+                        : (CH == 64 ? (const void*)fcomb_sampler_kernel<2> : (const void*)fcomb_sampler_kernel<1>);
     if (shmem > 48 * 1024) {  // raise the dynamic-LDS cap (160 KiB per CU on gfx950)
-        const void* fn = CH == 64 ? (const void*)fcomb_sampler_kernel<2> : (const void*)fcomb_sampler_kernel<1>;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {
             punet_set_error("punet_fcomb_sample: cannot reserve %zu bytes of LDS", shmem);
             return PUNET_ERR_HIP;
         }
     }
-    if (CH == 64)
-        fcomb_sampler_kernel<2><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
-    else
-        fcomb_sampler_kernel<1><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
+    if (x6) {
+        if (CH == 64) fcomb_sampler_x6_kernel<2><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
+        else fcomb_sampler_x6_kernel<1><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
+    } else {
+        if (CH == 64) fcomb_sampler_kernel<2><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
+        else fcomb_sampler_kernel<1><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
+    }
     PUNET_LAUNCH_CHECK("fcomb_sampler");
     return PUNET_OK;
+}
+
+extern "C" int punet_fcomb_sample(const float* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
+                                  const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z, float* logits, int N, int B, int HW,
+                                  int CH, int nmid, float upper, float lower, int masking, void* stream) {
+    return fcomb_sample_launch(false, feat, w1, zb, wmid, wmid_stride, bmid, bmid_stride, w3, b3, y, z, logits, N, B, HW, CH, nmid,
+                               upper, lower, masking, stream);
+}
+
+extern "C" int punet_fcomb_sample_x6(const float* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
+                                     const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z, float* logits, int N, int B,
+                                     int HW, int CH, int nmid, float upper, float lower, int masking, void* stream) {
+    return fcomb_sample_launch(true, feat, w1, zb, wmid, wmid_stride, bmid, bmid_stride, w3, b3, y, z, logits, N, B, HW, CH, nmid,
+                               upper, lower, masking, stream);
 }

@@ -235,6 +235,7 @@ class PUNetEngine:
         self.fuse_pool = os.environ.get("PUNET_FUSE_POOL", "1") != "0"
         # training path: Fcomb forward + BCE + backward in one kernel (K7t) where it applies (PUNET_FUSE_FCOMB=0: per-op path)
         self.fuse_fcomb = os.environ.get("PUNET_FUSE_FCOMB", "1") != "0"
+        self.sampler_x6 = os.environ.get("PUNET_SAMPLER_X6", "1") != "0"  # K7 on the BF16 matrix cores (0: fp32-MFMA kernel)
         self._x6 = {}  # (flat.data_ptr(), mode) -> bf16 planes buffer [3 * numel]
         self._x6_table = None  # (device int64 [nconv+1, 4], nconv, total_units) for punet_split_weights_x6_batch
         self._x6_1x1 = {}  # (flat.data_ptr(), mode) -> {conv name: bf16 planes} for the Fcomb 1x1 layers
@@ -431,7 +432,9 @@ class PUNetEngine:
         y = self._empty(B, 1, feat.H, feat.W) if want_consensus else None
         cz = self._empty(B, 1, feat.H, feat.W) if want_consensus else None
         logits = self._empty(N, B, 1, feat.H, feat.W) if want_logits else None
-        _lib.call("punet_fcomb_sample", feat.ptr, self._wptr(flat, c1), zb.data_ptr(), wmid, stride, bmid, stride,
+        # split-plane arithmetic on the BF16 matrix cores in every x6-family mode (always six products: parity), fp32 MFMA in "f32"
+        _lib.call("punet_fcomb_sample_x6" if self.x6 and self.sampler_x6 else "punet_fcomb_sample", feat.ptr, self._wptr(flat, c1),
+                  zb.data_ptr(), wmid, stride, bmid, stride,
                   self._wptr(flat, c3), self._bptr(flat, c3), y.data_ptr() if y is not None else None,
                   cz.data_ptr() if cz is not None else None, logits.data_ptr() if logits is not None else None, N, B, HW,
                   CH, nmid, float(upper), float(lower), int(masking), _stream())
