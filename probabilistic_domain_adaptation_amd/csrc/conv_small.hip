@@ -70,31 +70,34 @@ __global__ __launch_bounds__(256) void conv3x3_small_wgrad_kernel(const float* _
     float4 acc[ROWS];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const size_t P = (size_t)B * H * W;
     if (pl < ppb) {
-        for (size_t p = (size_t)blockIdx.x * ppb + pl; p < P; p += (size_t)gridDim.x * ppb) {
-            const unsigned pu = (unsigned)p, row = pu / (unsigned)W;
-            const int px = (int)(pu - row * (unsigned)W);
-            const unsigned bu = row / (unsigned)H;
-            const int py = (int)(row - bu * (unsigned)H);
-            const size_t b = bu;
-            const float4 d = *reinterpret_cast<const float4*>(dz + p * cout + g * 4);
-            acc[ROWS - 1].x += d.x; acc[ROWS - 1].y += d.y; acc[ROWS - 1].z += d.z; acc[ROWS - 1].w += d.w;
-            float xin[9 * CIN];  // branch-free taps, as in the forward
+        // a block walks whole image rows (row = blockIdx.x, blockIdx.x + gridDim.x, ...): the row / batch decomposition is
+        // block-uniform, per pixel only 32-bit adds remain (two 32-bit divisions per pixel had made this read-bound kernel
+        // ALU-bound, as in the forward)
+        for (unsigned row = blockIdx.x; row < (unsigned)(B * H); row += gridDim.x) {
+            const int py = (int)(row % (unsigned)H);
+            const float* xrow = x + (size_t)row * W * CIN;
+            const float* drow = dz + (size_t)row * W * cout + g * 4;
+            const bool up = py > 0, down = py < H - 1;
+            for (int px = pl; px < W; px += ppb) {
+                const float4 d = *reinterpret_cast<const float4*>(drow + (size_t)px * cout);
+                acc[ROWS - 1].x += d.x; acc[ROWS - 1].y += d.y; acc[ROWS - 1].z += d.z; acc[ROWS - 1].w += d.w;
+                float xin[9 * CIN];  // branch-free taps, as in the forward
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int gy = py + t / 3 - 1, gx = px + t % 3 - 1;
-                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                const float* xp = x + ((b * H + (in ? gy : py)) * W + (in ? gx : px)) * CIN;
+                for (int t = 0; t < 9; ++t) {
+                    const int dy = t / 3 - 1, dx = t % 3 - 1;
+                    const bool in = (dy < 0 ? up : (dy > 0 ? down : true)) && px + dx >= 0 && px + dx < W;
+                    const float* xp = xrow + (in ? (dy * W + px + dx) * CIN : px * CIN);
 #pragma unroll
-                for (int c = 0; c < CIN; ++c) xin[t * CIN + c] = in ? xp[c] : 0.f;
-            }
+                    for (int c = 0; c < CIN; ++c) xin[t * CIN + c] = in ? xp[c] : 0.f;
+                }
 #pragma unroll
-            for (int i = 0; i < 9 * CIN; ++i) {
-                const float xv = xin[i];
-                float4& a = acc[i];
-                a.x = fmaf(xv, d.x, a.x); a.y = fmaf(xv, d.y, a.y);
-                a.z = fmaf(xv, d.z, a.z); a.w = fmaf(xv, d.w, a.w);
+                for (int i = 0; i < 9 * CIN; ++i) {
+                    const float xv = xin[i];
+                    float4& a = acc[i];
+                    a.x = fmaf(xv, d.x, a.x); a.y = fmaf(xv, d.y, a.y);
+                    a.z = fmaf(xv, d.z, a.z); a.w = fmaf(xv, d.w, a.w);
+                }
             }
         }
     }
@@ -159,8 +162,8 @@ extern "C" int punet_conv3x3_small_wgrad(const float* x, int cin, const float* d
                     "punet_conv3x3_small_wgrad: cout/4 must divide 64 (got cout=%d)", cout);
     const size_t P = (size_t)B * H * W;
     PUNET_CHECK_ARG(P < (1ull << 31), "punet_conv3x3_small_wgrad: more than 2^31 pixels");
-    const int groups = cout / 4, ppb = 256 / groups;
-    int grid = (int)((P + ppb - 1) / ppb);
+    const int groups = cout / 4;
+    int grid = B * H;  // one image row per block and round
     if (grid > SMALL_WGRAD_BLOCKS) grid = SMALL_WGRAD_BLOCKS;
     const int rows = 9 * cin + 1;
     const size_t shmem = (size_t)4 * rows * groups * sizeof(float4);
