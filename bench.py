@@ -15,7 +15,8 @@ bf16 MFMAs with fp32 accumulation, logits within 1e-3 of the reference, masks bi
 reduced-precision fast modes (the reference scripts' mixed_precision=True analogue) - their lines say so in `dtype`
 and are NOT the headline number.
 
-The timed steps are replays of the step captured once into a hipGraph (`--no-graph`: launched eagerly from Python).
+The timed steps are replays of the step captured once into a hipGraph (`--no-graph`: launched eagerly from Python; under
+torch.distributed eager launches are the default and `--graph` selects the segmented replay).
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel = the 3x3 MFMA
 convolution, algorithmic FLOPs / HIP-event duration measured live in this run - in K eagerly launched steps right after
 the timed region, because events cannot sit inside a captured graph - against the matrix peak of the arithmetic in use)
@@ -209,6 +210,9 @@ def main():
                     help="3x3 conv arithmetic (default: $PUNET_CONV_MODE or x6); x3/bf16 are reduced-precision fast modes")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the timed steps eagerly from Python instead of replaying the captured hipGraph")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay graph segments also under torch.distributed (default there: eager launches - the step is GPU-bound "
+                         "either way and the segmented replay has only been rehearsed over gloo, never over RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -248,7 +252,7 @@ def main():
             torch.cuda.synchronize()
 
     B, H, W, N = a.batch, a.size, a.size, a.samples
-    use_graph = not a.no_graph
+    use_graph = not a.no_graph and (world == 1 or a.graph)
     run = Runner(a.workload, a, dev, rank, B, H, W, N, a.channels, a.conv_mode)
     eng = run.model.engine
     graph_note = None
