@@ -330,23 +330,274 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 2: the same kernel with a ROLLING ROW BUFFER.  The kernel above re-stages the whole 4 x 34-pixel halo for every
+// 2 x 32-pixel tile, i.e. every input row is loaded, split into planes and written to LDS 2.1 times (once as a tile's own
+// rows, once as its neighbour's halo).  Here a workgroup sweeps DOWN a 32-pixel column strip: the X rows live in a ring of
+// six row slots (four in use, two being filled), the dZ rows in a ring of four, and a tile stages only its successor's two
+// NEW rows of each operand - 68 + 64 instead of 136 + 64 pixels per tile (-34 % of the loads, splits and LDS writes that
+// share the instruction stream with the MFMAs), 127.5 KB of LDS instead of 153.6 KB.  A split-K slice owns a CONTIGUOUS run
+// of tiles in strip-major order; where a run starts (slice start, top of a strip) its first tile is staged in full by a
+// prologue.  Fragment reads take the ring slot of their row from four (X) + two (dZ) per-tile base offsets.
+constexpr int XSLOTS = 6, DSLOTS = 4;
+constexpr int XIMGR = XSLOTS * HTW * ROWB;  // one (plane, ci block) ring image: 13,056 B
+constexpr int DIMGR = DSLOTS * WTW * ROWB;  // one (plane, co block) ring image: 8,192 B
+
+// xa / db: per-lane byte offsets of the tile's four X rows / two dZ rows, INCLUDING the wave's channel-block image (the
+// remaining compile-time part - plane, column, tap - then fits the 16-bit offset field of the LDS instruction)
+template <int NP, int T0, int NT, typename F>
+__device__ __forceinline__ void tile_mfma_r(f32x16 (&acc)[GTMAX], const char* sX, const char* sD, const int (&xa)[4],
+                                            const int (&db)[2], F&& between) {
+    constexpr int P1 = NP > 1 ? 1 : 0, P2 = NP > 2 ? 2 : 0;
+#pragma unroll
+    for (int s = 0; s < NPD / 16; ++s) {
+        const int row = (16 * s) / WTW, col0 = (16 * s) % WTW;
+        Frag b[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) b[p].half4[r] = tr_read(sD, p * 2 * DIMGR + (col0 + 4 * r) * ROWB + db[row]);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const int t = T0 + tt, ky = t / 3, kx = t % 3;
+            Frag a[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    a[p].half4[r] = tr_read(sX, p * 2 * XIMGR + (col0 + kx + 4 * r) * ROWB + xa[row + ky]);
+            f32x16 c = acc[tt];
+            if (NP > 2) {
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P1].v, b[P1].v, c, 0, 0, 0);  // mm
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P2].v, b[0].v, c, 0, 0, 0);   // lh
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[P2].v, c, 0, 0, 0);   // hl
+            }
+            if (NP > 1) {
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P1].v, b[0].v, c, 0, 0, 0);  // mh
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[P1].v, c, 0, 0, 0);  // hm
+            }
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[0].v, c, 0, 0, 0);  // hh
+            acc[tt] = c;
+        }
+        between(s);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
+    constexpr int C4 = WC / 4;                                   // float4 units per pixel
+    constexpr int XNEW = 2 * HTW * C4, DNEW = 2 * WTW * C4;      // units of a tile's two new rows: 1,088 and 1,024
+    constexpr int XIT = (XNEW + 511) / 512, DIT = DNEW / 512;    // 3 and 2 staging registers per thread
+    static_assert(DNEW % 512 == 0, "every dZ unit is owned by exactly one thread (the bias sums rely on it)");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sX = smem;                       // [NP][2 ci blocks] ring images
+    char* sD = smem + NP * 2 * XIMGR;      // [NP][2 co blocks] ring images
+    float* sBias = reinterpret_cast<float*>(smem);  // reused after the last tile
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int pair = wave & 3, group = wave >> 2;
+    const int cib = pair >> 1, cob = pair & 1;
+    const int co_tiles = (a.cout + WC - 1) / WC;
+    const int ci_tile = blockIdx.y / co_tiles, co_tile = blockIdx.y % co_tiles;
+    const int ci0 = ci_tile * WC, co0 = co_tile * WC;
+    const int slice = blockIdx.x;
+    const int tiles_x = (a.W + WTW - 1) / WTW, tiles_y = (a.H + WTH - 1) / WTH;
+    const int ntiles = a.B * tiles_x * tiles_y;
+    const int t_begin = (int)((long)slice * ntiles / a.nslices), t_end = (int)((long)(slice + 1) * ntiles / a.nslices);
+
+    f32x16 acc[GTMAX];
+#pragma unroll
+    for (int t = 0; t < GTMAX; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int l16 = lane & 15, q = l16 >> 2, p4 = l16 & 3, cb = (lane >> 4) & 1;
+    const int lane_off = (8 * half + q) * ROWB + (16 * cb + 4 * p4) * 2;
+
+    // fp32 -> planes of one float4 unit, written at byte offset `off` inside the (plane, block 0) image of `img` bytes each
+    auto put_planes = [&](char* base, int img, int off, const float4& r) __attribute__((always_inline)) {
+        const float xv[4] = {r.x, r.y, r.z, r.w};
+        bf16x4 ph, pm, pl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __bf16 h_, m_, l_;
+            split3(xv[e], h_, m_, l_);
+            ph[e] = h_; pm[e] = m_; pl[e] = l_;
+        }
+        *reinterpret_cast<bf16x4*>(base + 0 * 2 * img + off) = ph;
+        if (NP > 1) *reinterpret_cast<bf16x4*>(base + (NP > 1) * 2 * img + off) = pm;
+        if (NP > 2) *reinterpret_cast<bf16x4*>(base + (NP > 2) * 4 * img + off) = pl;
+    };
+    auto load_x = [&](const float* xb, int gy, int px, int c4) __attribute__((always_inline)) -> float4 {
+        const int gx_ = px;  // already offset by the strip
+        const int c = ci0 + c4 * 4;
+        const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx_, 0), a.W - 1), cc = min(c, a.cs - 4);
+        return *reinterpret_cast<const float4*>(xb + (unsigned)((cy * a.W + cx) * a.cs + cc));
+    };
+    auto load_d = [&](const float* dbp, int gy, int gx_, int c4) __attribute__((always_inline)) -> float4 {
+        const int c = co0 + c4 * 4;
+        const int cy = min(gy, a.H - 1), cx = min(gx_, a.W - 1), cc = min(c, a.cout - 4);
+        return *reinterpret_cast<const float4*>(dbp + (unsigned)((cy * a.W + cx) * a.cout + cc));
+    };
+
+    for (int t = t_begin; t < t_end;) {
+        const int sid = t / tiles_y, ty_s = t - sid * tiles_y;
+        const int txi = sid % tiles_x, b = sid / tiles_x;
+        const int run = min(t_end - t, tiles_y - ty_s);  // tiles of this run: down the strip until its end or the slice's
+        const int tx0 = txi * WTW;
+        const float* const xb = a.x + (size_t)b * ((size_t)(a.H * a.W) * a.cs);
+        const float* const dbp = a.dz + (size_t)b * ((size_t)(a.H * a.W) * a.cout);
+
+        // ---- prologue of the run: the first tile's four X rows and two dZ rows in full (slots 0..3 / 0..1)
+        __syncthreads();  // the previous run's last readers are done
+        for (int u = tid; u < 4 * HTW * C4; u += 512) {
+            const int c4 = u % C4, pix = u / C4, hr = pix / HTW, px = pix % HTW;
+            const int gy = 2 * ty_s - 1 + hr, gx_ = tx0 + px - 1;
+            const bool in = gy >= 0 && gy < a.H && gx_ >= 0 && gx_ < a.W && ci0 + c4 * 4 < a.cs;
+            const float4 v = load_x(xb, gy, gx_, c4);
+            put_planes(sX, XIMGR, (c4 >> 3) * XIMGR + (hr * HTW + px) * ROWB + (c4 & 7) * 8, in ? v : make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+        for (int u = tid; u < 2 * WTW * C4; u += 512) {
+            const int c4 = u % C4, pix = u / C4, row = pix / WTW, px = pix % WTW;
+            const int gy = 2 * ty_s + row, gx_ = tx0 + px;
+            const bool in = gy < a.H && gx_ < a.W && co0 + c4 * 4 < a.cout;
+            float4 v = load_d(dbp, gy, gx_, c4);
+            if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+            put_planes(sD, DIMGR, (c4 >> 3) * DIMGR + (row * WTW + px) * ROWB + (c4 & 7) * 8, v);
+        }
+        __syncthreads();
+
+        for (int k = 0; k < run; ++k) {
+            const int ty = ty_s + k;
+            const bool has_next = k + 1 < run;  // block-uniform
+            // ring slots of this tile's rows and of the successor's two new rows
+            const int sx = (2 * k) % XSLOTS, sd = (2 * k) % DSLOTS;
+            int xa[4], db_[2];
+#pragma unroll
+            for (int hr = 0; hr < 4; ++hr) xa[hr] = ((sx + hr) % XSLOTS) * (HTW * ROWB) + lane_off + cib * XIMGR;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) db_[r] = ((sd + r) % DSLOTS) * (WTW * ROWB) + lane_off + cob * DIMGR;
+            const int nx0 = ((sx + 4) % XSLOTS) * (HTW * ROWB), nx1 = ((sx + 5) % XSLOTS) * (HTW * ROWB);
+            const int nd0 = ((sd + 2) % DSLOTS) * (WTW * ROWB), nd1 = ((sd + 3) % DSLOTS) * (WTW * ROWB);
+
+            // the successor's new rows: X rows 2 ty + 3, 2 ty + 4 (its halo rows 2, 3), dZ rows 2 ty + 2, 2 ty + 3.
+            // Unconditional and branch-free (clamped addresses; a run's last tile re-fetches valid rows and drops them).
+            float4 rx[XIT], rd[DIT];
+            unsigned inmask = 0u;
+#pragma unroll
+            for (int it = 0; it < XIT; ++it) {
+                const int u = min(tid + it * 512, XNEW - 1);
+                const int c4 = u % C4, pix = u / C4, nr = pix / HTW, px = pix % HTW;
+                const int gy = 2 * ty + 3 + nr, gx_ = tx0 + px - 1;
+                const bool in = gy < a.H && gx_ >= 0 && gx_ < a.W && ci0 + c4 * 4 < a.cs;
+                rx[it] = load_x(xb, gy, gx_, c4);
+                inmask = in ? inmask | (1u << it) : inmask;
+            }
+#pragma unroll
+            for (int it = 0; it < DIT; ++it) {
+                const int u = tid + it * 512;
+                const int c4 = u % C4, pix = u / C4, nr = pix / WTW, px = pix % WTW;
+                const int gy = 2 * ty + 2 + nr, gx_ = tx0 + px;
+                const bool in = gy < a.H && gx_ < a.W && co0 + c4 * 4 < a.cout;
+                rd[it] = load_d(dbp, gy, gx_, c4);
+                inmask = in ? inmask | (1u << (XIT + it)) : inmask;
+            }
+            auto commit_x = [&](int it) __attribute__((always_inline)) {
+                const int u = min(tid + it * 512, XNEW - 1);  // a clamped duplicate re-writes the last unit with the same data
+                const int c4 = u % C4, pix = u / C4, nr = pix / HTW, px = pix % HTW;
+                const float4 r = (inmask >> it) & 1u ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+                put_planes(sX, XIMGR, (c4 >> 3) * XIMGR + (nr ? nx1 : nx0) + px * ROWB + (c4 & 7) * 8, r);
+            };
+            auto commit_d = [&](int it) __attribute__((always_inline)) {
+                const int u = tid + it * 512;
+                const int c4 = u % C4, pix = u / C4, nr = pix / WTW, px = pix % WTW;
+                const float4 v = (inmask >> (XIT + it)) & 1u ? rd[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+                bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+                put_planes(sD, DIMGR, (c4 >> 3) * DIMGR + (nr ? nd1 : nd0) + px * ROWB + (c4 & 7) * 8, v);
+            };
+            auto between = [&](int s) __attribute__((always_inline)) {
+                if (s == 1) commit_x(0);
+                if (s == 2) {
+#pragma unroll
+                    for (int it = 1; it < XIT; ++it) commit_x(it);
+                }
+                if (s == 3) {
+#pragma unroll
+                    for (int it = 0; it < DIT; ++it) commit_d(it);
+                }
+            };
+            if (has_next) {
+                if (group == 0)
+                    tile_mfma_r<NP, 0, GT0>(acc, sX, sD, xa, db_, between);
+                else
+                    tile_mfma_r<NP, GT0, GT1>(acc, sX, sD, xa, db_, between);
+            } else {  // last tile of the run: nothing to stage (and the dZ column sums must not count rows twice)
+                auto nothing = [](int) {};
+                if (group == 0)
+                    tile_mfma_r<NP, 0, GT0>(acc, sX, sD, xa, db_, nothing);
+                else
+                    tile_mfma_r<NP, GT0, GT1>(acc, sX, sD, xa, db_, nothing);
+            }
+            __syncthreads();
+        }
+        t += run;
+    }
+
+    const int co = co0 + cob * 32 + l31;
+    if (group == 0)
+        store_partial<0, GT0>(acc, a, slice, ci0 + cib * 32, co, half);
+    else
+        store_partial<GT0, GT1>(acc, a, slice, ci0 + cib * 32, co, half);
+
+    if (a.bias_partial && ci_tile == 0) {  // block-uniform
+        __syncthreads();
+        sBias[tid * 4 + 0] = bsum.x; sBias[tid * 4 + 1] = bsum.y; sBias[tid * 4 + 2] = bsum.z; sBias[tid * 4 + 3] = bsum.w;
+        __syncthreads();
+        if (tid < WC) {
+            // thread t owns channel t: every thread's units have c4 = tid % 16 (512 and the unit counts are multiples of 16)
+            const int c4 = tid >> 2, e = tid & 3;
+            float sacc = 0.f;
+            for (int kk = 0; kk < 32; ++kk) sacc += sBias[(kk * 16 + c4) * 4 + e];
+            if (co0 + tid < a.cout) a.bias_partial[(size_t)slice * a.cout + co0 + tid] = sacc;
+        }
+    }
+}
+
+constexpr int smem_bytes_r(int np) {
+    const int operands = np * 2 * (XIMGR + DIMGR);  // 127,488 B at NP = 3
+    return operands > 512 * 16 ? operands : 512 * 16;
+}
+
 constexpr int smem_bytes(int np) {
     const int operands = np * 2 * (XIMG + DIMG);  // 76,800 B at NP = 3
     return operands > 512 * 16 ? operands : 512 * 16;  // the bias staging (512 threads x float4) re-uses the region
 }
 
+#ifndef PUNET_WGRAD_ROLLING
+#define PUNET_WGRAD_ROLLING 1  // 1: the rolling-row-buffer kernel (round 2), 0: the whole-halo-per-tile kernel of round 1
+#endif
+
 template <int NP>
 int launch_wgrad(const WgradX6Args& a, dim3 grid, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)wgrad3x3_x6_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * smem_bytes(NP)) != hipSuccess) {
-            punet_set_error("punet_conv_wgrad_x6: cannot reserve %d bytes of LDS", 2 * smem_bytes(NP));
-            return PUNET_ERR_HIP;
-        }
-        attr_set = true;
+#if PUNET_WGRAD_ROLLING
+    if (hipFuncSetAttribute((const void*)wgrad3x3_x6r_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes_r(NP)) !=
+        hipSuccess) {
+        punet_set_error("punet_conv_wgrad_x6: cannot reserve %d bytes of LDS", smem_bytes_r(NP));
+        return PUNET_ERR_HIP;
+    }
+    wgrad3x3_x6r_kernel<NP><<<grid, 512, smem_bytes_r(NP), stream>>>(a);
+#else
+    if (hipFuncSetAttribute((const void*)wgrad3x3_x6_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * smem_bytes(NP)) !=
+        hipSuccess) {
+        punet_set_error("punet_conv_wgrad_x6: cannot reserve %d bytes of LDS", 2 * smem_bytes(NP));
+        return PUNET_ERR_HIP;
     }
     wgrad3x3_x6_kernel<NP><<<grid, 512, 2 * smem_bytes(NP), stream>>>(a);
+#endif
     return PUNET_OK;
 }
 
