@@ -274,3 +274,28 @@ def test_batch_tensors_beyond_2e31_elements(dev):
     torch.cuda.synchronize()
     assert (dw - acc_w).abs().max().item() <= 2e-5 * acc_w.abs().max().item()
     assert (db - acc_b).abs().max().item() <= 2e-5 * acc_b.abs().max().item()
+
+
+def test_pseudo_prediction_livecell_image_size_against_oracle(dev):
+    """punet_pseudo_prediction's whole-image forward at the LIVECell image size 520 x 704 (8 | H, W but 32 does not divide H:
+    partial tiles in every kernel) with the scripts' filters: mean map within 1e-4 of the oracle, consensus
+    mask identical except where a sigmoid sits within 1e-5 of a threshold."""
+    from probabilistic_domain_adaptation_amd.my_predictions import pseudo_predict_image
+    m = _model(dev)
+    cfg = O.PUNetConfig(1, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    P = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    img = (np.random.default_rng(11).normal(size=(520, 704)) * 25 + 110).astype("float32")
+    n = 8
+    eps = torch.randn(n, 1, 6, generator=torch.Generator().manual_seed(12))
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref_mean, ref_mask = O.pseudo_prediction(P, cfg, img, eps)
+    mean, mask = pseudo_predict_image(m, img, prior_samples=n, eps=eps)
+    assert mean.shape == (520, 704) and mask.dtype == np.uint8
+    assert np.abs(mean - ref_mean).max() < 1e-4
+    with torch.no_grad():
+        st = O.punet_forward(P, cfg, torch.from_numpy(O.standardize_np(img))[None, None], None, False)
+        probs = torch.stack([torch.sigmoid(O.punet_sample(P, cfg, st, eps[i])) for i in range(n)])[:, 0, 0]
+    unsafe = ((probs - 0.9).abs().min(0).values <= 1e-5) | ((probs - 0.1).abs().min(0).values <= 1e-5)
+    mism = int((mask != ref_mask).sum())
+    print(f"\n520x704 pseudo-prediction: {mism} mask pixels differ ({int(unsafe.sum())} within 1e-5 of a threshold)")
+    assert mism <= int(unsafe.sum()) and 0.01 < ref_mask.mean() < 0.99
