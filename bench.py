@@ -206,7 +206,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--samples", type=int, default=8)
-    ap.add_argument("--conv-mode", default=None, choices=["x6", "f32", "x3", "bf16"],
+    ap.add_argument("--conv-mode", default=None, choices=["x6", "f32", "x3", "bf16", "bf16s"],
                     help="3x3 conv arithmetic (default: $PUNET_CONV_MODE or x6); x3/bf16 are reduced-precision fast modes")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the timed steps eagerly from Python instead of replaying the captured hipGraph")
@@ -300,7 +300,9 @@ def main():
             "value": round(patches / dt, 4), "unit": "patches/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"x6": "f32", "f32": "f32", "x3": "bf16x3 (fp32 storage, 16-bit significand products; reduced precision)",
-                      "bf16": "bf16 (fp32 storage; reduced precision)"}[eng.conv_mode], "data": "synthetic",
+                      "bf16": "bf16 (fp32 storage; reduced precision)",
+                      "bf16s": "bf16 (bf16 activation storage on the no-gradient passes; reduced precision)"}[eng.conv_mode],
+            "data": "synthetic",
             "config": {"workload": f"PUNet {a.workload} step: nf={NF}, latent 6, fcomb 3, BCE+KL, consensus masking, "
                                    f"{H}x{W}x{a.channels} patches, batch {B}/GPU, N={N} MC samples, Adam lr 1e-5, EMA 0.999",
                        "global_batch": world * B, "parallelism": f"dp{world}",
@@ -326,7 +328,9 @@ def main():
             "x3": "REDUCED PRECISION fast mode: 3x3 convs with 2 bf16 planes per operand, 3 bf16 MFMAs per product "
                   "(16 significand bits), fp32 accumulate and storage; 1x1 convs fp32-input MFMA",
             "bf16": "REDUCED PRECISION fast mode: 3x3 convs in plain bf16 (1 MFMA per product), fp32 accumulate and "
-                    "storage; 1x1 convs fp32-input MFMA"}[eng.conv_mode]
+                    "storage; 1x1 convs fp32-input MFMA",
+            "bf16s": "REDUCED PRECISION fast mode: as bf16, plus bf16 STORAGE of the activations on the passes no gradient flows "
+                     "through (teacher / weak pass, inference)"}[eng.conv_mode]
         if prof:
             out["config"]["instrumented_eager_region"] = {
                 "ms_per_step": round(1e3 * dt_eager / a.steps, 3), "host_enqueue_ms_per_step": round(1e3 * t_enq_eager / a.steps, 2),
@@ -360,7 +364,7 @@ def main():
                 ach = k3[0] / k3[1] / 1e12
                 if eng.x6:
                     # n bf16 MFMAs per product: the roofline of THIS arithmetic is the bf16 dense peak / n
-                    n = {"x6": 6, "x3": 3, "bf16": 1}[eng.conv_mode]
+                    n = {"x6": 6, "x3": 3, "bf16": 1, "bf16s": 1}[eng.conv_mode]
                     peak = BF16_MFMA_PEAK_TFLOPS / n
                     kname = (f"conv3x3_x6b_kernel<{(n + 1) // 2 if n > 1 else 1} planes> (3x3 NHWC direct conv forward, "
                              f"v_mfma_f32_16x16x32_bf16; conv3x3_x6_kernel for channel counts that are not multiples of 32)")

@@ -231,6 +231,22 @@ int punet_fcomb_train_reduce(const float* workspace, float* dw1, int w1_rows, fl
                              float* db3, float* S, float* chan_workspace, int B, int HW, int CH, int nmid, int accumulate,
                              void* stream);
 
+/* ---- "bf16s": the opt-in reduced-precision fast mode with bf16 STORAGE of the activations on the no-gradient forward path
+ *      (inference, teacher / weak pass).  [B,H,W,C] bf16 tensors; one bf16 MFMA per product; fp32 accumulate,
+ *      bias, interpolation weights and latent head.  NOT a parity mode. */
+int punet_conv3x3_small_fwd_bf16s(const float* x, int cin, const float* w, const float* bias, void* y, int cout, int B, int H,
+                                  int W, int relu, void* stream);                       /* fp32 image in, bf16 out */
+int punet_conv3x3_bf16s(const void* x0, int c0, const void* x1, int c1, const void* wplanes, long plane_stride, int n_row,
+                        int n_off, const float* bias, void* y, int n_out, void* pool_out, int relu, int B, int H, int W,
+                        void* stream);                                                  /* pool_out nullable: fused AvgPool2d(2,2) */
+int punet_upsample2x_fwd_bf16s(const void* x, void* y, int B, int H, int W, int C, void* stream);
+int punet_latent_head_fwd_bf16s(const void* enc, const float* w, const float* bias, float* mean, float* muls, float* workspace,
+                                int B, int P, int C, int J, void* stream);
+int punet_fcomb_sample_x6_bf16s(const void* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
+                                const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z,
+                                float* logits, int N, int B, int HW, int CH, int nmid, float upper, float lower, int masking,
+                                void* stream);
+
 /* ---- K8: the reduction half of K7 on given logits[N][P] (unit parity of the consensus rule) */
 int punet_consensus(const float* logits, int N, long P, float upper, float lower, int masking, float* y, float* z,
                     void* stream);

@@ -70,6 +70,11 @@ _SIGS = {
     "punet_fcomb_train_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "punet_fcomb_train_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "punet_fcomb_train_reduce": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "punet_conv3x3_small_fwd_bf16s": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "punet_conv3x3_bf16s": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _p, _i, _p, _i, _i, _i, _i, _p]),
+    "punet_upsample2x_fwd_bf16s": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "punet_latent_head_fwd_bf16s": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "punet_fcomb_sample_x6_bf16s": (_i, [_p, _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "punet_consensus": (_i, [_p, _i, _l, _f, _f, _i, _p, _p, _p]),
     "punet_loss_workspace_floats": (_sz, []),
     "punet_bce_fwd_bwd": (_i, [_p, _p, _p, _f, _p, _p, _p, _l, _p]),

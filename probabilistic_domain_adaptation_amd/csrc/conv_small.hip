@@ -13,7 +13,7 @@ namespace {
 // grid = (ceil(W / (ppb * XITER)), rows <= 65535): a block walks XITER strips of ppb pixels of ONE image row, so the
 // row / batch decomposition is block-uniform and the per-pixel index arithmetic is a handful of 32-bit adds (two 32-bit
 // divisions per pixel had made this store-bound kernel ALU-bound: 3.0 TB/s of stores, r02)
-template <int CIN>
+template <int CIN, bool OUT16 = false>  // OUT16: y holds bf16 (the "bf16s" fast mode)
 __global__ __launch_bounds__(256) void conv3x3_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ y,
                                                                int cout, int B, int H, int W, int relu, int xiter) {
@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void conv3x3_small_fwd_kernel(const float* __r
     for (unsigned row = blockIdx.y; row < (unsigned)(B * H); row += gridDim.y) {  // b * H + py
         const int py = (int)(row % (unsigned)H);
         const float* xrow = x + (size_t)row * W * CIN;  // 64-bit base per row, 32-bit offsets inside
-        float* yrow = y + (size_t)row * W * cout + g * 4;
+        float* yrow = OUT16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(y) + (size_t)row * W * cout + g * 4)
+                            : y + (size_t)row * W * cout + g * 4;
         const bool up = py > 0, down = py < H - 1;
         for (int it = 0; it < xiter; ++it) {
             const int px = ((int)blockIdx.x * xiter + it) * ppb + pl;
@@ -53,7 +54,14 @@ __global__ __launch_bounds__(256) void conv3x3_small_fwd_kernel(const float* __r
                 o.z = fmaf(xv, ww.z, o.z); o.w = fmaf(xv, ww.w, o.w);
             }
             if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-            *reinterpret_cast<float4*>(yrow + (size_t)px * cout) = o;
+            if constexpr (OUT16) {
+                typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+                bf16x4_ ob;
+                ob[0] = (__bf16)o.x; ob[1] = (__bf16)o.y; ob[2] = (__bf16)o.z; ob[3] = (__bf16)o.w;
+                *reinterpret_cast<bf16x4_*>(reinterpret_cast<__bf16*>(yrow) + (size_t)px * cout) = ob;
+            } else {
+                *reinterpret_cast<float4*>(yrow + (size_t)px * cout) = o;
+            }
         }
     }
 }
@@ -127,8 +135,8 @@ constexpr int SMALL_WGRAD_BLOCKS = 1024;
 
 }  // namespace
 
-extern "C" int punet_conv3x3_small_fwd(const float* x, int cin, const float* w, const float* bias, float* y, int cout,
-                                       int B, int H, int W, int relu, void* stream_) {
+static int small_fwd_launch(bool out16, const float* x, int cin, const float* w, const float* bias, void* y, int cout, int B, int H,
+                            int W, int relu, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     PUNET_CHECK_ARG(x && w && y, "punet_conv3x3_small_fwd: null pointer");
     PUNET_CHECK_ARG(cin >= 1 && cin <= 4, "punet_conv3x3_small_fwd: cin must be 1..4 (got %d)", cin);
@@ -138,14 +146,31 @@ extern "C" int punet_conv3x3_small_fwd(const float* x, int cin, const float* w, 
     const int ppb = 256 / (cout / 4);
     const int xiter = 8;
     const dim3 grid(ceil_div(W, ppb * xiter), B * H < 65535 ? B * H : 65535);
+    float* yf = (float*)y;
+#define PUNET_SMALL_FWD(CI)                                                                                          \
+    do {                                                                                                             \
+        if (out16) conv3x3_small_fwd_kernel<CI, true><<<grid, 256, 0, stream>>>(x, w, bias, yf, cout, B, H, W, relu, xiter); \
+        else conv3x3_small_fwd_kernel<CI, false><<<grid, 256, 0, stream>>>(x, w, bias, yf, cout, B, H, W, relu, xiter);      \
+    } while (0)
     switch (cin) {
-        case 1: conv3x3_small_fwd_kernel<1><<<grid, 256, 0, stream>>>(x, w, bias, y, cout, B, H, W, relu, xiter); break;
-        case 2: conv3x3_small_fwd_kernel<2><<<grid, 256, 0, stream>>>(x, w, bias, y, cout, B, H, W, relu, xiter); break;
-        case 3: conv3x3_small_fwd_kernel<3><<<grid, 256, 0, stream>>>(x, w, bias, y, cout, B, H, W, relu, xiter); break;
-        default: conv3x3_small_fwd_kernel<4><<<grid, 256, 0, stream>>>(x, w, bias, y, cout, B, H, W, relu, xiter); break;
+        case 1: PUNET_SMALL_FWD(1); break;
+        case 2: PUNET_SMALL_FWD(2); break;
+        case 3: PUNET_SMALL_FWD(3); break;
+        default: PUNET_SMALL_FWD(4); break;
     }
+#undef PUNET_SMALL_FWD
     PUNET_LAUNCH_CHECK("conv3x3_small_fwd");
     return PUNET_OK;
+}
+
+extern "C" int punet_conv3x3_small_fwd(const float* x, int cin, const float* w, const float* bias, float* y, int cout,
+                                       int B, int H, int W, int relu, void* stream) {
+    return small_fwd_launch(false, x, cin, w, bias, y, cout, B, H, W, relu, stream);
+}
+
+extern "C" int punet_conv3x3_small_fwd_bf16s(const float* x, int cin, const float* w, const float* bias, void* y, int cout, int B,
+                                             int H, int W, int relu, void* stream) {
+    return small_fwd_launch(true, x, cin, w, bias, y, cout, B, H, W, relu, stream);
 }
 
 extern "C" size_t punet_small_wgrad_workspace_floats(int cin, int cout) {

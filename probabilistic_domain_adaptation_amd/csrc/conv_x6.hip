@@ -81,8 +81,11 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
 // (ReLU gate of the destination as fp32 mask or bits, optional accumulate).  Two instantiations instead of run-time
 // flags: the kernel sits at the 256-VGPR limit and every live flag / pointer of the other mode costs registers.
 // KS = 3 or 1 (the Fcomb layers): with one tap the "last tap, two chunks per K-step" pairing is the whole K loop.
-template <int NP, bool DGRAD, int KS = 3>
+// IO16 (one-plane forward only; the opt-in "bf16s" fast mode): the activation tensors x0, x1, y and pool_out hold bf16 instead
+// of fp32 - the staging loads are half the bytes and need no conversion, the epilogue stores 8 instead of 16 bytes per quad.
+template <int NP, bool DGRAD, int KS = 3, bool IO16 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
+    static_assert(!IO16 || (NP == 1 && !DGRAD), "bf16 activation storage exists for the one-plane forward kernel only");
     constexpr int KK = KS * KS, PAD = KS / 2;
     constexpr int HTH = TH + KS - 1, HTW = TW + KS - 1;
     constexpr int NPIX = HTH * HTW;
@@ -133,6 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     zero_acc();
 
     float4 rx[XITER];
+    uint2 rx16[XITER];  // IO16: four bf16 of one unit, already in LDS format
     uint4 rw[WITER];
 
     // Staging addresses.  Everything that depends only on the thread and on the TILE is computed once per tile
@@ -176,7 +180,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
         const int q = min(tid + it * 256, XUNITS - 1) % (CK / 4);  // the same clamped unit index as in retarget / commit
         // raw value: the out-of-image zeroing happens where the register is consumed (split_unit) - a select right here
         // would make the wave wait for the load it has just issued
-        return *reinterpret_cast<const float4*>(src + (unsigned)(xpix[it] * cs + coff + q * 4));
+        if constexpr (IO16) {
+            const __bf16* s16 = reinterpret_cast<const __bf16*>(kbase < a.c0 ? a.x0 : a.x1) + (size_t)xb * ((size_t)(a.H * a.W) * cs);
+            rx16[it] = *reinterpret_cast<const uint2*>(s16 + (unsigned)(xpix[it] * cs + coff + q * 4));
+            return make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            return *reinterpret_cast<const float4*>(src + (unsigned)(xpix[it] * cs + coff + q * 4));
+        }
     };
     auto load_w = [&](int ch, int it) __attribute__((always_inline)) -> uint4 {
         return *reinterpret_cast<const uint4*>(a.wp + (wbase[it] + (unsigned)(ch * a.n_row * 8)));
@@ -198,6 +208,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     // the shadow of its own MFMAs, whereas VALU work of the OTHER resident wave is held up behind them.
     bf16x4 px[XITER][NP];
     auto split_unit = [&](int it) __attribute__((always_inline)) {
+        if constexpr (IO16) {  // already bf16: only the zero padding remains
+            const uint2 z = xin[it] ? rx16[it] : make_uint2(0u, 0u);
+            px[it][0] = __builtin_bit_cast(bf16x4, z);
+            return;
+        }
         const float4 r = xin[it] ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding outside the image
         const float xv[4] = {r.x, r.y, r.z, r.w};
         bf16x4 ph, pm, pl;
@@ -247,7 +262,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
         const int gx = ti.tx0 + l31;
         // uniform 64-bit base of image ti.b in the output-shaped tensors; offsets inside the image stay 32-bit
         const size_t img = (size_t)ti.b * ((size_t)(a.H * a.W) * N);
-        float* const yb = a.y + img;
+        // (IO16: y / pool_out hold bf16 - the element offsets below are halved in bytes by addressing through __bf16*)
+        float* const yb = IO16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(a.y) + img) : a.y + img;
         const float* const mb = a.mask ? a.mask + img : nullptr;
         // all eight bias quads first (one latency; per-quad loads inside the store loop had been a chain of 16 dependent L2
         // round trips per tile - 16k cycles, 17 % of a 64-channel layer's tile)
@@ -273,7 +289,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
             const unsigned pbase0 = (unsigned)((gy0 * a.W + gx) * N + ti.n0 + 4 * half);
             const unsigned pbase1 = pbase0 + (unsigned)(a.W * N);
             const unsigned qbase = (unsigned)(((gy0 >> 1) * (a.W >> 1) + (gx >> 1)) * N + ti.n0 + 4 * half);
-            float* const qb = a.pool_out ? a.pool_out + (img >> 2) : nullptr;  // the pooled image has a quarter of the pixels
+            float* const qb = !a.pool_out ? nullptr  // the pooled image has a quarter of the pixels
+                              : IO16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(a.pool_out) + (img >> 2)) : a.pool_out + (img >> 2);
             unsigned gout0 = 0u, gout1 = 0u;
             auto partner = [](float v) __attribute__((always_inline)) {  // value of lane ^ 1 (quad_perm [1, 0, 3, 2])
                 return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
@@ -293,13 +310,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                         v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
                         v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
                     }
+                    auto store4 = [](float* base, unsigned off, const float4& v) __attribute__((always_inline)) {
+                        if constexpr (IO16) {
+                            bf16x4 o;
+                            o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + off) = o;
+                        } else {
+                            *reinterpret_cast<float4*>(base + off) = v;
+                        }
+                    };
                     if (in0 && okc) {
-                        *reinterpret_cast<float4*>(yb + pbase0 + ch) = v0;
+                        store4(yb, pbase0 + ch, v0);
                         gout0 |= ((v0.x > 0.f ? 1u : 0u) | (v0.y > 0.f ? 2u : 0u) | (v0.z > 0.f ? 4u : 0u) | (v0.w > 0.f ? 8u : 0u))
                                  << (16 * nb + 4 * rg);
                     }
                     if (in1 && okc) {
-                        *reinterpret_cast<float4*>(yb + pbase1 + ch) = v1;
+                        store4(yb, pbase1 + ch, v1);
                         gout1 |= ((v1.x > 0.f ? 1u : 0u) | (v1.y > 0.f ? 2u : 0u) | (v1.z > 0.f ? 4u : 0u) | (v1.w > 0.f ? 8u : 0u))
                                  << (16 * nb + 4 * rg);
                     }
@@ -309,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                         q.y = (((v0.y + partner(v0.y)) + v1.y) + partner(v1.y)) * 0.25f;
                         q.z = (((v0.z + partner(v0.z)) + v1.z) + partner(v1.z)) * 0.25f;
                         q.w = (((v0.w + partner(v0.w)) + v1.w) + partner(v1.w)) * 0.25f;
-                        if (!(lane & 1) && in0 && okc) *reinterpret_cast<float4*>(qb + qbase + ch) = q;
+                        if (!(lane & 1) && in0 && okc) store4(qb, qbase + ch, q);
                     }
                 }
             if (a.gate_out) {  // forward with ReLU: (y > 0), for the consumers' backward
@@ -958,6 +984,36 @@ extern "C" int punet_conv1x1_x6_gated(const float* x0, int c0, const float* x1, 
                                       int accumulate, int relu, int B, int H, int W, void* stream) {
     return conv_x6_launch(1, x0, c0, x1, c1, wplanes, plane_stride, n_row, n_off, bias, bias_img_stride, y, n_out, mask, gate_bits,
                           gate_out, accumulate, relu, B, H, W, 0, stream);
+}
+
+// One-plane forward convolution on bf16 activation tensors (the "bf16s" fast mode: opt-in, reduced precision): x0 / x1 / y /
+// pool_out are [B,H,W,C] bf16; weights = plane 0 of punet_split_weights_x6; bias fp32; no gate bits (no backward follows).
+extern "C" int punet_conv3x3_bf16s(const void* x0, int c0, const void* x1, int c1, const void* wplanes, long plane_stride, int n_row,
+                                   int n_off, const float* bias, void* y, int n_out, void* pool_out, int relu, int B, int H, int W,
+                                   void* stream) {
+    PUNET_CHECK_ARG(x0 && wplanes && y, "punet_conv3x3_bf16s: null pointer");
+    PUNET_CHECK_ARG(c0 > 0 && c0 % CK == 0 && c1 >= 0 && c1 % CK == 0 && (c1 == 0 || x1),
+                    "punet_conv3x3_bf16s: source channels must be multiples of %d (c0=%d c1=%d)", CK, c0, c1);
+    PUNET_CHECK_ARG(n_out > 0 && n_out % 4 == 0 && n_off >= 0 && n_off + n_out <= n_row, "punet_conv3x3_bf16s: bad output-channel window");
+    PUNET_CHECK_ARG(B > 0 && H > 0 && W > 0 && (!pool_out || (H % 2 == 0 && W % 2 == 0)), "punet_conv3x3_bf16s: bad shape %dx%d", H, W);
+    {
+        const unsigned long long px = (unsigned long long)H * W;
+        const int cmax = c0 > c1 ? (c0 > n_out ? c0 : n_out) : (c1 > n_out ? c1 : n_out);
+        PUNET_CHECK_ARG(px * cmax < (1ull << 31) && (unsigned long long)B * px < (1ull << 31), "punet_conv3x3_bf16s: image too large");
+    }
+    ConvX6Args a{};
+    a.x0 = (const float*)x0; a.x1 = (const float*)x1; a.c0 = c0; a.c1 = c1;
+    a.wp = (const __bf16*)wplanes; a.plane_stride = plane_stride; a.n_row = n_row; a.n_off = n_off;
+    a.bias = bias; a.bias_img_stride = 0;
+    a.y = (float*)y; a.n_total = n_out; a.relu = relu; a.pool_out = (float*)pool_out;
+    a.B = B; a.H = H; a.W = W;
+    a.ntiles = B * ceil_div(H, TH) * ceil_div(W, TW) * ceil_div(n_out, TN);
+    const int cap = WG_PER_CU * punet_num_cus();
+    const int grid = a.ntiles < cap ? a.ntiles : cap;
+    a.xcd_remap = grid % 8 == 0;
+    conv3x3_x6_kernel<1, false, 3, true><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    PUNET_LAUNCH_CHECK("conv3x3_bf16s");
+    return PUNET_OK;
 }
 
 static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,

@@ -193,7 +193,7 @@ __device__ __forceinline__ f32x16 mfma6(const bf16x8s (&wa)[3], const Planes& xb
 #ifndef PUNET_K7X_WGS
 #define PUNET_K7X_WGS 2  // workgroups per CU the register allocation aims at (tools/ab_variants.sh experiment knob)
 #endif
-template <int NBLK>
+template <int NBLK, bool F16 = false>  // F16: a.feat holds bf16 (the "bf16s" fast mode)
 __global__ __launch_bounds__(256, PUNET_K7X_WGS) void fcomb_sampler_x6_kernel(SamplerArgs a) {
     constexpr int CH = 32 * NBLK, KB = CH / 16;
     constexpr int LAYER = 3 * KB * 2 * CH;  // uint4 (8 x bf16) units per layer: [plane][K block][half][co]
@@ -243,10 +243,21 @@ __global__ __launch_bounds__(256, PUNET_K7X_WGS) void fcomb_sampler_x6_kernel(Sa
             for (int r = 0; r < 16; ++r) t1[cb][r] = 0.f;
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
-            const float4 f0 = *reinterpret_cast<const float4*>(a.feat + pix * CH + 16 * j + 4 * half);
-            const float4 f1 = *reinterpret_cast<const float4*>(a.feat + pix * CH + 16 * j + 8 + 4 * half);
-            const float fv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-            const Planes xb = split8(fv);
+            Planes xb;
+            if constexpr (F16) {  // already bf16: plane 0 is the value, the other planes are zero
+                typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+                const __bf16* f16 = reinterpret_cast<const __bf16*>(a.feat) + pix * CH + 16 * j + 4 * half;
+                const bf16x4s g0 = *reinterpret_cast<const bf16x4s*>(f16), g1 = *reinterpret_cast<const bf16x4s*>(f16 + 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { xb.p[0][i] = g0[i]; xb.p[0][4 + i] = g1[i]; }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { xb.p[1][i] = (__bf16)0.f; xb.p[2][i] = (__bf16)0.f; }
+            } else {
+                const float4 f0 = *reinterpret_cast<const float4*>(a.feat + pix * CH + 16 * j + 4 * half);
+                const float4 f1 = *reinterpret_cast<const float4*>(a.feat + pix * CH + 16 * j + 8 + 4 * half);
+                const float fv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                xb = split8(fv);
+            }
 #pragma unroll
             for (int cb = 0; cb < NBLK; ++cb) {
                 bf16x8s wa[3];
@@ -314,7 +325,7 @@ __global__ __launch_bounds__(256, PUNET_K7X_WGS) void fcomb_sampler_x6_kernel(Sa
 
 }  // namespace
 
-static int fcomb_sample_launch(bool x6, const float* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
+static int fcomb_sample_launch(bool x6, bool f16, const float* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
                                const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z, float* logits,
                                int N, int B, int HW, int CH, int nmid, float upper, float lower, int masking, void* stream) {
     PUNET_CHECK_ARG(feat && w1 && zb && w3 && b3, "punet_fcomb_sample: null pointer");
@@ -340,7 +351,15 @@ static int fcomb_sample_launch(bool x6, const float* feat, const float* w1, cons
             return PUNET_ERR_HIP;
         }
     }
-    if (x6) {
+    if (x6 && f16) {
+        const void* fn16 = CH == 64 ? (const void*)fcomb_sampler_x6_kernel<2, true> : (const void*)fcomb_sampler_x6_kernel<1, true>;
+        if (shmem > 48 * 1024 && hipFuncSetAttribute(fn16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {
+            punet_set_error("punet_fcomb_sample: cannot reserve %zu bytes of LDS", shmem);
+            return PUNET_ERR_HIP;
+        }
+        if (CH == 64) fcomb_sampler_x6_kernel<2, true><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
+        else fcomb_sampler_x6_kernel<1, true><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
+    } else if (x6) {
         if (CH == 64) fcomb_sampler_x6_kernel<2><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
         else fcomb_sampler_x6_kernel<1><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
     } else {
@@ -354,13 +373,22 @@ static int fcomb_sample_launch(bool x6, const float* feat, const float* w1, cons
 extern "C" int punet_fcomb_sample(const float* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
                                   const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z, float* logits, int N, int B, int HW,
                                   int CH, int nmid, float upper, float lower, int masking, void* stream) {
-    return fcomb_sample_launch(false, feat, w1, zb, wmid, wmid_stride, bmid, bmid_stride, w3, b3, y, z, logits, N, B, HW, CH, nmid,
+    return fcomb_sample_launch(false, false, feat, w1, zb, wmid, wmid_stride, bmid, bmid_stride, w3, b3, y, z, logits, N, B, HW, CH, nmid,
                                upper, lower, masking, stream);
 }
 
 extern "C" int punet_fcomb_sample_x6(const float* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
                                      const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z, float* logits, int N, int B,
                                      int HW, int CH, int nmid, float upper, float lower, int masking, void* stream) {
-    return fcomb_sample_launch(true, feat, w1, zb, wmid, wmid_stride, bmid, bmid_stride, w3, b3, y, z, logits, N, B, HW, CH, nmid,
+    return fcomb_sample_launch(true, false, feat, w1, zb, wmid, wmid_stride, bmid, bmid_stride, w3, b3, y, z, logits, N, B, HW, CH, nmid,
                                upper, lower, masking, stream);
+}
+
+// the same with the feature map stored as bf16 (the "bf16s" fast mode; opt-in, reduced precision)
+extern "C" int punet_fcomb_sample_x6_bf16s(const void* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
+                                           const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z,
+                                           float* logits, int N, int B, int HW, int CH, int nmid, float upper, float lower, int masking,
+                                           void* stream) {
+    return fcomb_sample_launch(true, true, (const float*)feat, w1, zb, wmid, wmid_stride, bmid, bmid_stride, w3, b3, y, z, logits, N, B, HW,
+                               CH, nmid, upper, lower, masking, stream);
 }

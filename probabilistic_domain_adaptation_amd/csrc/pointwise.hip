@@ -190,6 +190,43 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float4* __res
     }
 }
 
+// the same on bf16 tensors (the "bf16s" fast mode): 8-byte loads / stores of four channels, fp32 interpolation
+typedef __bf16 pw_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_bf16x4(const pw_bf16x4* p) {
+    const pw_bf16x4 v = *p;
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__global__ __launch_bounds__(256) void upsample2x_fwd16_kernel(const pw_bf16x4* __restrict__ x, pw_bf16x4* __restrict__ y, int B, int H,
+                                                               int W, int C4, int c4_shift) {
+    const int OH = 2 * H, OW = 2 * W;
+    const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+    const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    for (unsigned row = blockIdx.y; row < (unsigned)(B * OH); row += gridDim.y) {
+        const unsigned bu = row / (unsigned)OH;
+        const int oy = (int)(row - bu * (unsigned)OH);
+        const unsigned e = blockIdx.x * 256u + threadIdx.x;
+        if (e >= (unsigned)(OW * C4)) return;
+        const int ox = c4_shift >= 0 ? (int)(e >> c4_shift) : (int)(e / (unsigned)C4);
+        const int c = (int)e - ox * C4;
+        const size_t b = bu;
+        int h1, hp, w1, wp;
+        float hl1, wl1;
+        up_src(oy, sh, H, h1, hp, hl1);
+        up_src(ox, sw, W, w1, wp, wl1);
+        const float hl0 = 1.f - hl1, wl0 = 1.f - wl1;
+        const pw_bf16x4* r0 = x + ((b * H + h1) * W) * C4 + c;
+        const pw_bf16x4* r1 = x + ((b * H + h1 + hp) * W) * C4 + c;
+        const float4 v00 = ld_bf16x4(r0 + (size_t)w1 * C4), v01 = ld_bf16x4(r0 + (size_t)(w1 + wp) * C4);
+        const float4 v10 = ld_bf16x4(r1 + (size_t)w1 * C4), v11 = ld_bf16x4(r1 + (size_t)(w1 + wp) * C4);
+        pw_bf16x4 o;
+        o[0] = (__bf16)(hl0 * (wl0 * v00.x + wl1 * v01.x) + hl1 * (wl0 * v10.x + wl1 * v11.x));
+        o[1] = (__bf16)(hl0 * (wl0 * v00.y + wl1 * v01.y) + hl1 * (wl0 * v10.y + wl1 * v11.y));
+        o[2] = (__bf16)(hl0 * (wl0 * v00.z + wl1 * v01.z) + hl1 * (wl0 * v10.z + wl1 * v11.z));
+        o[3] = (__bf16)(hl0 * (wl0 * v00.w + wl1 * v01.w) + hl1 * (wl0 * v10.w + wl1 * v11.w));
+        y[(size_t)row * OW * C4 + e] = o;
+    }
+}
+
 // weight with which output index o reads input index i along one axis
 __device__ __forceinline__ float up_weight(int o, int i, float scale, int in_size) {
     int i0, ip;
@@ -253,8 +290,10 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float4* __res
 // K6: latent head = global average pool + 1x1 conv C -> 2L (probabilistic_unet.py:126-137)
 // ------------------------------------------------------------------------------------------------
 // partial[b][s][c] = sum over the pixels of slice s of x[b][p][c]
-__global__ __launch_bounds__(256) void chan_sum_partial_kernel(const float4* __restrict__ x, float4* __restrict__ partial,
+template <bool IN16>  // IN16: x holds bf16 (the "bf16s" fast mode); sums are fp32 either way
+__global__ __launch_bounds__(256) void chan_sum_partial_kernel(const void* __restrict__ xv_, float4* __restrict__ partial,
                                                                int P, int C4, int S) {
+    const float4* x = reinterpret_cast<const float4*>(xv_);
     // thread = (pixel lane pl, channel quad c); the 256 / C4 pixel lanes of a block are combined in lane order via LDS
     extern __shared__ __attribute__((aligned(16))) float4 sh4[];  // [ppl][C4]
     const int s = blockIdx.x, b = blockIdx.y;
@@ -266,7 +305,14 @@ __global__ __launch_bounds__(256) void chan_sum_partial_kernel(const float4* __r
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < C4 && pl < ppl)
             for (int p = p0 + pl; p < p1; p += ppl) {
-                const float4 v = x[((size_t)b * P + p) * C4 + c];
+                float4 v;
+                if constexpr (IN16) {
+                    typedef __bf16 cs_bf16x4 __attribute__((ext_vector_type(4)));
+                    const cs_bf16x4 h = reinterpret_cast<const cs_bf16x4*>(xv_)[((size_t)b * P + p) * C4 + c];
+                    v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+                } else {
+                    v = x[((size_t)b * P + p) * C4 + c];
+                }
                 a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
             }
         __syncthreads();
@@ -1032,10 +1078,18 @@ extern "C" int punet_chan_sum(const float* x, float* out, float* workspace, int 
                               void* stream) {
     PUNET_CHECK_ARG(x && out && workspace && C % 4 == 0 && B > 0 && P > 0, "punet_chan_sum: bad args (C=%d)", C);
     const int S = chan_slices(P, C);
-    chan_sum_partial_kernel<<<dim3(S, B), 256, 256 * sizeof(float4), STREAM>>>((const float4*)x, (float4*)workspace, P, C / 4, S);
+    chan_sum_partial_kernel<false><<<dim3(S, B), 256, 256 * sizeof(float4), STREAM>>>(x, (float4*)workspace, P, C / 4, S);
     PUNET_LAUNCH_CHECK("chan_sum_partial");
     chan_sum_finalize_kernel<<<dim3(B, (C + 63) / 64), 256, 0, STREAM>>>(workspace, out, S, C, scale);
     PUNET_LAUNCH_CHECK("chan_sum_finalize");
+    return PUNET_OK;
+}
+
+extern "C" int punet_upsample2x_fwd_bf16s(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+    PUNET_CHECK_ARG(x && y && C % 4 == 0 && B > 0 && H > 0 && W > 0, "punet_upsample2x_fwd_bf16s: bad args (C=%d)", C);
+    upsample2x_fwd16_kernel<<<dim3(ceil_div(2 * W * (C / 4), 256), B * 2 * H < 65535 ? B * 2 * H : 65535), 256, 0, STREAM>>>(
+        (const pw_bf16x4*)x, (pw_bf16x4*)y, B, H, W, C / 4, pow2_shift(C / 4));
+    PUNET_LAUNCH_CHECK("upsample2x_fwd16");
     return PUNET_OK;
 }
 
@@ -1044,6 +1098,19 @@ extern "C" int punet_latent_head_fwd(const float* enc, const float* w, const flo
     PUNET_CHECK_ARG(enc && w && bias && mean && muls && workspace, "punet_latent_head_fwd: null pointer");
     int rc = punet_chan_sum(enc, mean, workspace, B, P, C, 1.f / (float)P, stream);
     if (rc != PUNET_OK) return rc;
+    latent_head_kernel<<<B, 256, 0, STREAM>>>(mean, w, bias, muls, C, J);
+    PUNET_LAUNCH_CHECK("latent_head");
+    return PUNET_OK;
+}
+
+extern "C" int punet_latent_head_fwd_bf16s(const void* enc, const float* w, const float* bias, float* mean, float* muls,
+                                           float* workspace, int B, int P, int C, int J, void* stream) {
+    PUNET_CHECK_ARG(enc && w && bias && mean && muls && workspace && C % 4 == 0, "punet_latent_head_fwd_bf16s: bad args");
+    const int S = chan_slices(P, C);
+    chan_sum_partial_kernel<true><<<dim3(S, B), 256, 256 * sizeof(float4), STREAM>>>(enc, (float4*)workspace, P, C / 4, S);
+    PUNET_LAUNCH_CHECK("chan_sum_partial16");
+    chan_sum_finalize_kernel<<<dim3(B, (C + 63) / 64), 256, 0, STREAM>>>(workspace, mean, S, C, 1.f / (float)P);
+    PUNET_LAUNCH_CHECK("chan_sum_finalize");
     latent_head_kernel<<<B, 256, 0, STREAM>>>(mean, w, bias, muls, C, J);
     PUNET_LAUNCH_CHECK("latent_head");
     return PUNET_OK;

@@ -187,7 +187,7 @@ def _stream():
 
 
 # bf16 products per fp32 product in the split-plane kernels; handed to the library with every call (options word)
-_X6_PRODUCTS = {"x6": 6, "x3": 3, "bf16": 1}
+_X6_PRODUCTS = {"x6": 6, "x3": 3, "bf16": 1, "bf16s": 1}
 
 
 class Workspace:
@@ -225,8 +225,12 @@ class PUNetEngine:
         # bits, more than the fp16 autocast of the reference), "bf16" = one plane.  Storage stays fp32 in every mode.
         self.conv_mode = conv_mode or os.environ.get("PUNET_CONV_MODE", "x6")
         if self.conv_mode not in _X6_PRODUCTS and self.conv_mode != "f32":
-            raise ValueError("PUNET_CONV_MODE must be one of 'x6', 'f32', 'x3', 'bf16'")
+            raise ValueError("PUNET_CONV_MODE must be one of 'x6', 'f32', 'x3', 'bf16', 'bf16s'")
         self.x6 = self.conv_mode in _X6_PRODUCTS  # the split-plane kernel family
+        # "bf16s" = "bf16" + bf16 STORAGE of the activations wherever no backward follows (forward_features: inference, the
+        # teacher / weak pass): half the activation traffic, no fp32 -> bf16 conversion in the conv loaders
+        self.act16 = self.conv_mode == "bf16s"
+        self._infer16 = False  # set while forward_features runs in that mode
         # per-call options word of the split-plane kernels: products of this mode, MFMA shape 16 ($PUNET_X6_MFMA_SHAPE=32
         # selects the older 32x32x16 kernels, an A/B switch)
         shape = 32 if os.environ.get("PUNET_X6_MFMA_SHAPE", "16") == "32" else 16
@@ -276,6 +280,8 @@ class PUNetEngine:
 
     def to_nchw(self, a: "Act") -> torch.Tensor:
         """NHWC activation -> contiguous [B,C,H,W] tensor (what the reference's attributes such as unet_features hold)."""
+        if a.t.dtype != torch.float32:  # bf16 storage (fast mode): inspection path only
+            return a.t.float().permute(0, 3, 1, 2).contiguous()
         if a.C == 1:
             return a.t.view(a.B, 1, a.H, a.W)
         y = self._empty(a.B, a.C, a.H, a.W)
@@ -290,9 +296,28 @@ class PUNetEngine:
         can produce it in its epilogue (split-plane 3x3 kernel, even H and W); left empty otherwise."""
         c = self.L.convs[name]
         B, H, W = x0.B, x0.H, x0.W
-        y = Act(self._empty(B, H, W, c.cout), B, H, W, c.cout, relu_out=relu)
         cin = x0.C + (x1.C if x1 is not None else 0)
         assert cin == c.cin, (name, cin, c.cin)
+        if self._infer16 and c.k == 3:  # bf16 activation storage (no tape, no gate bits: nothing is differentiated here)
+            assert tape is None and not tape_bits
+            y = Act(torch.empty(B, H, W, c.cout, dtype=torch.bfloat16, device=self.device), B, H, W, c.cout, relu_out=relu)
+            if cin <= 4:
+                _lib.call("punet_conv3x3_small_fwd_bf16s", x0.ptr, cin, self._wptr(flat, c), self._bptr(flat, c), y.ptr, c.cout, B, H,
+                          W, int(relu), _stream())
+            else:
+                q = None
+                if pooled is not None and H % 2 == 0 and W % 2 == 0:
+                    q = Act(torch.empty(B, H // 2, W // 2, c.cout, dtype=torch.bfloat16, device=self.device), B, H // 2, W // 2, c.cout)
+                    pooled.append(q)
+                planes = self._x6[(flat.data_ptr(), 0)]
+                self._timed("conv3x3_fwd", 2.0 * B * H * W * cin * c.cout * 9, "punet_conv3x3_bf16s", x0.ptr, x0.C,
+                            x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0, planes.data_ptr() + 2 * 3 * c.w_off,
+                            c.w_numel, c.cout, 0, self._bptr(flat, c), y.ptr, c.cout, q.ptr if q is not None else None, int(relu),
+                            B, H, W, _stream())
+            if taps is not None:
+                taps["conv:" + name] = y
+            return y
+        y = Act(self._empty(B, H, W, c.cout), B, H, W, c.cout, relu_out=relu)
         if cin <= 4:
             assert x1 is None and c.k == 3
             _lib.call("punet_conv3x3_small_fwd", x0.ptr, cin, self._wptr(flat, c), self._bptr(flat, c), y.ptr, c.cout,
@@ -340,6 +365,10 @@ class PUNetEngine:
         return y
 
     def upsample(self, x: Act, tape=None) -> Act:
+        if x.t.dtype == torch.bfloat16:
+            y = Act(torch.empty(x.B, 2 * x.H, 2 * x.W, x.C, dtype=torch.bfloat16, device=self.device), x.B, 2 * x.H, 2 * x.W, x.C)
+            _lib.call("punet_upsample2x_fwd_bf16s", x.ptr, y.ptr, x.B, x.H, x.W, x.C, _stream())
+            return y
         y = Act(self._empty(x.B, 2 * x.H, 2 * x.W, x.C), x.B, 2 * x.H, 2 * x.W, x.C)
         _lib.call("punet_upsample2x_fwd", x.ptr, y.ptr, x.B, x.H, x.W, x.C, _stream())
         if tape is not None:
@@ -391,8 +420,9 @@ class PUNetEngine:
         mean = self._empty(enc.B, enc.C)
         muls = self._empty(enc.B, c.cout)
         ws = self.ws.get("chan", _lib.call("punet_chan_sum_workspace_floats", enc.B, P, enc.C))
-        _lib.call("punet_latent_head_fwd", enc.ptr, self._wptr(flat, c), self._bptr(flat, c), mean.data_ptr(), muls.data_ptr(),
-                  ws.data_ptr(), enc.B, P, enc.C, c.cout, _stream())
+        _lib.call("punet_latent_head_fwd_bf16s" if enc.t.dtype == torch.bfloat16 else "punet_latent_head_fwd", enc.ptr,
+                  self._wptr(flat, c), self._bptr(flat, c), mean.data_ptr(), muls.data_ptr(), ws.data_ptr(), enc.B, P, enc.C, c.cout,
+                  _stream())
         return muls, mean, enc
 
     # ---------------------------------------------------------------- inference / teacher path
@@ -401,8 +431,12 @@ class PUNetEngine:
         B, H, W, C = x_nhwc.shape
         self.prepare_forward_weights(flat)
         xin = Act(x_nhwc, B, H, W, C, needs_grad=False)
-        muls_p, _, _ = self.latent(flat, "prior", xin, None, taps)
-        feat = self.unet(flat, xin, None, taps)
+        self._infer16 = self.act16
+        try:
+            muls_p, _, _ = self.latent(flat, "prior", xin, None, taps)
+            feat = self.unet(flat, xin, None, taps)
+        finally:
+            self._infer16 = False
         return {"features": feat, "prior_muls": muls_p}
 
     def _fcomb_ptrs(self, flat):
@@ -433,7 +467,9 @@ class PUNetEngine:
         cz = self._empty(B, 1, feat.H, feat.W) if want_consensus else None
         logits = self._empty(N, B, 1, feat.H, feat.W) if want_logits else None
         # split-plane arithmetic on the BF16 matrix cores in every x6-family mode (always six products: parity), fp32 MFMA in "f32"
-        _lib.call("punet_fcomb_sample_x6" if self.x6 and self.sampler_x6 else "punet_fcomb_sample", feat.ptr, self._wptr(flat, c1),
+        fn = "punet_fcomb_sample_x6_bf16s" if feat.t.dtype == torch.bfloat16 else \
+            ("punet_fcomb_sample_x6" if self.x6 and self.sampler_x6 else "punet_fcomb_sample")
+        _lib.call(fn, feat.ptr, self._wptr(flat, c1),
                   zb.data_ptr(), wmid, stride, bmid, stride,
                   self._wptr(flat, c3), self._bptr(flat, c3), y.data_ptr() if y is not None else None,
                   cz.data_ptr() if cz is not None else None, logits.data_ptr() if logits is not None else None, N, B, HW,

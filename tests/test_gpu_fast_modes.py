@@ -116,7 +116,7 @@ def test_concurrent_threads_keep_their_own_arithmetic(L):
     assert torch.equal(outs[6], serial[6]) and torch.equal(outs[3], serial[3])
 
 
-@pytest.mark.parametrize("mode,logit_band", [("x3", (2e-2, 1e-6)), ("bf16", (2.0, 1e-4))])
+@pytest.mark.parametrize("mode,logit_band", [("x3", (2e-2, 1e-6)), ("bf16", (2.0, 1e-4)), ("bf16s", (2.0, 1e-4))])
 def test_model_fast_mode_against_reference_logits(golden_dir, mode, logit_band):
     """Whole inference path in a fast mode against the reference's logits (fixture 'fixed_small'); the measured error is
     printed for DESIGN.md.  x3 stays well inside what fp16 autocast gives the reference on CUDA; bf16 is coarse."""
@@ -167,3 +167,41 @@ def test_fast_mode_training_step_runs_and_default_is_x6(golden_dir):
     assert np.isfinite(losses["x3"]) and abs(losses["x3"] - losses["x6"]) < 1e-3 * abs(losses["x6"]), losses
     with pytest.raises(ValueError):
         ProbabilisticUnet(1, 1, [32, 32, 32, 32], 6, 3, device=dev, conv_mode="fp8")
+
+
+def test_bf16_storage_mode_runs_on_bf16_tensors_and_stays_close_to_bf16_arithmetic(golden_dir):
+    """"bf16s": the no-gradient forward path keeps its activations in bf16 (every block output IS a bf16 tensor), the result
+    stays within the bf16 arithmetic's own error of the fp32-storage bf16 mode, and a Mean-Teacher step in that mode runs
+    (teacher pass on bf16 tensors, student pass on fp32 tensors as in "bf16")."""
+    import copy
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    dev = torch.device("cuda:0")
+    nf = [64, 64, 96, 128]
+    x, x1, x2, y = [t.to(dev) for t in O.synth_batch(2, 1, 64, 96, 0)]
+    eps = torch.randn(4, 2, 6, generator=torch.Generator().manual_seed(5)).to(dev)
+    outs = {}
+    for mode in ("x6", "bf16", "bf16s"):
+        m = ProbabilisticUnet(1, 1, nf, 6, 3, 1.0, consensus_masking=True, device=dev, seed=1, conv_mode=mode)
+        taps = {}
+        with torch.no_grad():
+            st = m.engine.forward_features(m.flat_params, m.engine.to_nhwc(x1), taps)
+            z = m.engine.reparam(st["prior_muls"], eps)
+            ym, cz, lg = m.engine.sample(m.flat_params, st["features"], z, 0.9, 0.1, False, want_logits=True)
+        torch.cuda.synchronize()
+        dt = {v.t.dtype for k, v in taps.items()}
+        assert dt == ({torch.bfloat16} if mode == "bf16s" else {torch.float32}), (mode, dt)
+        outs[mode] = (lg.float().cpu(), ym.cpu())
+    e_bf16 = (outs["bf16"][0] - outs["x6"][0]).abs().max().item()
+    e_s = (outs["bf16s"][0] - outs["x6"][0]).abs().max().item()
+    print(f"\nlogits max abs err vs x6: bf16 {e_bf16:.3e}, bf16s {e_s:.3e}")
+    assert 1e-4 < e_s < 3.0 * e_bf16 + 1e-2
+    assert not torch.equal(outs["bf16s"][0], outs["bf16"][0])
+    m = ProbabilisticUnet(1, 1, nf, 6, 3, 1.0, consensus_masking=True, device=dev, seed=1, conv_mode="bf16s")
+    t = copy.deepcopy(m)
+    assert t.engine.conv_mode == "bf16s"
+    opt = FusedAdam(m, lr=1e-4)
+    loss, ys, zs, _ = FU.fused_self_training_step(m, t, opt, x1, x2, 4, True, eps_pl=eps, eps_s=eps[:1])
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss)) and ys.dtype == torch.float32 and 0.0 <= float(ys.min()) and float(ys.max()) <= 1.0
