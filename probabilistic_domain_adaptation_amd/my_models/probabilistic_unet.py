@@ -80,8 +80,9 @@ class ProbabilisticUnet(nn.Module):
     def __init__(self, input_channels=1, num_classes=1, num_filters=[32, 64, 128, 192], latent_dim=6, no_convs_fcomb=4,
                  beta=10.0, consensus_masking=False, rl_swap=False, device=None, seed: Optional[int] = None,
                  conv_mode: Optional[str] = None):
-        """conv_mode (extension): None = $PUNET_CONV_MODE or "x6" (fp32-accurate); "x3" / "bf16" are the opt-in fast
-        modes standing in for the reference's mixed_precision=True (engine.PUNetEngine)."""
+        """conv_mode (extension): None = $PUNET_CONV_MODE or "x6" (fp32-accurate); "x3" / "bf16" / "bf16s" (bf16 arithmetic and
+        bf16 activation storage on the no-gradient passes) are the opt-in fast modes standing in for the reference's
+        mixed_precision=True (engine.PUNetEngine)."""
         super().__init__()
         self.input_channels = input_channels
         self.num_classes = num_classes
