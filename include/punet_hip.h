@@ -237,8 +237,20 @@ int punet_fcomb_train_reduce(const float* workspace, float* dw1, int w1_rows, fl
 int punet_conv3x3_small_fwd_bf16s(const float* x, int cin, const float* w, const float* bias, void* y, int cout, int B, int H,
                                   int W, int relu, void* stream);                       /* fp32 image in, bf16 out */
 int punet_conv3x3_bf16s(const void* x0, int c0, const void* x1, int c1, const void* wplanes, long plane_stride, int n_row,
-                        int n_off, const float* bias, void* y, int n_out, void* pool_out, int relu, int B, int H, int W,
-                        void* stream);                                                  /* pool_out nullable: fused AvgPool2d(2,2) */
+                        int n_off, const float* bias, void* y, int n_out, void* gate_out, void* pool_out, int relu, int B, int H,
+                        int W, void* stream);                        /* gate_out, pool_out nullable (gate bits; fused AvgPool2d(2,2)) */
+/* student pass of the same mode: weight gradient with the activation operand stored as bf16 (dz fp32), the fused Fcomb training
+ * kernel reading bf16 features, the latent head's backward gated by the encoder output's gate BITS instead of its fp32 values */
+int punet_conv_wgrad_bf16s(const void* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off, float* dbias,
+                           float* workspace, int nslices, int B, int H, int W, int accumulate, float scale, void* stream);
+int punet_fcomb_train_fwd_bwd_bf16s(const void* feat, const float* w1, const float* zb, const float* wmid, const float* bmid,
+                                    const float* w3, const float* b3, const float* target, const float* consm, float gscale,
+                                    float* logits, float* dfeat, float* loss_sum, float* workspace, int B, int HW, int CH,
+                                    int nmid, void* stream);
+/* gate bits (punet_gate_dwords layout) of a bf16 [B,H,W,C] activation: (y > 0) */
+int punet_gate_bits_bf16(const void* y, void* bits, int B, int H, int W, int C, void* stream);
+int punet_latent_head_bwd_bits(const float* d_muls, const float* mean, const float* w, const void* enc_bits, float* dw, float* db,
+                               float* dmean, float* denc, int B, int H, int W, int C, int J, int accumulate, void* stream);
 int punet_upsample2x_fwd_bf16s(const void* x, void* y, int B, int H, int W, int C, void* stream);
 int punet_latent_head_fwd_bf16s(const void* enc, const float* w, const float* bias, float* mean, float* muls, float* workspace,
                                 int B, int P, int C, int J, void* stream);

@@ -71,7 +71,11 @@ _SIGS = {
     "punet_fcomb_train_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "punet_fcomb_train_reduce": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "punet_conv3x3_small_fwd_bf16s": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "punet_conv3x3_bf16s": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _p, _i, _p, _i, _i, _i, _i, _p]),
+    "punet_conv3x3_bf16s": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "punet_conv_wgrad_bf16s": (_i, [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "punet_fcomb_train_fwd_bwd_bf16s": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "punet_gate_bits_bf16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "punet_latent_head_bwd_bits": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "punet_upsample2x_fwd_bf16s": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "punet_latent_head_fwd_bf16s": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "punet_fcomb_sample_x6_bf16s": (_i, [_p, _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),

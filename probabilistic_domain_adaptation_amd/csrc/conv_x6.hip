@@ -987,10 +987,11 @@ extern "C" int punet_conv1x1_x6_gated(const float* x0, int c0, const float* x1, 
 }
 
 // One-plane forward convolution on bf16 activation tensors (the "bf16s" fast mode: opt-in, reduced precision): x0 / x1 / y /
-// pool_out are [B,H,W,C] bf16; weights = plane 0 of punet_split_weights_x6; bias fp32; no gate bits (no backward follows).
+// pool_out are [B,H,W,C] bf16; weights = plane 0 of punet_split_weights_x6; bias fp32; gate_out (nullable) as punet_conv3x3_x6_gated.
 extern "C" int punet_conv3x3_bf16s(const void* x0, int c0, const void* x1, int c1, const void* wplanes, long plane_stride, int n_row,
-                                   int n_off, const float* bias, void* y, int n_out, void* pool_out, int relu, int B, int H, int W,
-                                   void* stream) {
+                                   int n_off, const float* bias, void* y, int n_out, void* gate_out, void* pool_out, int relu, int B,
+                                   int H, int W, void* stream) {
+    PUNET_CHECK_ARG(!gate_out || relu, "punet_conv3x3_bf16s: gate_out is the ReLU gate of the output and needs relu != 0");
     PUNET_CHECK_ARG(x0 && wplanes && y, "punet_conv3x3_bf16s: null pointer");
     PUNET_CHECK_ARG(c0 > 0 && c0 % CK == 0 && c1 >= 0 && c1 % CK == 0 && (c1 == 0 || x1),
                     "punet_conv3x3_bf16s: source channels must be multiples of %d (c0=%d c1=%d)", CK, c0, c1);
@@ -1005,7 +1006,7 @@ extern "C" int punet_conv3x3_bf16s(const void* x0, int c0, const void* x1, int c
     a.x0 = (const float*)x0; a.x1 = (const float*)x1; a.c0 = c0; a.c1 = c1;
     a.wp = (const __bf16*)wplanes; a.plane_stride = plane_stride; a.n_row = n_row; a.n_off = n_off;
     a.bias = bias; a.bias_img_stride = 0;
-    a.y = (float*)y; a.n_total = n_out; a.relu = relu; a.pool_out = (float*)pool_out;
+    a.y = (float*)y; a.n_total = n_out; a.relu = relu; a.pool_out = (float*)pool_out; a.gate_out = (unsigned*)gate_out;
     a.B = B; a.H = H; a.W = W;
     a.ntiles = B * ceil_div(H, TH) * ceil_div(W, TW) * ceil_div(n_out, TN);
     const int cap = WG_PER_CU * punet_num_cus();

@@ -70,8 +70,23 @@ __device__ __forceinline__ auto& pick(A& a, B& b) {
     if constexpr (FIRST) return a; else return b;
 }
 
-template <int NBLK, int NMID>
+// F16: a.feat holds bf16 (the "bf16s" fast mode)
+template <int NBLK, int NMID, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
+    // four consecutive channels of one pixel / one channel of one pixel, from either storage
+    auto ldf4 = [&](size_t e) __attribute__((always_inline)) -> float4 {
+        if constexpr (F16) {
+            typedef __bf16 ft_bf16x4 __attribute__((ext_vector_type(4)));
+            const ft_bf16x4 h = *reinterpret_cast<const ft_bf16x4*>(reinterpret_cast<const __bf16*>(a.feat) + e);
+            return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        } else {
+            return *reinterpret_cast<const float4*>(a.feat + e);
+        }
+    };
+    auto ldf1 = [&](size_t e) __attribute__((always_inline)) -> float {
+        if constexpr (F16) return (float)reinterpret_cast<const __bf16*>(a.feat)[e];
+        else return a.feat[e];
+    };
     constexpr int CH = 32 * NBLK;
     constexpr int WP = CH + 1;                       // weight pitch: row-wise AND column-wise b32 reads are conflict-free
     constexpr int TP = (CH % 64 == 0) ? CH + 32 : CH;  // tile pitch: rows 2s and 2s+1 fall into different bank halves
@@ -149,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
         // ---------------- forward: h0 = relu(W1f^T F + zb)
         float4 fr[CH / 8];
 #pragma unroll
-        for (int g = 0; g < CH / 8; ++g) fr[g] = *reinterpret_cast<const float4*>(a.feat + pix * CH + 8 * g + 4 * half);
+        for (int g = 0; g < CH / 8; ++g) fr[g] = ldf4(pix * CH + 8 * g + 4 * half);
         f32x16 h0[NBLK];
 #pragma unroll
         for (int cb = 0; cb < NBLK; ++cb)
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
             float av[NBLK], bv[NBLK];
 #pragma unroll
             for (int i = 0; i < NBLK; ++i) {
-                av[i] = a.feat[((size_t)tile * 32 + 2 * s + half) * CH + i * 32 + l31];
+                av[i] = ldf1(((size_t)tile * 32 + 2 * s + half) * CH + i * 32 + l31);
                 bv[i] = TB[(2 * s + half) * TP + i * 32 + l31];
                 ssum[i] += bv[i];
             }
@@ -327,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     // channels 32 kb + 8 q + 4 half .. + 3 of this pixel, re-read (L1/L2 hit) rather than kept in 32 registers
-                    const float4 f = *reinterpret_cast<const float4*>(a.feat + pix * CH + kb * 32 + 8 * q + 4 * half);
+                    const float4 f = ldf4(pix * CH + kb * 32 + 8 * q + 4 * half);
                     float4 o;
                     o.x = f.x > 0.f ? df[4 * q + 0] : 0.f; o.y = f.y > 0.f ? df[4 * q + 1] : 0.f;
                     o.z = f.z > 0.f ? df[4 * q + 2] : 0.f; o.w = f.w > 0.f ? df[4 * q + 3] : 0.f;
@@ -425,10 +440,29 @@ extern "C" size_t punet_fcomb_train_workspace_floats(int B, int HW, int CH, int 
     return (size_t)grid * slab_floats(CH, nmid) + (size_t)ntiles * CH + (size_t)grid + 4;
 }
 
+static int fcomb_train_impl(bool f16, const float* feat, const float* w1, const float* zb, const float* wmid, const float* bmid,
+                            const float* w3, const float* b3, const float* target, const float* consm, float gscale, float* logits,
+                            float* dfeat, float* loss_sum, float* workspace, int B, int HW, int CH, int nmid, void* stream_);
+
 extern "C" int punet_fcomb_train_fwd_bwd(const float* feat, const float* w1, const float* zb, const float* wmid, const float* bmid,
                                          const float* w3, const float* b3, const float* target, const float* consm, float gscale,
                                          float* logits, float* dfeat, float* loss_sum, float* workspace, int B, int HW, int CH,
                                          int nmid, void* stream_) {
+    return fcomb_train_impl(false, feat, w1, zb, wmid, bmid, w3, b3, target, consm, gscale, logits, dfeat, loss_sum, workspace, B, HW,
+                            CH, nmid, stream_);
+}
+
+extern "C" int punet_fcomb_train_fwd_bwd_bf16s(const void* feat, const float* w1, const float* zb, const float* wmid,
+                                               const float* bmid, const float* w3, const float* b3, const float* target,
+                                               const float* consm, float gscale, float* logits, float* dfeat, float* loss_sum,
+                                               float* workspace, int B, int HW, int CH, int nmid, void* stream_) {
+    return fcomb_train_impl(true, (const float*)feat, w1, zb, wmid, bmid, w3, b3, target, consm, gscale, logits, dfeat, loss_sum,
+                            workspace, B, HW, CH, nmid, stream_);
+}
+
+static int fcomb_train_impl(bool f16, const float* feat, const float* w1, const float* zb, const float* wmid, const float* bmid,
+                            const float* w3, const float* b3, const float* target, const float* consm, float gscale, float* logits,
+                            float* dfeat, float* loss_sum, float* workspace, int B, int HW, int CH, int nmid, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     PUNET_CHECK_ARG(feat && w1 && zb && w3 && b3 && target && logits && dfeat && loss_sum && workspace,
                     "punet_fcomb_train_fwd_bwd: null pointer");
@@ -444,21 +478,27 @@ extern "C" int punet_fcomb_train_fwd_bwd(const float* feat, const float* w1, con
     a.slabs = workspace;
     a.stile = workspace + (size_t)grid * a.slab_stride;
     a.loss_part = a.stile + (size_t)a.ntiles * CH;
-#define PUNET_TRAIN_LAUNCH(NB, NM)                                                                                           \
+#define PUNET_TRAIN_LAUNCH1(NB, NM, F)                                                                                       \
     do {                                                                                                                     \
         const size_t sh = train_smem_bytes<NB, NM>();                                                                        \
-        if (hipFuncSetAttribute((const void*)fcomb_train_kernel<NB, NM>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+        if (hipFuncSetAttribute((const void*)fcomb_train_kernel<NB, NM, F>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                 (int)sh) != hipSuccess) {                                                                    \
             punet_set_error("punet_fcomb_train_fwd_bwd: cannot reserve %zu bytes of LDS", sh);                               \
             return PUNET_ERR_HIP;                                                                                            \
         }                                                                                                                    \
-        fcomb_train_kernel<NB, NM><<<grid, 256, sh, stream>>>(a);                                                            \
+        fcomb_train_kernel<NB, NM, F><<<grid, 256, sh, stream>>>(a);                                                         \
+    } while (0)
+#define PUNET_TRAIN_LAUNCH(NB, NM)                \
+    do {                                          \
+        if (f16) PUNET_TRAIN_LAUNCH1(NB, NM, true); \
+        else PUNET_TRAIN_LAUNCH1(NB, NM, false);  \
     } while (0)
     if (CH == 64 && nmid == 1) PUNET_TRAIN_LAUNCH(2, 1);
     else if (CH == 64) PUNET_TRAIN_LAUNCH(2, 0);
     else if (nmid == 1) PUNET_TRAIN_LAUNCH(1, 1);
     else PUNET_TRAIN_LAUNCH(1, 0);
 #undef PUNET_TRAIN_LAUNCH
+#undef PUNET_TRAIN_LAUNCH1
     PUNET_LAUNCH_CHECK("fcomb_train");
     sum_loss_parts_kernel<<<1, 256, 0, stream>>>(a.loss_part, grid, loss_sum);
     PUNET_LAUNCH_CHECK("sum_loss_parts");

@@ -593,6 +593,55 @@ __global__ void bcast_mean_bwd_kernel(const float4* __restrict__ dmean, const fl
     }
 }
 
+// ReLU gate bits (punet_gate_dwords layout) of a bf16 activation tensor: for producers that do not publish them themselves (the
+// first-layer kernel in the "bf16s" mode).  One thread per dword: pixel x = 32 t + (l & 31), bit 16 nb + 4 rg + e <-> channel
+// 64 cb + 32 nb + 8 rg + 4 (l >> 5) + e.
+__global__ void gate_bits_bf16_kernel(const __bf16* __restrict__ y, unsigned* __restrict__ bits, int B, int H, int W, int C) {
+    const int tiles = (W + 31) >> 5, cbs = (C + 63) >> 6;
+    const size_t n = (size_t)B * H * tiles * cbs * 64;
+    GRID_STRIDE(i, n) {
+        const int l = (int)(i & 63);
+        size_t r = i >> 6;
+        const int cb = (int)(r % cbs); r /= cbs;
+        const int t = (int)(r % tiles); r /= tiles;
+        const int yy = (int)(r % H);
+        const size_t b = r / H;
+        const int x = 32 * t + (l & 31), half = l >> 5;
+        unsigned g = 0u;
+        if (x < W) {
+            const __bf16* p = y + ((b * H + yy) * W + x) * C;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int c = 64 * cb + 32 * nb + 8 * rg + 4 * half;
+                    if (c < C) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g |= ((float)p[c + e] > 0.f ? 1u : 0u) << (16 * nb + 4 * rg + e);
+                    }
+                }
+        }
+        bits[i] = g;
+    }
+}
+
+// the same gated by the encoder output's ReLU gate BITS (punet_gate_dwords layout) instead of its values
+__global__ void bcast_mean_bwd_bits_kernel(const float4* __restrict__ dmean, const unsigned* __restrict__ bits,
+                                           float4* __restrict__ denc, int B, int H, int W, int C4, float inv_p) {
+    const size_t P = (size_t)H * W, n = (size_t)B * P * C4;
+    GRID_STRIDE(i, n) {
+        const int c = (int)(i % C4);
+        const size_t pix = (i / C4) % P, b = i / (P * C4);
+        const int y = (int)(pix / W), x = (int)(pix % W);
+        const float4 g = dmean[b * C4 + c];
+        const unsigned g4 = punet_gate_nibble(bits, b, H, W, 4 * C4, y, x, 4 * c);
+        float4 v;
+        v.x = g4 & 1u ? g.x * inv_p : 0.f; v.y = g4 & 2u ? g.y * inv_p : 0.f;
+        v.z = g4 & 4u ? g.z * inv_p : 0.f; v.w = g4 & 8u ? g.w * inv_p : 0.f;
+        denc[i] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fcomb pieces (probabilistic_unet.py:200-214): the z term of the first 1x1 conv folded into a per-image
 // bias, and the last 1x1 conv C -> 1 with its backward
@@ -1208,6 +1257,28 @@ extern "C" int punet_latent_head_bwd(const float* d_muls, const float* mean, con
     bcast_mean_bwd_kernel<<<ew_grid(n), EW_BLOCK, 0, STREAM>>>((const float4*)dmean, (const float4*)enc, (float4*)denc, B, P,
                                                                C / 4, 1.f / (float)P);
     PUNET_LAUNCH_CHECK("bcast_mean_bwd");
+    return PUNET_OK;
+}
+
+extern "C" int punet_gate_bits_bf16(const void* y, void* bits, int B, int H, int W, int C, void* stream) {
+    PUNET_CHECK_ARG(y && bits && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "punet_gate_bits_bf16: bad args");
+    const size_t n = (size_t)B * H * ((W + 31) / 32) * ((C + 63) / 64) * 64;
+    gate_bits_bf16_kernel<<<ew_grid(n), EW_BLOCK, 0, STREAM>>>((const __bf16*)y, (unsigned*)bits, B, H, W, C);
+    PUNET_LAUNCH_CHECK("gate_bits_bf16");
+    return PUNET_OK;
+}
+
+extern "C" int punet_latent_head_bwd_bits(const float* d_muls, const float* mean, const float* w, const void* enc_bits, float* dw,
+                                          float* db, float* dmean, float* denc, int B, int H, int W, int C, int J, int accumulate,
+                                          void* stream) {
+    PUNET_CHECK_ARG(d_muls && mean && w && enc_bits && dw && db && dmean && denc && C % 4 == 0 && B > 0 && H > 0 && W > 0,
+                    "punet_latent_head_bwd_bits: bad args");
+    latent_head_bwd_kernel<<<16, 256, 0, STREAM>>>(d_muls, mean, w, dw, db, dmean, B, C, J, accumulate);
+    PUNET_LAUNCH_CHECK("latent_head_bwd");
+    const size_t n = (size_t)B * H * W * (C / 4);
+    bcast_mean_bwd_bits_kernel<<<ew_grid(n), EW_BLOCK, 0, STREAM>>>((const float4*)dmean, (const unsigned*)enc_bits, (float4*)denc, B, H,
+                                                                   W, C / 4, 1.f / (float)((size_t)H * W));
+    PUNET_LAUNCH_CHECK("bcast_mean_bwd_bits");
     return PUNET_OK;
 }
 

@@ -384,8 +384,10 @@ __device__ __forceinline__ void tile_mfma_r(f32x16 (&acc)[GTMAX], const char* sX
     }
 }
 
-template <int NP>
+// X16 (one plane only; the "bf16s" fast mode): the activation operand x holds bf16 - its staging is a plain 8-byte copy
+template <int NP, bool X16 = false>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
+    static_assert(!X16 || NP == 1, "bf16 activation storage exists for the one-plane arithmetic only");
     constexpr int C4 = WC / 4;                                   // float4 units per pixel
     constexpr int XNEW = 2 * HTW * C4, DNEW = 2 * WTW * C4;      // units of a tile's two new rows: 1,088 and 1,024
     constexpr int XIT = (XNEW + 511) / 512, DIT = DNEW / 512;    // 3 and 2 staging registers per thread
@@ -435,7 +437,21 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
         const int gx_ = px;  // already offset by the strip
         const int c = ci0 + c4 * 4;
         const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx_, 0), a.W - 1), cc = min(c, a.cs - 4);
-        return *reinterpret_cast<const float4*>(xb + (unsigned)((cy * a.W + cx) * a.cs + cc));
+        if constexpr (X16) {  // four bf16 travel in the first two dwords of the staging register (bit pattern, not values)
+            const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(xb) + (unsigned)((cy * a.W + cx) * a.cs + cc));
+            return make_float4(__builtin_bit_cast(float, h.x), __builtin_bit_cast(float, h.y), 0.f, 0.f);
+        } else {
+            return *reinterpret_cast<const float4*>(xb + (unsigned)((cy * a.W + cx) * a.cs + cc));
+        }
+    };
+    // the X operand's unit -> LDS: split (fp32 storage) or copied as it is (bf16 storage)
+    auto put_x = [&](int off, const float4& r, bool in) __attribute__((always_inline)) {
+        if constexpr (X16) {
+            const uint2 h = in ? make_uint2(__builtin_bit_cast(unsigned, r.x), __builtin_bit_cast(unsigned, r.y)) : make_uint2(0u, 0u);
+            *reinterpret_cast<uint2*>(sX + off) = h;
+        } else {
+            put_planes(sX, XIMGR, off, in ? r : make_float4(0.f, 0.f, 0.f, 0.f));
+        }
     };
     auto load_d = [&](const float* dbp, int gy, int gx_, int c4) __attribute__((always_inline)) -> float4 {
         const int c = co0 + c4 * 4;
@@ -448,7 +464,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
         const int txi = sid % tiles_x, b = sid / tiles_x;
         const int run = min(t_end - t, tiles_y - ty_s);  // tiles of this run: down the strip until its end or the slice's
         const int tx0 = txi * WTW;
-        const float* const xb = a.x + (size_t)b * ((size_t)(a.H * a.W) * a.cs);
+        const float* const xb = X16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.x) + (size_t)b * ((size_t)(a.H * a.W) * a.cs))
+                                    : a.x + (size_t)b * ((size_t)(a.H * a.W) * a.cs);
         const float* const dbp = a.dz + (size_t)b * ((size_t)(a.H * a.W) * a.cout);
 
         // ---- prologue of the run: the first tile's four X rows and two dZ rows in full (slots 0..3 / 0..1)
@@ -458,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
             const int gy = 2 * ty_s - 1 + hr, gx_ = tx0 + px - 1;
             const bool in = gy >= 0 && gy < a.H && gx_ >= 0 && gx_ < a.W && ci0 + c4 * 4 < a.cs;
             const float4 v = load_x(xb, gy, gx_, c4);
-            put_planes(sX, XIMGR, (c4 >> 3) * XIMGR + (hr * HTW + px) * ROWB + (c4 & 7) * 8, in ? v : make_float4(0.f, 0.f, 0.f, 0.f));
+            put_x((c4 >> 3) * XIMGR + (hr * HTW + px) * ROWB + (c4 & 7) * 8, v, in);
         }
         for (int u = tid; u < 2 * WTW * C4; u += 512) {
             const int c4 = u % C4, pix = u / C4, row = pix / WTW, px = pix % WTW;
@@ -509,8 +526,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
             auto commit_x = [&](int it) __attribute__((always_inline)) {
                 const int u = min(tid + it * 512, XNEW - 1);  // a clamped duplicate re-writes the last unit with the same data
                 const int c4 = u % C4, pix = u / C4, nr = pix / HTW, px = pix % HTW;
-                const float4 r = (inmask >> it) & 1u ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);
-                put_planes(sX, XIMGR, (c4 >> 3) * XIMGR + (nr ? nx1 : nx0) + px * ROWB + (c4 & 7) * 8, r);
+                put_x((c4 >> 3) * XIMGR + (nr ? nx1 : nx0) + px * ROWB + (c4 & 7) * 8, rx[it], (inmask >> it) & 1u);
             };
             auto commit_d = [&](int it) __attribute__((always_inline)) {
                 const int u = tid + it * 512;
@@ -581,6 +597,16 @@ constexpr int smem_bytes(int np) {
 #define PUNET_WGRAD_ROLLING 1  // 1: the rolling-row-buffer kernel (round 2), 0: the whole-halo-per-tile kernel of round 1
 #endif
 
+int launch_wgrad_x16(const WgradX6Args& a, dim3 grid, hipStream_t stream) {
+    if (hipFuncSetAttribute((const void*)wgrad3x3_x6r_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes_r(1)) !=
+        hipSuccess) {
+        punet_set_error("punet_conv_wgrad_bf16s: cannot reserve %d bytes of LDS", smem_bytes_r(1));
+        return PUNET_ERR_HIP;
+    }
+    wgrad3x3_x6r_kernel<1, true><<<grid, 512, smem_bytes_r(1), stream>>>(a);
+    return PUNET_OK;
+}
+
 template <int NP>
 int launch_wgrad(const WgradX6Args& a, dim3 grid, hipStream_t stream) {
 #if PUNET_WGRAD_ROLLING
@@ -611,9 +637,28 @@ extern "C" int punet_wgrad_x6_slices(int cs, int cout, int B, int H, int W) {
     return ns < 1 ? 1 : ns;
 }
 
+static int wgrad_x6_impl(bool x16, const float* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off,
+                         float* dbias, float* workspace, int nslices, int B, int H, int W, int accumulate, float scale, int opts,
+                         void* stream_);
+
 extern "C" int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off,
                                    float* dbias, float* workspace, int nslices, int B, int H, int W, int accumulate,
                                    float scale, int opts, void* stream_) {
+    return wgrad_x6_impl(false, x, cs, dz, cout, dw, cin_total, ci_off, dbias, workspace, nslices, B, H, W, accumulate, scale, opts,
+                         stream_);
+}
+
+// the same in the one-plane arithmetic with the activation operand x stored as bf16 (the "bf16s" fast mode); dz stays fp32
+extern "C" int punet_conv_wgrad_bf16s(const void* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off,
+                                      float* dbias, float* workspace, int nslices, int B, int H, int W, int accumulate, float scale,
+                                      void* stream_) {
+    return wgrad_x6_impl(true, (const float*)x, cs, dz, cout, dw, cin_total, ci_off, dbias, workspace, nslices, B, H, W, accumulate,
+                         scale, PUNET_X6_OPTS(1, 16), stream_);
+}
+
+static int wgrad_x6_impl(bool x16, const float* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off,
+                         float* dbias, float* workspace, int nslices, int B, int H, int W, int accumulate, float scale, int opts,
+                         void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int planes = punet_x6_planes_of(opts);
     PUNET_CHECK_ARG(planes > 0, "punet_conv_wgrad_x6: bad options word 0x%x", opts);
@@ -630,7 +675,8 @@ extern "C" int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int 
     a.bias_partial = dbias ? workspace + (size_t)nslices * 9 * cs * cout : nullptr;
     a.B = B; a.H = H; a.W = W; a.nslices = nslices;
     dim3 grid(nslices, ceil_div(cs, WC) * ceil_div(cout, WC));
-    const int rc0 = planes == 3 ? launch_wgrad<3>(a, grid, stream)
+    const int rc0 = x16 ? launch_wgrad_x16(a, grid, stream)
+                    : planes == 3 ? launch_wgrad<3>(a, grid, stream)
                     : planes == 2 ? launch_wgrad<2>(a, grid, stream) : launch_wgrad<1>(a, grid, stream);
     if (rc0 != PUNET_OK) return rc0;
     PUNET_LAUNCH_CHECK("wgrad3x3_x6");

@@ -298,22 +298,29 @@ class PUNetEngine:
         B, H, W = x0.B, x0.H, x0.W
         cin = x0.C + (x1.C if x1 is not None else 0)
         assert cin == c.cin, (name, cin, c.cin)
-        if self._infer16 and c.k == 3:  # bf16 activation storage (no tape, no gate bits: nothing is differentiated here)
-            assert tape is None and not tape_bits
+        if self._infer16 and c.k == 3:  # bf16 activation storage ("bf16s"): the gradients, if any follow, stay fp32
             y = Act(torch.empty(B, H, W, c.cout, dtype=torch.bfloat16, device=self.device), B, H, W, c.cout, relu_out=relu)
             if cin <= 4:
                 _lib.call("punet_conv3x3_small_fwd_bf16s", x0.ptr, cin, self._wptr(flat, c), self._bptr(flat, c), y.ptr, c.cout, B, H,
                           W, int(relu), _stream())
+                if relu and tape is not None:  # the first-layer kernel publishes no gate bits: one small pass makes them
+                    y.bits = torch.empty(_lib.call("punet_gate_dwords", B, H, W, c.cout), dtype=torch.int32, device=self.device)
+                    _lib.call("punet_gate_bits_bf16", y.ptr, y.bits.data_ptr(), B, H, W, c.cout, _stream())
             else:
                 q = None
                 if pooled is not None and H % 2 == 0 and W % 2 == 0:
                     q = Act(torch.empty(B, H // 2, W // 2, c.cout, dtype=torch.bfloat16, device=self.device), B, H // 2, W // 2, c.cout)
                     pooled.append(q)
+                if relu and (tape is not None or tape_bits):
+                    y.bits = torch.empty(_lib.call("punet_gate_dwords", B, H, W, c.cout), dtype=torch.int32, device=self.device)
                 planes = self._x6[(flat.data_ptr(), 0)]
                 self._timed("conv3x3_fwd", 2.0 * B * H * W * cin * c.cout * 9, "punet_conv3x3_bf16s", x0.ptr, x0.C,
                             x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0, planes.data_ptr() + 2 * 3 * c.w_off,
-                            c.w_numel, c.cout, 0, self._bptr(flat, c), y.ptr, c.cout, q.ptr if q is not None else None, int(relu),
-                            B, H, W, _stream())
+                            c.w_numel, c.cout, 0, self._bptr(flat, c), y.ptr, c.cout,
+                            y.bits.data_ptr() if y.bits is not None else None, q.ptr if q is not None else None, int(relu), B, H, W,
+                            _stream())
+            if tape is not None:
+                tape.append(("conv", c, x0, x1, y))
             if taps is not None:
                 taps["conv:" + name] = y
             return y
@@ -368,6 +375,8 @@ class PUNetEngine:
         if x.t.dtype == torch.bfloat16:
             y = Act(torch.empty(x.B, 2 * x.H, 2 * x.W, x.C, dtype=torch.bfloat16, device=self.device), x.B, 2 * x.H, 2 * x.W, x.C)
             _lib.call("punet_upsample2x_fwd_bf16s", x.ptr, y.ptr, x.B, x.H, x.W, x.C, _stream())
+            if tape is not None:
+                tape.append(("up", x, y))
             return y
         y = Act(self._empty(x.B, 2 * x.H, 2 * x.W, x.C), x.B, 2 * x.H, 2 * x.W, x.C)
         _lib.call("punet_upsample2x_fwd", x.ptr, y.ptr, x.B, x.H, x.W, x.C, _stream())
@@ -532,9 +541,13 @@ class PUNetEngine:
         tq = [] if record else None
         tp = [] if record else None
         tu = [] if record else None
-        muls_q, mean_q, enc_q = self.latent(flat, "posterior", xq, tq, taps)
-        muls_p, mean_p, enc_p = self.latent(flat, "prior", xin, tp, taps)
-        feat = self.unet(flat, xin, tu, taps)
+        self._infer16 = self.act16 and record  # "bf16s": the student pass stores its activations as bf16 too (gradients fp32)
+        try:
+            muls_q, mean_q, enc_q = self.latent(flat, "posterior", xq, tq, taps)
+            muls_p, mean_p, enc_p = self.latent(flat, "prior", xin, tp, taps)
+            feat = self.unet(flat, xin, tu, taps)
+        finally:
+            self._infer16 = False
         st.update(muls_q=muls_q, muls_p=muls_p, mean_q=mean_q, mean_p=mean_p, enc_q=enc_q, enc_p=enc_p, feat=feat,
                   tapes=(tq, tp, tu))
         return st
@@ -572,7 +585,8 @@ class PUNetEngine:
             cm_ = L.convs[L.fcomb_mid[0]] if nmid else None
             ws = self._empty(_lib.call("punet_fcomb_train_workspace_floats", B, H * W, CH, nmid))
             logits, dfeat, rec = self._empty(B, 1, H, W), self._empty(B, H, W, CH), self._empty(1)
-            self._timed("fcomb_train", 2.0 * 3 * B * H * W * CH * (CH * (1 + nmid) + 1), "punet_fcomb_train_fwd_bwd", feat.ptr,
+            self._timed("fcomb_train", 2.0 * 3 * B * H * W * CH * (CH * (1 + nmid) + 1),
+                        "punet_fcomb_train_fwd_bwd_bf16s" if feat.t.dtype == torch.bfloat16 else "punet_fcomb_train_fwd_bwd", feat.ptr,
                         self._wptr(flat, c1), zb.data_ptr(), self._wptr(flat, cm_) if nmid else None,
                         self._bptr(flat, cm_) if nmid else None, self._wptr(flat, c3), self._bptr(flat, c3), y_tgt.data_ptr(),
                         consm.data_ptr() if consm is not None else None, float(gscale), logits.data_ptr(), dfeat.data_ptr(),
@@ -581,6 +595,11 @@ class PUNetEngine:
                       loss_kind=loss_kind, kl_sampled=not analytic_kl, z_is_mean=bool(posterior_mean), recorded=record,
                       fused_fcomb=ws, dfeat=dfeat)
             return st
+        if feat.t.dtype == torch.bfloat16:  # "bf16s" outside the fused kernel's domain: the per-op kernels read fp32
+            f32 = Act(feat.t.float(), B, H, W, CH, relu_out=True)
+            f32.bits = feat.bits
+            st["feat_f32"] = f32
+            feat = f32
         # Fcomb, single sample, activations materialised for the backward
         h = Act(self._empty(B, H, W, CH), B, H, W, CH, relu_out=True)
         p1 = self._x6_1x1.get((flat.data_ptr(), 0), {}).get(c1.name) if self.x6 else None
@@ -637,6 +656,11 @@ class PUNetEngine:
         x6 = self.x6 and c.k == 3
         ns = _lib.call("punet_wgrad_x6_slices" if x6 else "punet_wgrad_slices", x.C, c.cout, B, H, W)
         ws = self.ws.get("wgrad", _lib.call("punet_wgrad_workspace_floats", x.C, c.cout, c.k, ns))
+        if x6 and x.t.dtype == torch.bfloat16:
+            self._timed("conv3x3_wgrad", 2.0 * B * H * W * x.C * c.cout * 9, "punet_conv_wgrad_bf16s", x.ptr, x.C, dz.data_ptr(),
+                        c.cout, dw, c.cin, ci_off, db if with_bias else None, ws.data_ptr(), ns, B, H, W, int(accumulate), 1.0,
+                        _stream())
+            return
         if x6:
             self._timed("conv3x3_wgrad", 2.0 * B * H * W * x.C * c.cout * 9, "punet_conv_wgrad_x6", x.ptr, x.C, dz.data_ptr(),
                         c.cout, dw, c.cin, ci_off, db if with_bias else None, ws.data_ptr(), ns, B, H, W, int(accumulate), 1.0,
@@ -736,7 +760,7 @@ class PUNetEngine:
         """(buffer, accumulate flag) for the gradient of activation a."""
         g = gm.get(id(a))
         if g is None:
-            g = torch.empty_like(a.t)
+            g = torch.empty(a.t.shape, dtype=torch.float32, device=self.device)  # gradients are fp32 whatever the storage of a
             gm[id(a)] = g
             return g, 0
         return g, 1
@@ -821,6 +845,7 @@ class PUNetEngine:
         c1, c3 = L.convs["fcomb.layers.0"], L.convs["fcomb.last_layer"]
         hs: List[Act] = st["hs"]
         feat: Act = st["feat"]
+        fread: Act = st.get("feat_f32", feat)  # what the per-op kernels read (an fp32 copy when the features are stored as bf16)
         # last layer C -> 1
         dz_h = torch.empty_like(hs[-1].t)
         ws = self.ws.get("dot", _lib.call("punet_dot_bwd_workspace_floats", CH))
@@ -835,7 +860,7 @@ class PUNetEngine:
             self._dgrad(flat, c, dz_h, 0, xin.C, dprev, xin.ptr, 0, B, H, W, bits=xin.bits)
             dz_h = dprev
         # first layer: feature rows by wgrad (+ bias), z rows and dz from the per-image column sums
-        self._wgrad(gflat, c1, feat, 0, dz_h, True, accumulate)
+        self._wgrad(gflat, c1, fread, 0, dz_h, True, accumulate)
         S = self._empty(B, CH)
         wsc = self.ws.get("chan", _lib.call("punet_chan_sum_workspace_floats", B, H * W, CH))
         _lib.call("punet_chan_sum", dz_h.data_ptr(), S.data_ptr(), wsc.data_ptr(), B, H * W, CH, 1.0, _stream())
@@ -844,7 +869,7 @@ class PUNetEngine:
                   dz.data_ptr(), B, Ld, CH, acc, _stream())
         gm_u = {}
         dfeat, _ = self._grad_into(gm_u, feat)
-        self._dgrad(flat, c1, dz_h, 0, CH, dfeat, feat.ptr, 0, B, H, W, bits=feat.bits)
+        self._dgrad(flat, c1, dz_h, 0, CH, dfeat, fread.ptr, 0, B, H, W, bits=feat.bits)
         return dz, gm_u
 
     def _latent_backward(self, flat, gflat, st, dz, accumulate):
@@ -867,9 +892,14 @@ class PUNetEngine:
             gm = {}
             denc, _ = self._grad_into(gm, enc)
             dmean = self._empty(B, enc.C)
-            _lib.call("punet_latent_head_bwd", d.data_ptr(), mean.data_ptr(), self._wptr(flat, c), enc.ptr,
-                      gflat.data_ptr() + 4 * c.w_off, gflat.data_ptr() + 4 * c.b_off, dmean.data_ptr(), denc.data_ptr(), B,
-                      enc.H * enc.W, enc.C, c.cout, acc, _stream())
+            if enc.t.dtype == torch.bfloat16:
+                _lib.call("punet_latent_head_bwd_bits", d.data_ptr(), mean.data_ptr(), self._wptr(flat, c), enc.bits.data_ptr(),
+                          gflat.data_ptr() + 4 * c.w_off, gflat.data_ptr() + 4 * c.b_off, dmean.data_ptr(), denc.data_ptr(), B, enc.H,
+                          enc.W, enc.C, c.cout, acc, _stream())
+            else:
+                _lib.call("punet_latent_head_bwd", d.data_ptr(), mean.data_ptr(), self._wptr(flat, c), enc.ptr,
+                          gflat.data_ptr() + 4 * c.w_off, gflat.data_ptr() + 4 * c.b_off, dmean.data_ptr(), denc.data_ptr(), B,
+                          enc.H * enc.W, enc.C, c.cout, acc, _stream())
             self._backward_tape(flat, gflat, tape, gm, accumulate)
 
     # ---------------------------------------------------------------- regulariser / optimiser

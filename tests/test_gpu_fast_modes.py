@@ -198,6 +198,28 @@ def test_bf16_storage_mode_runs_on_bf16_tensors_and_stays_close_to_bf16_arithmet
     print(f"\nlogits max abs err vs x6: bf16 {e_bf16:.3e}, bf16s {e_s:.3e}")
     assert 1e-4 < e_s < 3.0 * e_bf16 + 1e-2
     assert not torch.equal(outs["bf16s"][0], outs["bf16"][0])
+    # training: the student pass stores bf16 activations too (fp32 gradients); its gradients must stay within the one-plane
+    # arithmetic's error of the fp32-storage bf16 mode - fused Fcomb kernel and per-op Fcomb path (Dice) alike
+    grads = {}
+    for mode in ("bf16", "bf16s"):
+        for loss_kind in ("bce", "dice"):
+            m = ProbabilisticUnet(1, 1, nf, 6, 3, 1.0, consensus_masking=True, device=dev, seed=1, conv_mode=mode)
+            eng = m.engine
+            consm = (torch.rand(2, 1, 64, 96, generator=torch.Generator().manual_seed(3)) > 0.3).float().to(dev)
+            st = eng.elbo_forward(m.flat_params, eng.to_nhwc(x2), y, consm, eps[0], loss_kind, 1.0, 1.0, True)
+            if mode == "bf16s":
+                assert st["feat"].t.dtype == torch.bfloat16 and st["enc_q"].t.dtype == torch.bfloat16
+                assert (st.get("fused_fcomb") is not None) == (loss_kind == "bce")
+            g = torch.zeros_like(m.flat_params)
+            eng.elbo_backward(m.flat_params, g, st, False)
+            torch.cuda.synchronize()
+            grads[(mode, loss_kind)] = (g.clone(), st["rec"].item())
+    for loss_kind in ("bce", "dice"):
+        (ga, ra), (gb, rb) = grads[("bf16", loss_kind)], grads[("bf16s", loss_kind)]
+        assert torch.isfinite(gb).all() and abs(ra - rb) <= 2e-2 * abs(ra) + 1e-3, (loss_kind, ra, rb)
+        rel = (ga - gb).norm().item() / ga.norm().item()
+        print(f"{loss_kind}: relative gradient difference bf16s vs bf16 {rel:.3e}")
+        assert 1e-6 < rel < 0.1, (loss_kind, rel)
     m = ProbabilisticUnet(1, 1, nf, 6, 3, 1.0, consensus_masking=True, device=dev, seed=1, conv_mode="bf16s")
     t = copy.deepcopy(m)
     assert t.engine.conv_mode == "bf16s"
