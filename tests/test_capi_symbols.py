@@ -50,3 +50,18 @@ def test_layout_matches_reference_state_dict():
         spec = O.param_spec(c, 1, nf, 6, 3)
         assert [(n, s) for n, _, _, s in lay.entries] == [(n, tuple(s)) for n, s in spec.items()]
     assert ParamLayout(1, 1, [64, 128, 256, 512]).n_params == 27349593
+
+
+def test_package_exports_cover_the_reference_packages():
+    """Every name the reference's hot-path packages export (prob_utils/my_models/__init__.py:1-2, my_trainer/__init__.py:1-6,
+    my_predictions/__init__.py:2, my_utils/util.py) that is in scope imports from this package under the same name."""
+    import importlib
+    want = {"my_models": ["ProbabilisticUnet", "l2_regularisation", "clean_folder"],
+            "my_trainer": ["MeanTeacherTrainer", "MeanTeacherLogger", "AdaMatchLogger", "AdaMatchTrainer", "AdaMTTrainer", "AdaMTLogger",
+                           "FixMatchLogger", "FixMatchTrainer", "PUNetLogger", "PUNetTrainer", "PseudoLogger", "PseudoTrainerPUNet"],
+            "my_predictions": ["punet_prediction", "punet_pseudo_prediction"],
+            "my_utils": ["dice_score", "my_standardize_torch", "DummyLoss"]}
+    for mod, names in want.items():
+        m = importlib.import_module("probabilistic_domain_adaptation_amd." + mod)
+        for n in names:
+            assert hasattr(m, n), (mod, n)
