@@ -530,7 +530,6 @@ class PUNetEngine:
     def train_forward(self, flat, x_nhwc, segm, record=True, taps=None):
         """forward(patch, segm, training=True) (probabilistic_unet.py:285-293): posterior on [patch, segm], prior and U-Net
         features.  segm: [B,1,H,W] float.  With record the tapes for elbo_backward are kept."""
-        L = self.L
         B, H, W, C = x_nhwc.shape
         st = {"B": B, "H": H, "W": W, "recorded": bool(record)}
         self.prepare_forward_weights(flat)
@@ -809,7 +808,6 @@ class PUNetEngine:
         B, H, W = st["B"], st["H"], st["W"]
         Ld, CH = L.latent_dim, L.nf[0]
         acc = int(accumulate)
-        P = B * H * W
         self.prepare_dgrad_weights(flat)
         c1, c3 = L.convs["fcomb.layers.0"], L.convs["fcomb.last_layer"]
         feat: Act = st["feat"]
@@ -828,8 +826,7 @@ class PUNetEngine:
             gm_u = {id(feat): st["dfeat"]}
         else:
             dz, gm_u = self._fcomb_backward_ops(flat, gflat, st, accumulate)
-        tq, tp, tu = st["tapes"]
-        self._backward_tape(flat, gflat, tu, gm_u, accumulate)
+        self._backward_tape(flat, gflat, st["tapes"][2], gm_u, accumulate)
         if after_unet is not None:
             after_unet()
         self._latent_backward(flat, gflat, st, dz, accumulate)
@@ -878,7 +875,7 @@ class PUNetEngine:
         B = st["B"]
         Ld = L.latent_dim
         acc = int(accumulate)
-        tq, tp, tu = st["tapes"]
+        tq, tp = st["tapes"][0], st["tapes"][1]
         # latent heads: KL + reparameterisation
         dq = self._empty(B, 2 * Ld)
         dp = self._empty(B, 2 * Ld)
