@@ -533,16 +533,19 @@ def punet_validate(P: Params, cfg: PUNetConfig, batches, eps_elbo, eps_samples, 
 
 
 def mean_teacher_validate(P_s: Params, P_t: Params, cfg: PUNetConfig, batches, eps_teacher, eps_elbo, eps_model,
-                          masking: bool, reg_weight: float = 1e-5):
+                          masking: bool, reg_weight: float = 1e-5, use_consensus: bool = True):
     """MeanTeacherTrainer._validate_impl (mean_teacher_trainer.py:142-191) -> dict(metric, loss, gt_metric, samples, y, z)
     (samples / y / z of the last batch): teacher pseudo-labels on x1 (:153), no-grad student loss on x2 with elbo(y, z)
-    (:157-161), sample_from_model (:163, :90-93), 1 - dice vs the pseudo-label (:164-166) and vs the true gt (:168-170)."""
+    (:157-161), sample_from_model (:163, :90-93), 1 - dice vs the pseudo-label (:164-166) and vs the true gt (:168-170).
+    The same body serves FixMatchTrainer (fixmatch_trainer.py:111-160; P_t = P_s), AdaMTTrainer (adamt_trainer.py:139-189)
+    and AdaMatchTrainer (adamatch_trainer.py:118-168), whose elbo(y) drops the consensus until training has switched
+    `consensus_masking_is_activated` on (:138) - `use_consensus=False`."""
     metric = loss_val = gt_metric = 0.0
     out = {}
     with torch.no_grad():
         for (x, x1, x2, gt), et, e1, em in zip(batches, eps_teacher, eps_elbo, eps_model):
             y, z = sample_consensus(P_t, cfg, x1, et, masking=masking)
-            loss, aux = training_loss(P_s, cfg, x2, y, z, e1, reg_weight)
+            loss, aux = training_loss(P_s, cfg, x2, y, z if use_consensus else None, e1, reg_weight)
             st = aux["state"]
             samples = torch.stack([torch.sigmoid(punet_sample(P_s, cfg, st, em[i])) for i in range(em.shape[0])], 0).sum(0) / em.shape[0]
             pred = samples.numpy().squeeze()

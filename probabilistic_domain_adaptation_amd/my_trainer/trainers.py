@@ -177,6 +177,9 @@ class _SelfTrainingBase(_PUNetTrainerBase):
         y, _ = self.model.sample_consensus(self.n_samples, eps=self._eps("val", self.n_samples, self.model._state["x"].shape[0]))
         return y
 
+    def _validation_uses_consensus(self):
+        return True
+
     def _validate_impl(self, forward_context):
         self.model.eval()
         metric_val = loss_val = dice_metric = gt_metric_val = 0.0
@@ -185,7 +188,7 @@ class _SelfTrainingBase(_PUNetTrainerBase):
                 x1, x2 = x1.to(self.device), x2.to(self.device)
                 y, z = self._pseudo_labels(x1)
                 with forward_context():
-                    loss = self._dropin_loss(x2, y, z, "student")
+                    loss = self._dropin_loss(x2, y, z if self._validation_uses_consensus() else None, "student")
                     samples = self.sample_from_model()
                     d, dg = self._validation_metric(samples, y, gt_)
                 dice_metric += d
@@ -417,6 +420,10 @@ class AdaMTTrainer(_JointBase):
     def _momentum_update(self):
         FU.ema_update(self.model, self.teacher, self._ema_momentum())
 
+    def _validate_impl(self, forward_context):
+        self.target_val_loader = self.val_loader  # adamt_trainer.py:148
+        return super()._validate_impl(forward_context)
+
     def save_checkpoint(self, name, current_metric, best_metric, train_time=0.0, **extra):
         super().save_checkpoint(name, current_metric, best_metric, train_time=train_time,
                                 teacher_state=self.teacher.state_dict(), **extra)
@@ -444,3 +451,10 @@ class AdaMatchTrainer(_JointBase):
                 self.consensus_masking_is_activated = True
             return True
         return False
+
+    def _validation_uses_consensus(self):
+        return self.consensus_masking_is_activated  # adamatch_trainer.py:138: elbo(y, z) only once training switched it on
+
+    def _validate_impl(self, forward_context):
+        self.target_val_loader = self.val_loader  # adamatch_trainer.py:127
+        return super()._validate_impl(forward_context)

@@ -553,6 +553,68 @@ def gen_api_case(name, nf, B, H, W, n_samples, seeds=(13, 14, 15)):
     print(f"[gen_golden] wrote {name}.npz ({os.path.getsize(os.path.join(HERE, name + '.npz')) / 1e6:.2f} MB)")
 
 
+def gen_validate_case(name, nf, B, H, W, n_samples, seeds=(23, 24, 25)):
+    """`_validate_impl` of the three remaining self-training trainers, run through the reference's own methods over two
+    batches: FixMatchTrainer (fixmatch_trainer.py:111-160), AdaMTTrainer (adamt_trainer.py:139-189) and AdaMatchTrainer
+    (adamatch_trainer.py:118-168) before and after `consensus_masking_is_activated` flips (:138)."""
+    out = {}
+    C, L = 1, 6
+    cfg = O.PUNetConfig(C, 1, nf, L, 3, 1.0, consensus_masking=True, rl_swap=False)
+    x, x1, x2, gt = O.synth_batch(B, C, H, W, seeds[0])
+    xb, x1b, x2b, gtb = O.synth_batch(B, C, H, W, seeds[0] + 1)
+    out["meta"] = np.array([B, C, H, W, seeds[0], seeds[1], seeds[2], n_samples] + list(nf), dtype=np.int64)
+    m, Pnp = make_ref_model(cfg, seeds[1], True)
+    Po = O.to_torch(Pnp)
+    Pt_np = O.synth_params(cfg.spec(), seeds[1] + 1)
+    mbatches = [(x, x1, x2, gt), (xb, x1b, x2b, gtb)]
+
+    def E(n, k):
+        return eps_draws(n, B, L, seeds[2] + k)
+
+    def run(tr, tag, masking, teacher, use_z):
+        tr.n_samples = n_samples
+        tr.logger = _CaptureLogger()
+        for i in range(2):
+            for e in E(n_samples, 40 + i):
+                EPS.push(e)
+            EPS.push(E(1, 50 + i)[0])
+            for e in E(n_samples, 60 + i):
+                EPS.push(e)
+        for e in E(n_samples, 70):  # the logger branch samples once more
+            EPS.push(e)
+        metric = tr._validate_impl(contextlib.nullcontext)
+        (a, k), = tr.logger.calls
+        assert a[1] == metric and not EPS.q
+        out[f"{tag}_val"] = np.array([metric, a[2], k["gt_metric"]], dtype=np.float64)
+        out[f"{tag}_y"] = a[6].detach().numpy().copy()
+        out[f"{tag}_z"] = a[7].detach().numpy().copy()
+        r = O.mean_teacher_validate(Po, O.to_torch(Pt_np) if teacher else Po, cfg, mbatches,
+                                    [E(n_samples, 40 + i) for i in range(2)], [E(1, 50 + i)[0] for i in range(2)],
+                                    [E(n_samples, 60 + i) for i in range(2)], masking, use_consensus=use_z)
+        assert abs(r["metric"] - metric) < 1e-6 and abs(r["gt_metric"] - k["gt_metric"]) < 1e-6, (tag, r["metric"], metric)
+        assert abs(r["loss"] - a[2]) <= 1e-5 * abs(a[2]), (tag, r["loss"], a[2])
+        assert (r["z"].numpy() == a[7].numpy()).all()
+
+    for masking in (True, False):
+        mk = "mask" if masking else "weight"
+        tr = mt.FixMatchTrainer(name="g", train_loader=[], val_loader=mbatches, model=m, optimizer=None, device="cpu",
+                                do_consensus_masking=masking)
+        run(tr, f"fixmatch_{mk}", masking, False, True)
+        tr = mt.AdaMTTrainer(source_train_loader=[], target_train_loader=[0], name="g", val_loader=mbatches, model=m,
+                             optimizer=None, device="cpu", do_consensus_masking=masking)
+        tr.teacher.load_state_dict({k: torch.from_numpy(v) for k, v in Pt_np.items()})
+        run(tr, f"adamt_{mk}", masking, True, True)
+        assert tr.target_val_loader is tr.val_loader
+        tr = mt.AdaMatchTrainer(source_train_loader=[], target_train_loader=[0], name="g", val_loader=mbatches, model=m,
+                                optimizer=None, device="cpu", do_consensus_masking=masking)
+        run(tr, f"adamatch_off_{mk}", masking, False, False)
+        tr.consensus_masking_is_activated = True
+        run(tr, f"adamatch_on_{mk}", masking, False, True)
+    assert abs(out["adamatch_off_mask_val"][1] - out["adamatch_on_mask_val"][1]) > 1e-3 * abs(out["adamatch_on_mask_val"][1])
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(f"[gen_golden] wrote {name}.npz ({os.path.getsize(os.path.join(HERE, name + '.npz')) / 1e6:.2f} MB)")
+
+
 def gen_plain_unet_case(name, nf, H, W, seed=1):
     """BASELINE.json configs[0]: plain Unet forward (prob_utils/my_models/unet.py, apply_last_layer=True) on one
     synthetic patch, CPU reference."""
@@ -581,6 +643,9 @@ if __name__ == "__main__":
     if "--only-api" in sys.argv:
         gen_api_case("api_small", [32, 64, 64, 96], B=2, H=32, W=32, n_samples=4)
         sys.exit(0)
+    if "--only-validate" in sys.argv:
+        gen_validate_case("validate_small", [32, 64, 64, 96], B=2, H=32, W=32, n_samples=4)
+        sys.exit(0)
     if "--only-unet" in sys.argv:
         gen_plain_unet_case("plain_unet_256", [64, 128, 256, 512], 256, 256)
         sys.exit(0)
@@ -600,5 +665,7 @@ if __name__ == "__main__":
     gen_trainer_case("trainers_small", [32, 64, 64, 96], B=2, H=32, W=32, n_samples=4)
     # (5b) model-API corners, validation loops, prediction bodies
     gen_api_case("api_small", [32, 64, 64, 96], B=2, H=32, W=32, n_samples=4)
+    # (5c) validation loops of FixMatch / AdaMT / AdaMatch
+    gen_validate_case("validate_small", [32, 64, 64, 96], B=2, H=32, W=32, n_samples=4)
     # (6) BASELINE.json configs[0]: plain Unet forward, one 256x256x1 patch
     gen_plain_unet_case("plain_unet_256", [64, 128, 256, 512], 256, 256)

@@ -215,3 +215,24 @@ def test_api_corners_validation_and_prediction(golden_dir):
     bh, bw, hh, hw, ns, nt = [int(v) for v in fx["tiled_geo"]]
     tiled = O.tiled_prediction(P, cfg, fx["img_b"], [g1(ns, s2 + 100 + t) for t in range(nt)], (bh, bw), (hh, hw))
     np.testing.assert_allclose(tiled, fx["tiled_pred"], atol=1e-6)
+
+
+def test_validation_loops_of_fixmatch_adamt_adamatch(golden_dir):
+    """validate_small.npz (gen_golden.py::gen_validate_case): `_validate_impl` of FixMatchTrainer, AdaMTTrainer and
+    AdaMatchTrainer (before / after consensus_masking_is_activated) as the reference's own code ran them."""
+    fx = _load(golden_dir, "validate_small")
+    B, C, H, W, s0, s1, s2, n = [int(v) for v in fx["meta"][:8]]
+    nf = [int(v) for v in fx["meta"][8:]]
+    cfg = O.PUNetConfig(C, 1, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    P = O.to_torch(O.synth_params(cfg.spec(), s1))
+    Pt = O.to_torch(O.synth_params(cfg.spec(), s1 + 1))
+    E = lambda k, m: _eps(k, B, 6, s2 + m)
+    batches = [O.synth_batch(B, C, H, W, s0), O.synth_batch(B, C, H, W, s0 + 1)]
+    for masking, mk in ((True, "mask"), (False, "weight")):
+        for which, teacher, use_z in (("fixmatch", P, True), ("adamt", Pt, True), ("adamatch_off", P, False),
+                                      ("adamatch_on", P, True)):
+            r = O.mean_teacher_validate(P, teacher, cfg, batches, [E(n, 40), E(n, 41)], [E(1, 50)[0], E(1, 51)[0]],
+                                        [E(n, 60), E(n, 61)], masking, use_consensus=use_z)
+            np.testing.assert_allclose([r["metric"], r["loss"], r["gt_metric"]], fx[f"{which}_{mk}_val"], rtol=1e-5)
+            assert (r["z"].numpy() == fx[f"{which}_{mk}_z"]).all()
+            np.testing.assert_allclose(r["y"].numpy(), fx[f"{which}_{mk}_y"], atol=1e-6)
