@@ -71,9 +71,17 @@ def test_smallest_and_ragged_shapes_match_oracle(model, B, H, W, n):
     assert (ym.cpu() - probs.mean(0)).abs().max() < 1e-4
 
 
-def test_filters_that_are_multiples_of_8_not_32():
-    """num_filters = [32, 40, 72, 104]: widths that are multiples of 8 but not of 32 go through the 32x32x16 kernels (the
-    16x16x32 kernel needs a multiple of 32) - whole training path (logits, loss scalars, all gradients) against the oracle."""
+@pytest.mark.parametrize("nf,H,W,latent,nfc,C", [
+    ([32, 40, 72, 104], 40, 56, 6, 3, 1),      # multiples of 8, not of 32: the 32x32x16 kernels
+    ([32, 64, 128, 192], 32, 32, 6, 4, 1),     # the reference's constructor defaults (probabilistic_unet.py:227-237)
+    ([32, 64, 96], 24, 40, 2, 3, 1),           # three levels, the original paper's latent_dim 2
+    ([32, 32, 64, 64, 96], 48, 80, 6, 2, 3),   # five levels, the shortest Fcomb, RGB input
+], ids=["nf8", "ctor_defaults", "depth3_latent2", "depth5_fcomb2_rgb"])
+def test_constructor_space_against_oracle(nf, H, W, latent, nfc, C):
+    """The constructor's argument space beyond the scripts' one setting - widths that are multiples of 8 but not of 32 (they
+    go through the 32x32x16 kernels; the 16x16x32 kernel needs a multiple of 32), the reference's default arguments, other
+    depths, latent sizes, Fcomb lengths and input channels: whole training path (logits, loss scalars, all gradients)
+    against the oracle."""
     import numpy as np
     import torch
     from oracle import punet_oracle as O
@@ -81,16 +89,16 @@ def test_filters_that_are_multiples_of_8_not_32():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     dev = torch.device("cuda:0")
-    nf, B, H, W = [32, 40, 72, 104], 2, 40, 56
-    cfg = O.PUNetConfig(1, 1, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    B = 2
+    cfg = O.PUNetConfig(C, 1, nf, latent, nfc, 1.0, consensus_masking=True, rl_swap=False)
     Pnp = O.synth_params(cfg.spec(), 6)
-    lay = ParamLayout(1, 1, nf, 6, 3)
+    lay = ParamLayout(C, 1, nf, latent, nfc)
     eng = PUNetEngine(lay, dev)
     flat = torch.zeros(lay.numel, device=dev)
     for k, v in lay.views(flat).items():
         v.copy_(torch.from_numpy(Pnp[k]))
-    x, x1, x2, y = O.synth_batch(B, 1, H, W, 8)
-    eps = torch.randn(1, 6, generator=torch.Generator().manual_seed(9)).expand(B, 6).contiguous()
+    x, x1, x2, y = O.synth_batch(B, C, H, W, 8)
+    eps = torch.randn(1, latent, generator=torch.Generator().manual_seed(9)).expand(B, latent).contiguous()
     consm = (torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(3)) > 0.3).float()
     taps = {}
     st = eng.elbo_forward(flat, eng.to_nhwc(x2.to(dev)), y.to(dev), consm.to(dev), eps.to(dev), "bce", 1.0, 1.0, True, taps)
@@ -111,6 +119,21 @@ def test_filters_that_are_multiples_of_8_not_32():
     for k, ref in go.items():
         e = (gv[k].cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-8)
         assert e < 5e-4, (k, e)
+    # the inference path of the same configuration: N = 3 prior samples, logits + consensus mask
+    n = 3
+    epn = torch.randn(n, B, latent, generator=torch.Generator().manual_seed(11))
+    Pd = O.to_torch(Pnp)
+    with torch.no_grad():
+        so = O.punet_forward(Pd, cfg, x1, None, False)
+        ref_lg = torch.stack([O.punet_sample(Pd, cfg, so, epn[i]) for i in range(n)])
+        out = eng.forward_features(flat, eng.to_nhwc(x1.to(dev)))
+        ym, cz, lg = eng.sample(flat, out["features"], eng.reparam(out["prior_muls"], epn.to(dev)), 0.9, 0.1, True, want_logits=True)
+    torch.cuda.synchronize()
+    assert (lg.cpu() - ref_lg).abs().max().item() < 1e-3
+    probs = torch.sigmoid(ref_lg)
+    ref_mask = (((probs >= 0.9) | (probs <= 0.1)).float().sum(0) == n).float()
+    safe = ((probs - 0.9).abs().min(0).values > 1e-5) & ((probs - 0.1).abs().min(0).values > 1e-5)
+    assert torch.equal(cz.cpu()[safe], ref_mask[safe])
 
 
 def test_init_families_match_the_reference(model):
