@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     static_assert(OPERANDS * 16 <= 65536, "static LDS limit");
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it stays in SGPRs
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
 
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int ntn = (a.n_total + TN - 1) / TN;
@@ -517,6 +518,12 @@ __host__ __device__ constexpr int x6b_slot(int ph, int t) {
     return ph == 0 ? t : ph == 1 ? (t < 8 ? t : 9) : ph == 2 ? (t < 7 ? t : t == 7 ? 8 : 10) : (t < 6 ? t : 2 * t - 5);
 }
 
+#ifndef X6B_TIMING  // timing-only builds (WRONG results; tools/ab_variants.sh + tools/ab_layers_detail.sh): 1 = no output
+#define X6B_TIMING 0  // stores, 2 = no activation loads (synthetic values), 4 = no epilogue, 8 = loads from a cache-resident window
+#endif
+#ifndef X6B_VECTOR_WAVE  // 1 = the wave index as a VGPR value (the form before round 2's scalar wave index), for A/B runs
+#define X6B_VECTOR_WAVE 0
+#endif
 template <int NP, bool DGRAD>
 __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     constexpr int KS = 3, KK = 9, PAD = 1;
@@ -538,7 +545,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     uint4* sW = smem + 2 * XBUF;
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, l16 = lane & 15, g = lane >> 4;
+    // the wave index as a SCALAR: everything the weight DMA derives from it (plane, tap, slot, row address) then lives in
+    // SGPRs and SALU instructions instead of ~30 loop-invariant VGPRs and 64-bit VALU multiplies per row
+#if X6B_VECTOR_WAVE
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int lane = tid & 63, l16 = lane & 15, g = lane >> 4;
 
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int ntn = (a.n_total + TN - 1) / TN;
@@ -546,14 +560,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     const int K = a.c0 + a.c1;
     const int nchunks = K / CK;  // a multiple of 4 (host check)
 
+    // block-uniform; the divisions run on the vector ALU (no scalar divide), readfirstlane brings the results back to SGPRs
+    // so that everything derived from them (image bases, weight rows) is scalar arithmetic again
     auto decode = [&](int tile) {
         TileInfo t;
-        t.n0 = (tile % ntn) * TN;
+        int n0 = (tile % ntn) * TN;
         int sid = tile / ntn;
-        t.tx0 = (sid % tiles_x) * TW;
+        int tx0 = (sid % tiles_x) * TW;
         sid /= tiles_x;
-        t.ty0 = (sid % tiles_y) * TH;
-        t.b = sid / tiles_y;
+        int ty0 = (sid % tiles_y) * TH;
+        int b = sid / tiles_y;
+#if !X6B_VECTOR_WAVE
+        n0 = __builtin_amdgcn_readfirstlane(n0); tx0 = __builtin_amdgcn_readfirstlane(tx0);
+        ty0 = __builtin_amdgcn_readfirstlane(ty0); b = __builtin_amdgcn_readfirstlane(b);
+#endif
+        t.n0 = n0; t.tx0 = tx0; t.ty0 = ty0; t.b = b;
         return t;
     };
 
@@ -571,7 +592,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     // kept 7 x 16 bytes + 7 offsets per thread across the K-steps, which is what the fragments of this kernel need).
     float4 rx[XITER];
     int xpix[XITER];
-    int xb = 0;  // image of the tile the staging registers are being loaded for (block-uniform)
+    const float* xbase0 = a.x0;  // image of the tile the staging registers are being loaded for, per source (block-uniform)
+    const float* xbase1 = a.x1;
     bool xin[XITER];
     unsigned wlane = 0;  // this lane's output-channel offset (elements) inside a weight row
     auto retarget = [&](const TileInfo& ti) __attribute__((always_inline)) {
@@ -584,14 +606,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
             xin[it] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             xpix[it] = min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1);  // inside image xb (32-bit); the image
         }                                                                          // base is a uniform 64-bit term
-        xb = ti.b;
+        xbase0 = a.x0 + (size_t)ti.b * ((size_t)(a.H * a.W) * a.c0);
+        xbase1 = a.x1 + (size_t)ti.b * ((size_t)(a.H * a.W) * a.c1);
         wlane = (unsigned)((a.n_off + min(ti.n0 + lane, N - 1)) * 8);  // columns beyond N copy column N - 1 (never stored)
     };
     auto load_x = [&](int ch, int it) __attribute__((always_inline)) -> float4 {
         const int kbase = ch * CK;
         const int cs = kbase < a.c0 ? a.c0 : a.c1, coff = kbase < a.c0 ? kbase : kbase - a.c0;
-        const float* src = (kbase < a.c0 ? a.x0 : a.x1) + (size_t)xb * ((size_t)(a.H * a.W) * cs);  // uniform image base
+        const float* src = kbase < a.c0 ? xbase0 : xbase1;  // uniform image base (SGPR pair) + 32-bit lane offset
         const int q = min(tid + it * 256, XUNITS - 1) % (CK / 4);
+#if X6B_TIMING & 2
+        return make_float4((float)(xpix[it] & 7), 1.f, (float)q, (float)(coff & 3));
+#endif
+#if X6B_TIMING & 8
+        return *reinterpret_cast<const float4*>(src + (unsigned)((xpix[it] & 1023) * cs + coff + q * 4));
+#endif
         return *reinterpret_cast<const float4*>(src + (unsigned)(xpix[it] * cs + coff + q * 4));
     };
     auto prefetch = [&](int ch) __attribute__((always_inline)) {
@@ -699,6 +728,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     };
     auto epilogue = [&](const TileInfo& ti) __attribute__((always_inline)) {
         const int cq = ti.n0 + 4 * g;  // + 16 cb: first of this lane's four consecutive channels
+#if X6B_TIMING & 4
+        if (acc[0][0][0] != 1.2345e-30f) return;
+#endif
         // uniform 64-bit base of image ti.b in the output-shaped tensors; offsets inside the image stay 32-bit
         const size_t img = (size_t)ti.b * ((size_t)(a.H * a.W) * N);
         float* const yb = a.y + img;
@@ -748,6 +780,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
                     }
                     if (ok) {
                         if (DGRAD && a.accumulate) v += *reinterpret_cast<const f32x4*>(yb + pbase + 16 * cb);
+#if X6B_TIMING & 1
+                        if (v[0] == 1.2345e-30f)
+#endif
                         *reinterpret_cast<f32x4*>(yb + pbase + 16 * cb) = v;
                         if (!DGRAD) gout |= nibble(v) << sh;
                     }

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void fcomb_sampler_kernel(SamplerArgs a) {
     for (int i = tid; i < CH; i += 256) sW3[i] = a.w3[i];
     __syncthreads();
 
-    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it stays in SGPRs
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const float b3 = a.b3[0];
     const size_t P = (size_t)a.B * a.HW;
 
@@ -222,7 +223,8 @@ __global__ __launch_bounds__(256, PUNET_K7X_WGS) void fcomb_sampler_x6_kernel(Sa
     for (int i = tid; i < CH; i += 256) sW3[i] = a.w3[i];
     __syncthreads();
 
-    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it stays in SGPRs
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const float b3 = a.b3[0];
     const size_t P = (size_t)a.B * a.HW;
     auto afrag = [&](int layer, int j, int ob, bf16x8s (&wa)[3]) __attribute__((always_inline)) {

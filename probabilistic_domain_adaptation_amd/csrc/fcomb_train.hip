@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
     for (int i = tid; i < CH; i += 256) sW3[i] = a.w3[i];
     __syncthreads();
 
-    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it stays in SGPRs
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     float* TA = sT + wave * 2 * TILE;
     float* TB = TA + TILE;
     const float b3 = a.b3[0];

@@ -151,7 +151,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
     float* sBias = reinterpret_cast<float*>(smem);  // reused after the last tile
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it stays in SGPRs
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int pair = wave & 3, group = wave >> 2;
     const int cib = pair >> 1, cob = pair & 1;
 
@@ -398,7 +399,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
     float* sBias = reinterpret_cast<float*>(smem);  // reused after the last tile
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it stays in SGPRs
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int pair = wave & 3, group = wave >> 2;
     const int cib = pair >> 1, cob = pair & 1;
     const int co_tiles = (a.cout + WC - 1) / WC;
