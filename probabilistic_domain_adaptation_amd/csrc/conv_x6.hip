@@ -552,6 +552,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 #else
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
+    __builtin_assume(wave >= 0 && wave < 4);
     const int lane = tid & 63, l16 = lane & 15, g = lane >> 4;
 
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
@@ -676,15 +677,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         for (int it = 0; it < XITER; ++it) rx[it] = load_x(nch, it);
     };
 
-    // One K-step: lane group g contracts block g = {image buffer, tap, weight slot} (compile-time per group).
-    auto kstep = [&](auto b0, auto b1, auto b2, auto b3, auto&& mid) __attribute__((always_inline)) {
-        constexpr int P1 = NP > 1 ? 1 : 0, P2 = NP > 2 ? 2 : 0;
-        // block code = buffer * 4096 + tap * 16 + slot
-        constexpr int c0 = decltype(b0)::value, c1 = decltype(b1)::value, c2 = decltype(b2)::value, c3 = decltype(b3)::value;
+    // One K-step: lane group g contracts block g = {image buffer, tap, weight slot} (compile-time per group).  The nine
+    // K-steps of a 4-chunk cycle have fixed blocks, so the per-lane LDS offsets of all of them are computed ONCE (18 VGPRs):
+    // selected per K-step they were two 4-way selects on the lane group = ~50 instructions of exec-masked control flow
+    // between every operand barrier and the first fragment read behind it.
+    // block code = buffer * 4096 + tap * 16 + slot;  O(ph, t) = this chunk's tap t, P(ph, t) = the previous chunk's tap t
+#define X6B_O(ph, t) (((ph) & 1) * 4096 + (t) * 16 + x6b_slot(ph, t))
+#define X6B_P(ph, t) ((((ph) - 1) & 1) * 4096 + (t) * 16 + x6b_slot((ph) - 1, t))
+    // lane-group pairs (0, 1) and (2, 3) take taps of one column (t, t + 3, t + 6 are 48 pixels apart) wherever the
+    // 9-tap arithmetic allows: 15 of the 18 pairs per 4 chunks; the other 3 cost their reads a second LDS cycle
+    constexpr int KCODE[9][4] = {
+        {X6B_O(0, 0), X6B_O(0, 3), X6B_O(0, 1), X6B_O(0, 4)}, {X6B_O(0, 2), X6B_O(0, 5), X6B_O(0, 6), X6B_O(0, 7)},
+        {X6B_P(1, 8), X6B_O(1, 2), X6B_O(1, 0), X6B_O(1, 3)}, {X6B_O(1, 1), X6B_O(1, 4), X6B_O(1, 5), X6B_O(1, 6)},
+        {X6B_P(2, 7), X6B_O(2, 1), X6B_P(2, 8), X6B_O(2, 2)}, {X6B_O(2, 0), X6B_O(2, 3), X6B_O(2, 4), X6B_O(2, 5)},
+        {X6B_P(3, 6), X6B_O(3, 0), X6B_P(3, 7), X6B_O(3, 1)}, {X6B_P(3, 8), X6B_O(3, 2), X6B_O(3, 3), X6B_O(3, 6)},
+        {X6B_O(3, 4), X6B_O(3, 7), X6B_O(3, 5), X6B_O(3, 8)}};
+#undef X6B_O
+#undef X6B_P
+    int koffA[9], koffB[9];
+#pragma unroll
+    for (int ki = 0; ki < 9; ++ki) {
         auto offA_of = [](int c) { return (c >> 12) * XBUF + (((c >> 4) & 15) / KS) * HTWP + ((c >> 4) & 15) % KS; };
         auto offB_of = [](int c) { return (c & 15) * TN; };
-        const int offA = (g == 0 ? offA_of(c0) : g == 1 ? offA_of(c1) : g == 2 ? offA_of(c2) : offA_of(c3)) + l16;
-        const int offB = (g == 0 ? offB_of(c0) : g == 1 ? offB_of(c1) : g == 2 ? offB_of(c2) : offB_of(c3)) + l16;
+        const int c0 = KCODE[ki][0], c1 = KCODE[ki][1], c2 = KCODE[ki][2], c3 = KCODE[ki][3];
+        koffA[ki] = (g == 0 ? offA_of(c0) : g == 1 ? offA_of(c1) : g == 2 ? offA_of(c2) : offA_of(c3)) + l16;
+        koffB[ki] = (g == 0 ? offB_of(c0) : g == 1 ? offB_of(c1) : g == 2 ? offB_of(c2) : offB_of(c3)) + l16;
+        asm volatile("" : "+v"(koffA[ki]), "+v"(koffB[ki]));  // keep them resident: do not re-derive them inside the loop
+    }
+    auto kstep = [&](auto ki_c, auto&& mid) __attribute__((always_inline)) {
+        constexpr int P1 = NP > 1 ? 1 : 0, P2 = NP > 2 ? 2 : 0;
+        const int offA = koffA[decltype(ki_c)::value], offB = koffB[decltype(ki_c)::value];
         // all four channel blocks' weight fragments resident (48 registers), pixel fragments streamed with one block of
         // lookahead (12 + 12): every fragment is read once per K-step (24 reads per 96 MFMAs, as in the 32 x 32 x 16 kernel)
         U4 bw[NP][4];
@@ -822,9 +844,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 #pragma unroll
     for (int it = 0; it < XITER; ++it) split_unit(it);
 
-    // block codes: buffer * 4096 + tap * 16 + slot;  O(ph, t) = this chunk's tap t, P(ph, t) = the previous chunk's tap t
-#define X6B_O(ph, t) std::integral_constant<int, ((ph) & 1) * 4096 + (t) * 16 + x6b_slot(ph, t)>{}
-#define X6B_P(ph, t) std::integral_constant<int, (((ph) - 1) & 1) * 4096 + (t) * 16 + x6b_slot((ph) - 1, t)>{}
     auto phase = [&](auto ph_c) __attribute__((always_inline)) -> bool {
         constexpr int ph = decltype(ph_c)::value;
         int nch = ch + 1, ntile = tile;
@@ -845,28 +864,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         // a __syncthreads() here would drain them too (its fence waits vmcnt(0) while an LDS-DMA is pending)
         __builtin_amdgcn_s_waitcnt(XITER | (7 << 4) | (0 << 8));  // vmcnt(XITER) expcnt(7) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
-        // lane-group pairs (0, 1) and (2, 3) take taps of one column (t, t + 3, t + 6 are 48 pixels apart) wherever the
-        // 9-tap arithmetic allows: 15 of the 18 pairs per 4 chunks; the other 3 cost their reads a second LDS cycle
         auto s0 = [&]() __attribute__((always_inline)) { split_unit(0); };
         auto s1 = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int it = 1; it < XITER; ++it) split_unit(it);
         };
         auto s_ = []() {};
+#define X6B_K(i) std::integral_constant<int, i>{}
         if (ph == 0) {
-            kstep(X6B_O(0, 0), X6B_O(0, 3), X6B_O(0, 1), X6B_O(0, 4), s0);
-            kstep(X6B_O(0, 2), X6B_O(0, 5), X6B_O(0, 6), X6B_O(0, 7), s1);
+            kstep(X6B_K(0), s0);
+            kstep(X6B_K(1), s1);
         } else if (ph == 1) {
-            kstep(X6B_P(1, 8), X6B_O(1, 2), X6B_O(1, 0), X6B_O(1, 3), s0);
-            kstep(X6B_O(1, 1), X6B_O(1, 4), X6B_O(1, 5), X6B_O(1, 6), s1);
+            kstep(X6B_K(2), s0);
+            kstep(X6B_K(3), s1);
         } else if (ph == 2) {
-            kstep(X6B_P(2, 7), X6B_O(2, 1), X6B_P(2, 8), X6B_O(2, 2), s0);
-            kstep(X6B_O(2, 0), X6B_O(2, 3), X6B_O(2, 4), X6B_O(2, 5), s1);
+            kstep(X6B_K(4), s0);
+            kstep(X6B_K(5), s1);
         } else {
-            kstep(X6B_P(3, 6), X6B_O(3, 0), X6B_P(3, 7), X6B_O(3, 1), s0);
-            kstep(X6B_P(3, 8), X6B_O(3, 2), X6B_O(3, 3), X6B_O(3, 6), s1);
-            kstep(X6B_O(3, 4), X6B_O(3, 7), X6B_O(3, 5), X6B_O(3, 8), s_);
+            kstep(X6B_K(6), s0);
+            kstep(X6B_K(7), s1);
+            kstep(X6B_K(8), s_);
         }
+#undef X6B_K
         if (ph == 3 && ch == nchunks - 1) {  // no barrier: the epilogue touches no LDS, waves drain into it as they finish
             epilogue(ti);
             zero_acc();
@@ -876,8 +895,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         ti = nti;
         return !has_next;
     };
-#undef X6B_O
-#undef X6B_P
     while (true) {
         if (phase(std::integral_constant<int, 0>{})) break;
         if (phase(std::integral_constant<int, 1>{})) break;
