@@ -521,6 +521,9 @@ __host__ __device__ constexpr int x6b_slot(int ph, int t) {
 #ifndef X6B_TIMING  // timing-only builds (WRONG results; tools/ab_variants.sh + tools/ab_layers_detail.sh): 1 = no output
 #define X6B_TIMING 0  // stores, 2 = no activation loads (synthetic values), 4 = no epilogue, 8 = loads from a cache-resident window
 #endif
+#ifndef X6B_GENERAL_EPILOGUE  // 1 = only the general epilogue (every flag tested at run time, per store), for A/B runs
+#define X6B_GENERAL_EPILOGUE 0
+#endif
 #ifndef X6B_VECTOR_WAVE  // 1 = the wave index as a VGPR value (the form before round 2's scalar wave index), for A/B runs
 #define X6B_VECTOR_WAVE 0
 #endif
@@ -748,7 +751,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     auto nibble = [](const f32x4& v) -> unsigned {
         return (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
     };
-    auto epilogue = [&](const TileInfo& ti) __attribute__((always_inline)) {
+    // EC = compile-time knowledge about this tile's epilogue (block-uniform, decided once per tile in `epilogue`):
+    //   bit 0  F: the tile lies fully inside the image and the channel block inside N, and the layer has the usual form
+    //             (forward: bias + ReLU; input gradient: gated by bits) - no per-store predicates, no per-store flag tests
+    //   bit 1  G: forward writes the gate bits            bit 2  P: forward writes the pooled output / input gradient accumulates
+    // EC = 0 is the general path with every flag tested at run time.  The general path alone cost the 8-chunk tiles of the
+    // 64-channel layers 12 % of their time: ~1100 instructions, three branches per store.
+    auto epilogue_ec = [&](const TileInfo& ti, auto ec_c) __attribute__((always_inline)) {
+        constexpr int EC = decltype(ec_c)::value;
+        constexpr bool F = EC & 1, G = EC & 2, P = EC & 4;
+        const bool f_relu = F ? true : a.relu != 0, f_bias = F ? true : a.bias != nullptr;
+        const bool f_gate_out = F ? G : a.gate_out != nullptr, f_pool = F ? P : a.pool_out != nullptr;
+        const bool f_gate_bits = F ? true : a.gate_bits != nullptr, f_acc = F ? P : a.accumulate != 0;
         const int cq = ti.n0 + 4 * g;  // + 16 cb: first of this lane's four consecutive channels
 #if X6B_TIMING & 4
         if (acc[0][0][0] != 1.2345e-30f) return;
@@ -762,7 +776,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 bq[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (a.bias && cq + 16 * cb < N)
+                if (f_bias && (F || cq + 16 * cb < N))
                     bq[cb] = *reinterpret_cast<const f32x4*>(a.bias + (size_t)ti.b * a.bias_img_stride + cq + 16 * cb);
             }
         }
@@ -775,25 +789,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int gy = ti.ty0 + 2 * wave + m;
-                const bool pix_in = gy < a.H && gx < a.W;
+                const bool pix_in = F || (gy < a.H && gx < a.W);
                 // dword of (pixel, channel) in the punet_gate_dwords layout: (x % 32) + 32 * ((c % 8) / 4) = 16 h + l16 + 32 (g & 1)
                 const unsigned gd = (unsigned)(((((ti.b * a.H + gy) * tiles_x + (ti.tx0 / TW)) * ntn + (ti.n0 / TN)) << 6) +
                                                16 * h + l16 + 32 * (g & 1));
                 const unsigned pbase = (unsigned)((gy * a.W + gx) * N + cq);
                 unsigned gin = 0u, gout = 0u;
-                if (DGRAD && a.gate_bits && pix_in) gin = a.gate_bits[gd];
+                if (DGRAD && f_gate_bits && pix_in) gin = a.gate_bits[gd];
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
-                    const bool ok = pix_in && cq + 16 * cb < N;
+                    const bool ok = F || (pix_in && cq + 16 * cb < N);
                     const int sh = 16 * (cb >> 1) + 8 * (cb & 1) + 4 * (g >> 1);  // this quad's nibble in its dword
                     f32x4 v = acc[2 * m + h][cb];
                     if (!DGRAD) {
                         v += bq[cb];
-                        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                    } else if (a.gate_bits) {
+                        if (f_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    } else if (f_gate_bits) {
                         const unsigned g4 = gin >> sh;
                         v[0] = g4 & 1u ? v[0] : 0.f; v[1] = g4 & 2u ? v[1] : 0.f; v[2] = g4 & 4u ? v[2] : 0.f; v[3] = g4 & 8u ? v[3] : 0.f;
-                    } else if (a.mask) {
+                    } else if (!F && a.mask) {
                         if (ok) {
                             const f32x4 gm = *reinterpret_cast<const f32x4*>(mb + pbase + 16 * cb);
                             v[0] = gm[0] > 0.f ? v[0] : 0.f; v[1] = gm[1] > 0.f ? v[1] : 0.f;
@@ -801,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
                         }
                     }
                     if (ok) {
-                        if (DGRAD && a.accumulate) v += *reinterpret_cast<const f32x4*>(yb + pbase + 16 * cb);
+                        if (DGRAD && f_acc) v += *reinterpret_cast<const f32x4*>(yb + pbase + 16 * cb);
 #if X6B_TIMING & 1
                         if (v[0] == 1.2345e-30f)
 #endif
@@ -809,15 +823,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
                         if (!DGRAD) gout |= nibble(v) << sh;
                     }
                 }
-                if (!DGRAD && a.gate_out) {  // uniform; the other half of the dword's bits sits in lane ^ 32
+                if (!DGRAD && f_gate_out) {  // uniform; the other half of the dword's bits sits in lane ^ 32
                     const auto sw = __builtin_amdgcn_permlane32_swap(gout, gout, false, false);
                     const unsigned full = sw[0] | sw[1];  // {own, partner} in either order
                     if (g < 2 && pix_in) a.gate_out[gd] = full;
                 }
             }
-            if (!DGRAD && a.pool_out) {  // uniform: AvgPool2d(2, 2) of the output, order ((y00 + y01) + y10) + y11
+            if (!DGRAD && f_pool) {  // uniform: AvgPool2d(2, 2) of the output, order ((y00 + y01) + y10) + y11
                 const int gy0 = ti.ty0 + 2 * wave;
-                const bool ok0 = gy0 < a.H && gx < a.W;
+                const bool ok0 = F || (gy0 < a.H && gx < a.W);
                 const unsigned qbase = (unsigned)(((gy0 >> 1) * (a.W >> 1) + (gx >> 1)) * N + cq);
                 float* const qb = a.pool_out + (img >> 2);  // the pooled image has a quarter of the pixels
 #pragma unroll
@@ -825,14 +839,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
                     f32x4 v0 = acc[h][cb] + bq[cb], v1 = acc[2 + h][cb] + bq[cb], q;  // recomputed: no live copies of the rows
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (a.relu) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                        if (f_relu) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
                         q[e] = (((v0[e] + partner(v0[e])) + v1[e]) + partner(v1[e])) * 0.25f;
                     }
-                    if (!(lane & 1) && ok0 && cq + 16 * cb < N) *reinterpret_cast<f32x4*>(qb + qbase + 16 * cb) = q;
+                    if (!(lane & 1) && ok0 && (F || cq + 16 * cb < N)) *reinterpret_cast<f32x4*>(qb + qbase + 16 * cb) = q;
                 }
             }
         }
     };
+#define X6B_EC(v) std::integral_constant<int, v>{}
+    auto epilogue = [&](const TileInfo& ti) __attribute__((always_inline)) {
+#if X6B_GENERAL_EPILOGUE
+        epilogue_ec(ti, X6B_EC(0));
+#else
+        const bool full = ti.ty0 + TH <= a.H && ti.tx0 + TW <= a.W && ti.n0 + TN <= N;  // block-uniform
+        if (!DGRAD) {
+            if (full && a.relu && a.bias && !a.mask) {
+                if (a.gate_out) {
+                    if (a.pool_out) epilogue_ec(ti, X6B_EC(7)); else epilogue_ec(ti, X6B_EC(3));
+                } else {
+                    if (a.pool_out) epilogue_ec(ti, X6B_EC(5)); else epilogue_ec(ti, X6B_EC(1));
+                }
+            } else {
+                epilogue_ec(ti, X6B_EC(0));
+            }
+        } else {
+            if (full && a.gate_bits) {
+                if (a.accumulate) epilogue_ec(ti, X6B_EC(5)); else epilogue_ec(ti, X6B_EC(1));
+            } else {
+                epilogue_ec(ti, X6B_EC(0));
+            }
+        }
+#endif
+    };
+#undef X6B_EC
 
     int tile = blockIdx.x;
     if (a.xcd_remap) tile = (tile & 7) * ((int)gridDim.x >> 3) + (tile >> 3);
