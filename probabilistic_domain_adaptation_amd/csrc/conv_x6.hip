@@ -751,6 +751,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     auto nibble = [](const f32x4& v) -> unsigned {
         return (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
     };
+    // What the epilogue needs from memory is fetched at the head of the tile's LAST chunk (behind its operand barrier), a
+    // whole chunk of MFMAs ahead of its use: the gate dwords of the input gradient (4 per lane) / the bias quads of the
+    // forward (4 x 16 bytes).  Loaded inside the epilogue each of them was a memory round trip in front of the first store.
+    unsigned gpre[4] = {0u, 0u, 0u, 0u};
+    f32x4 bpre[4];
+    auto epilogue_prefetch = [&](const TileInfo& ti) __attribute__((always_inline)) {
+        if (DGRAD) {
+            if (a.gate_bits) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const int gx = ti.tx0 + 16 * h + l16, gy = ti.ty0 + 2 * wave + m;
+                        const unsigned gd = (unsigned)(((((ti.b * a.H + gy) * tiles_x + (ti.tx0 / TW)) * ntn + (ti.n0 / TN)) << 6) +
+                                                       16 * h + l16 + 32 * (g & 1));
+                        gpre[2 * h + m] = (gy < a.H && gx < a.W) ? a.gate_bits[gd] : 0u;
+                    }
+            }
+        } else {
+            const int cq = ti.n0 + 4 * g;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                bpre[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.bias && cq + 16 * cb < N)
+                    bpre[cb] = *reinterpret_cast<const f32x4*>(a.bias + (size_t)ti.b * a.bias_img_stride + cq + 16 * cb);
+            }
+        }
+    };
     // EC = compile-time knowledge about this tile's epilogue (block-uniform, decided once per tile in `epilogue`):
     //   bit 0  F: the tile lies fully inside the image and the channel block inside N, and the layer has the usual form
     //             (forward: bias + ReLU; input gradient: gated by bits) - no per-store predicates, no per-store flag tests
@@ -760,7 +788,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     auto epilogue_ec = [&](const TileInfo& ti, auto ec_c) __attribute__((always_inline)) {
         constexpr int EC = decltype(ec_c)::value;
         constexpr bool F = EC & 1, G = EC & 2, P = EC & 4;
-        const bool f_relu = F ? true : a.relu != 0, f_bias = F ? true : a.bias != nullptr;
+        const bool f_relu = F ? true : a.relu != 0;
         const bool f_gate_out = F ? G : a.gate_out != nullptr, f_pool = F ? P : a.pool_out != nullptr;
         const bool f_gate_bits = F ? true : a.gate_bits != nullptr, f_acc = F ? P : a.accumulate != 0;
         const int cq = ti.n0 + 4 * g;  // + 16 cb: first of this lane's four consecutive channels
@@ -774,11 +802,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         f32x4 bq[4];
         if (!DGRAD) {
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                bq[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (f_bias && (F || cq + 16 * cb < N))
-                    bq[cb] = *reinterpret_cast<const f32x4*>(a.bias + (size_t)ti.b * a.bias_img_stride + cq + 16 * cb);
-            }
+            for (int cb = 0; cb < 4; ++cb) bq[cb] = bpre[cb];  // epilogue_prefetch
         }
         auto partner = [](float v) __attribute__((always_inline)) {  // value of lane ^ 1 (quad_perm [1, 0, 3, 2])
             return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
@@ -795,7 +819,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
                                                16 * h + l16 + 32 * (g & 1));
                 const unsigned pbase = (unsigned)((gy * a.W + gx) * N + cq);
                 unsigned gin = 0u, gout = 0u;
-                if (DGRAD && f_gate_bits && pix_in) gin = a.gate_bits[gd];
+                if (DGRAD && f_gate_bits) gin = gpre[2 * h + m];  // epilogue_prefetch (0 outside the image)
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
                     const bool ok = F || (pix_in && cq + 16 * cb < N);
@@ -904,6 +928,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         // a __syncthreads() here would drain them too (its fence waits vmcnt(0) while an LDS-DMA is pending)
         __builtin_amdgcn_s_waitcnt(XITER | (7 << 4) | (0 << 8));  // vmcnt(XITER) expcnt(7) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
+        if (ph == 3 && ch == nchunks - 1) epilogue_prefetch(ti);  // block-uniform
         auto s0 = [&]() __attribute__((always_inline)) { split_unit(0); };
         auto s1 = [&]() __attribute__((always_inline)) {
 #pragma unroll
