@@ -56,7 +56,10 @@ struct ConvX6Args {
     int accumulate, relu;
     int B, H, W, ntiles;
     int xcd_remap;
-};
+    unsigned m_ntn, m_tx, m_ty;  // floor(2^32 / d) + 1 for d = channel blocks, tiles per row, tile rows: n / d = mulhi(n, m)
+};                               // exactly while n * d < 2^32 (host check) - the tile decode without a division
+
+static inline unsigned x6_magic(int d) { return (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
 
 struct TileInfo {
     int b, ty0, tx0, n0;
@@ -564,21 +567,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     const int K = a.c0 + a.c1;
     const int nchunks = K / CK;  // a multiple of 4 (host check)
 
-    // block-uniform; the divisions run on the vector ALU (no scalar divide), readfirstlane brings the results back to SGPRs
-    // so that everything derived from them (image bases, weight rows) is scalar arithmetic again
+    // block-uniform and scalar: tile -> (channel block, tile column, tile row, image) by multiplications with the host's
+    // reciprocals (s_mul_hi_u32) - integer division has no scalar instruction and compiles to ~30 vector instructions each
     auto decode = [&](int tile) {
         TileInfo t;
-        int n0 = (tile % ntn) * TN;
+#if X6B_VECTOR_WAVE
+        t.n0 = (tile % ntn) * TN;
         int sid = tile / ntn;
-        int tx0 = (sid % tiles_x) * TW;
+        t.tx0 = (sid % tiles_x) * TW;
         sid /= tiles_x;
-        int ty0 = (sid % tiles_y) * TH;
-        int b = sid / tiles_y;
-#if !X6B_VECTOR_WAVE
-        n0 = __builtin_amdgcn_readfirstlane(n0); tx0 = __builtin_amdgcn_readfirstlane(tx0);
-        ty0 = __builtin_amdgcn_readfirstlane(ty0); b = __builtin_amdgcn_readfirstlane(b);
+        t.ty0 = (sid % tiles_y) * TH;
+        t.b = sid / tiles_y;
+#else
+        const unsigned ut = (unsigned)__builtin_amdgcn_readfirstlane(tile);
+        const unsigned s1 = ntn == 1 ? ut : __umulhi(ut, a.m_ntn);  // (the reciprocal of 1 does not fit 32 bits)
+        const unsigned s2 = tiles_x == 1 ? s1 : __umulhi(s1, a.m_tx);
+        const unsigned s3 = tiles_y == 1 ? s2 : __umulhi(s2, a.m_ty);
+        t.n0 = (int)(ut - s1 * (unsigned)ntn) * TN;
+        t.tx0 = (int)(s1 - s2 * (unsigned)tiles_x) * TW;
+        t.ty0 = (int)(s2 - s3 * (unsigned)tiles_y) * TH;
+        t.b = (int)s3;
 #endif
-        t.n0 = n0; t.tx0 = tx0; t.ty0 = ty0; t.b = b;
         return t;
     };
 
@@ -1126,6 +1135,7 @@ extern "C" int punet_conv3x3_bf16s(const void* x0, int c0, const void* x1, int c
     a.y = (float*)y; a.n_total = n_out; a.relu = relu; a.pool_out = (float*)pool_out; a.gate_out = (unsigned*)gate_out;
     a.B = B; a.H = H; a.W = W;
     a.ntiles = B * ceil_div(H, TH) * ceil_div(W, TW) * ceil_div(n_out, TN);
+    a.m_ntn = x6_magic(ceil_div(n_out, TN)); a.m_tx = x6_magic(ceil_div(W, TW)); a.m_ty = x6_magic(ceil_div(H, TH));
     const int cap = WG_PER_CU * punet_num_cus();
     const int grid = a.ntiles < cap ? a.ntiles : cap;
     a.xcd_remap = grid % 8 == 0;
@@ -1155,6 +1165,11 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
                         "punet_conv3x3_x6: one image is too large for 32-bit offsets (%llu pixels x %d channels)", px, cmax);
         PUNET_CHECK_ARG((unsigned long long)B * H * ceil_div(W, TW) * ceil_div(n_out, TN) * 64ull < (1ull << 32) &&
                         (unsigned long long)B * px < (1ull << 31), "punet_conv3x3_x6: too many pixels for the tile / gate indices");
+        // the tile decode divides by multiplication with 32-bit reciprocals: exact while tile index x divisor < 2^32
+        const unsigned long long nt = (unsigned long long)B * ceil_div(H, TH) * ceil_div(W, TW) * ceil_div(n_out, TN);
+        const int dmax = ceil_div(H, TH) > ceil_div(W, TW) ? ceil_div(H, TH) : ceil_div(W, TW);
+        PUNET_CHECK_ARG(nt * (unsigned long long)(dmax > ceil_div(n_out, TN) ? dmax : ceil_div(n_out, TN)) < (1ull << 32),
+                        "punet_conv3x3_x6: too many tiles for the reciprocal tile decode");
     }
     ConvX6Args a{};
     a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1;
@@ -1166,6 +1181,7 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
     a.gate_bits = (const unsigned*)gate_bits; a.gate_out = (unsigned*)gate_out; a.pool_out = pool_out;
     a.B = B; a.H = H; a.W = W;
     a.ntiles = B * ceil_div(H, TH) * ceil_div(W, TW) * ceil_div(n_out, TN);
+    a.m_ntn = x6_magic(ceil_div(n_out, TN)); a.m_tx = x6_magic(ceil_div(W, TW)); a.m_ty = x6_magic(ceil_div(H, TH));
     const int cap = WG_PER_CU * punet_num_cus();
     const int grid = a.ntiles < cap ? a.ntiles : cap;
     // the input-gradient epilogue whenever one of its features is asked for; bias / ReLU / gate_out belong to the forward
