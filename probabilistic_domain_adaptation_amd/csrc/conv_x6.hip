@@ -78,28 +78,6 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)r2;
 }
 
-// The same split for a PAIR of values in packed arithmetic: v_cvt_pk_bf16_f32 converts both, the packed dword IS the LDS
-// image's element pair, its halves shifted / masked back to fp32 feed one v_pk_add_f32 per level - 9 vector instructions
-// per pair instead of ~12, bit-identical results (same round-to-nearest conversions, exact subtractions).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-template <int NP>
-__device__ __forceinline__ void split3_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-    const f32x2 x = {a, b};
-    h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
-    m = l = 0u;
-    if (NP > 1) {
-        const f32x2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
-        const f32x2 r1 = x - hf;
-        m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
-        if (NP > 2) {
-            const f32x2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xffff0000u)};
-            const f32x2 r2 = r1 - mf;
-            l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
-        }
-    }
-}
-
 // NP = number of bf16 planes per operand: 3 -> six products (fp32-accurate, the parity arithmetic); 2 -> hh + hm + mh
 // (16 significand bits, opt-in fast mode); 1 -> plain bf16 (opt-in).
 // DGRAD selects the epilogue: false = forward (bias, ReLU, optional gate bits of the output); true = input gradient
@@ -240,17 +218,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
             return;
         }
         const float4 r = xin[it] ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding outside the image
-        const float xv[4] = {r.x, r.y, r.z, r.w};
-        bf16x4 ph, pm, pl;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            __bf16 h_, m_, l_;
-            split3(xv[e], h_, m_, l_);
-            ph[e] = h_; pm[e] = m_; pl[e] = l_;
-        }
-        px[it][0] = ph;
-        if (NP > 1) px[it][NP > 1 ? 1 : 0] = pm;
-        if (NP > 2) px[it][NP > 2 ? 2 : 0] = pl;
+        uint2 ph, pm, pl;
+        split3_quad<NP>(r, ph, pm, pl);
+        px[it][0] = __builtin_bit_cast(bf16x4, ph);
+        if (NP > 1) px[it][NP > 1 ? 1 : 0] = __builtin_bit_cast(bf16x4, pm);
+        if (NP > 2) px[it][NP > 2 ? 2 : 0] = __builtin_bit_cast(bf16x4, pl);
     };
     auto commit = [&](int par, int nch) __attribute__((always_inline)) {
         uint4* sXc = sX + par * XBUF;
@@ -666,8 +638,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     auto split_unit = [&](int it) __attribute__((always_inline)) {
         const float4 r = xin[it] ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);
         uint2 ph_, pm, pl;
-        split3_pair<NP>(r.x, r.y, ph_.x, pm.x, pl.x);
-        split3_pair<NP>(r.z, r.w, ph_.y, pm.y, pl.y);
+        split3_quad<NP>(r, ph_, pm, pl);
         px[it][0] = __builtin_bit_cast(bf16x4, ph_);
         if (NP > 1) px[it][NP > 1 ? 1 : 0] = __builtin_bit_cast(bf16x4, pm);
         if (NP > 2) px[it][NP > 2 ? 2 : 0] = __builtin_bit_cast(bf16x4, pl);
