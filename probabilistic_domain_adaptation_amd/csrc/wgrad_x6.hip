@@ -461,115 +461,112 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
         return *reinterpret_cast<const float4*>(dbp + (unsigned)((cy * a.W + cx) * a.cout + cc));
     };
 
-    for (int t = t_begin; t < t_end;) {
-        const int sid = t / tiles_y, ty_s = t - sid * tiles_y;
-        const int txi = sid % tiles_x, b = sid / tiles_x;
-        const int run = min(t_end - t, tiles_y - ty_s);  // tiles of this run: down the strip until its end or the slice's
-        const int tx0 = txi * WTW;
-        const float* const xb = X16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.x) + (size_t)b * ((size_t)(a.H * a.W) * a.cs))
-                                    : a.x + (size_t)b * ((size_t)(a.H * a.W) * a.cs);
-        const float* const dbp = a.dz + (size_t)b * ((size_t)(a.H * a.W) * a.cout);
+    // The two tap groups run the WHOLE sweep in their own instantiation (one uniform branch per launch): with the branch
+    // around each tile's MFMA block the two paths ended in different accumulator registers and every wave paid ~40
+    // v_mov_b64 of accumulator copies per tile at the join.
+    auto sweep = [&](auto ta_c, auto tb_c) __attribute__((always_inline)) {
+        constexpr int TA = decltype(ta_c)::value, TB = decltype(tb_c)::value;
+        for (int t = t_begin; t < t_end;) {
+            const int sid = t / tiles_y, ty_s = t - sid * tiles_y;
+            const int txi = sid % tiles_x, b = sid / tiles_x;
+            const int run = min(t_end - t, tiles_y - ty_s);  // tiles of this run: down the strip until its end or the slice's
+            const int tx0 = txi * WTW;
+            const float* const xb = X16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.x) + (size_t)b * ((size_t)(a.H * a.W) * a.cs))
+                                        : a.x + (size_t)b * ((size_t)(a.H * a.W) * a.cs);
+            const float* const dbp = a.dz + (size_t)b * ((size_t)(a.H * a.W) * a.cout);
 
-        // ---- prologue of the run: the first tile's four X rows and two dZ rows in full (slots 0..3 / 0..1)
-        __syncthreads();  // the previous run's last readers are done
-        for (int u = tid; u < 4 * HTW * C4; u += 512) {
-            const int c4 = u % C4, pix = u / C4, hr = pix / HTW, px = pix % HTW;
-            const int gy = 2 * ty_s - 1 + hr, gx_ = tx0 + px - 1;
-            const bool in = gy >= 0 && gy < a.H && gx_ >= 0 && gx_ < a.W && ci0 + c4 * 4 < a.cs;
-            const float4 v = load_x(xb, gy, gx_, c4);
-            put_x((c4 >> 3) * XIMGR + (hr * HTW + px) * ROWB + (c4 & 7) * 8, v, in);
-        }
-        for (int u = tid; u < 2 * WTW * C4; u += 512) {
-            const int c4 = u % C4, pix = u / C4, row = pix / WTW, px = pix % WTW;
-            const int gy = 2 * ty_s + row, gx_ = tx0 + px;
-            const bool in = gy < a.H && gx_ < a.W && co0 + c4 * 4 < a.cout;
-            float4 v = load_d(dbp, gy, gx_, c4);
-            if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
-            put_planes(sD, DIMGR, (c4 >> 3) * DIMGR + (row * WTW + px) * ROWB + (c4 & 7) * 8, v);
-        }
-        __syncthreads();
-
-        for (int k = 0; k < run; ++k) {
-            const int ty = ty_s + k;
-            const bool has_next = k + 1 < run;  // block-uniform
-            // ring slots of this tile's rows and of the successor's two new rows
-            const int sx = (2 * k) % XSLOTS, sd = (2 * k) % DSLOTS;
-            int xa[4], db_[2];
-#pragma unroll
-            for (int hr = 0; hr < 4; ++hr) xa[hr] = ((sx + hr) % XSLOTS) * (HTW * ROWB) + lane_off + cib * XIMGR;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) db_[r] = ((sd + r) % DSLOTS) * (WTW * ROWB) + lane_off + cob * DIMGR;
-            const int nx0 = ((sx + 4) % XSLOTS) * (HTW * ROWB), nx1 = ((sx + 5) % XSLOTS) * (HTW * ROWB);
-            const int nd0 = ((sd + 2) % DSLOTS) * (WTW * ROWB), nd1 = ((sd + 3) % DSLOTS) * (WTW * ROWB);
-
-            // the successor's new rows: X rows 2 ty + 3, 2 ty + 4 (its halo rows 2, 3), dZ rows 2 ty + 2, 2 ty + 3.
-            // Unconditional and branch-free (clamped addresses; a run's last tile re-fetches valid rows and drops them).
-            float4 rx[XIT], rd[DIT];
-            unsigned inmask = 0u;
-#pragma unroll
-            for (int it = 0; it < XIT; ++it) {
-                const int u = min(tid + it * 512, XNEW - 1);
-                const int c4 = u % C4, pix = u / C4, nr = pix / HTW, px = pix % HTW;
-                const int gy = 2 * ty + 3 + nr, gx_ = tx0 + px - 1;
-                const bool in = gy < a.H && gx_ >= 0 && gx_ < a.W && ci0 + c4 * 4 < a.cs;
-                rx[it] = load_x(xb, gy, gx_, c4);
-                inmask = in ? inmask | (1u << it) : inmask;
+            // ---- prologue of the run: the first tile's four X rows and two dZ rows in full (slots 0..3 / 0..1)
+            __syncthreads();  // the previous run's last readers are done
+            for (int u = tid; u < 4 * HTW * C4; u += 512) {
+                const int c4 = u % C4, pix = u / C4, hr = pix / HTW, px = pix % HTW;
+                const int gy = 2 * ty_s - 1 + hr, gx_ = tx0 + px - 1;
+                const bool in = gy >= 0 && gy < a.H && gx_ >= 0 && gx_ < a.W && ci0 + c4 * 4 < a.cs;
+                const float4 v = load_x(xb, gy, gx_, c4);
+                put_x((c4 >> 3) * XIMGR + (hr * HTW + px) * ROWB + (c4 & 7) * 8, v, in);
             }
-#pragma unroll
-            for (int it = 0; it < DIT; ++it) {
-                const int u = tid + it * 512;
-                const int c4 = u % C4, pix = u / C4, nr = pix / WTW, px = pix % WTW;
-                const int gy = 2 * ty + 2 + nr, gx_ = tx0 + px;
+            for (int u = tid; u < 2 * WTW * C4; u += 512) {
+                const int c4 = u % C4, pix = u / C4, row = pix / WTW, px = pix % WTW;
+                const int gy = 2 * ty_s + row, gx_ = tx0 + px;
                 const bool in = gy < a.H && gx_ < a.W && co0 + c4 * 4 < a.cout;
-                rd[it] = load_d(dbp, gy, gx_, c4);
-                inmask = in ? inmask | (1u << (XIT + it)) : inmask;
-            }
-            auto commit_x = [&](int it) __attribute__((always_inline)) {
-                const int u = min(tid + it * 512, XNEW - 1);  // a clamped duplicate re-writes the last unit with the same data
-                const int c4 = u % C4, pix = u / C4, nr = pix / HTW, px = pix % HTW;
-                put_x((c4 >> 3) * XIMGR + (nr ? nx1 : nx0) + px * ROWB + (c4 & 7) * 8, rx[it], (inmask >> it) & 1u);
-            };
-            auto commit_d = [&](int it) __attribute__((always_inline)) {
-                const int u = tid + it * 512;
-                const int c4 = u % C4, pix = u / C4, nr = pix / WTW, px = pix % WTW;
-                const float4 v = (inmask >> (XIT + it)) & 1u ? rd[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 v = load_d(dbp, gy, gx_, c4);
+                if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
-                put_planes(sD, DIMGR, (c4 >> 3) * DIMGR + (nr ? nd1 : nd0) + px * ROWB + (c4 & 7) * 8, v);
-            };
-            auto between = [&](int s) __attribute__((always_inline)) {
-                if (s == 1) commit_x(0);
-                if (s == 2) {
-#pragma unroll
-                    for (int it = 1; it < XIT; ++it) commit_x(it);
-                }
-                if (s == 3) {
-#pragma unroll
-                    for (int it = 0; it < DIT; ++it) commit_d(it);
-                }
-            };
-            if (has_next) {
-                if (group == 0)
-                    tile_mfma_r<NP, 0, GT0>(acc, sX, sD, xa, db_, between);
-                else
-                    tile_mfma_r<NP, GT0, GT1>(acc, sX, sD, xa, db_, between);
-            } else {  // last tile of the run: nothing to stage (and the dZ column sums must not count rows twice)
-                auto nothing = [](int) {};
-                if (group == 0)
-                    tile_mfma_r<NP, 0, GT0>(acc, sX, sD, xa, db_, nothing);
-                else
-                    tile_mfma_r<NP, GT0, GT1>(acc, sX, sD, xa, db_, nothing);
+                put_planes(sD, DIMGR, (c4 >> 3) * DIMGR + (row * WTW + px) * ROWB + (c4 & 7) * 8, v);
             }
             __syncthreads();
-        }
-        t += run;
-    }
 
-    const int co = co0 + cob * 32 + l31;
+            for (int k = 0; k < run; ++k) {
+                const int ty = ty_s + k;
+                const bool has_next = k + 1 < run;  // block-uniform
+                // ring slots of this tile's rows and of the successor's two new rows
+                const int sx = (2 * k) % XSLOTS, sd = (2 * k) % DSLOTS;
+                int xa[4], db_[2];
+    #pragma unroll
+                for (int hr = 0; hr < 4; ++hr) xa[hr] = ((sx + hr) % XSLOTS) * (HTW * ROWB) + lane_off + cib * XIMGR;
+    #pragma unroll
+                for (int r = 0; r < 2; ++r) db_[r] = ((sd + r) % DSLOTS) * (WTW * ROWB) + lane_off + cob * DIMGR;
+                const int nx0 = ((sx + 4) % XSLOTS) * (HTW * ROWB), nx1 = ((sx + 5) % XSLOTS) * (HTW * ROWB);
+                const int nd0 = ((sd + 2) % DSLOTS) * (WTW * ROWB), nd1 = ((sd + 3) % DSLOTS) * (WTW * ROWB);
+
+                // the successor's new rows: X rows 2 ty + 3, 2 ty + 4 (its halo rows 2, 3), dZ rows 2 ty + 2, 2 ty + 3.
+                // Unconditional and branch-free (clamped addresses; a run's last tile re-fetches valid rows and drops them).
+                float4 rx[XIT], rd[DIT];
+                unsigned inmask = 0u;
+    #pragma unroll
+                for (int it = 0; it < XIT; ++it) {
+                    const int u = min(tid + it * 512, XNEW - 1);
+                    const int c4 = u % C4, pix = u / C4, nr = pix / HTW, px = pix % HTW;
+                    const int gy = 2 * ty + 3 + nr, gx_ = tx0 + px - 1;
+                    const bool in = gy < a.H && gx_ >= 0 && gx_ < a.W && ci0 + c4 * 4 < a.cs;
+                    rx[it] = load_x(xb, gy, gx_, c4);
+                    inmask = in ? inmask | (1u << it) : inmask;
+                }
+    #pragma unroll
+                for (int it = 0; it < DIT; ++it) {
+                    const int u = tid + it * 512;
+                    const int c4 = u % C4, pix = u / C4, nr = pix / WTW, px = pix % WTW;
+                    const int gy = 2 * ty + 2 + nr, gx_ = tx0 + px;
+                    const bool in = gy < a.H && gx_ < a.W && co0 + c4 * 4 < a.cout;
+                    rd[it] = load_d(dbp, gy, gx_, c4);
+                    inmask = in ? inmask | (1u << (XIT + it)) : inmask;
+                }
+                auto commit_x = [&](int it) __attribute__((always_inline)) {
+                    const int u = min(tid + it * 512, XNEW - 1);  // a clamped duplicate re-writes the last unit with the same data
+                    const int c4 = u % C4, pix = u / C4, nr = pix / HTW, px = pix % HTW;
+                    put_x((c4 >> 3) * XIMGR + (nr ? nx1 : nx0) + px * ROWB + (c4 & 7) * 8, rx[it], (inmask >> it) & 1u);
+                };
+                auto commit_d = [&](int it) __attribute__((always_inline)) {
+                    const int u = tid + it * 512;
+                    const int c4 = u % C4, pix = u / C4, nr = pix / WTW, px = pix % WTW;
+                    const float4 v = (inmask >> (XIT + it)) & 1u ? rd[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+                    put_planes(sD, DIMGR, (c4 >> 3) * DIMGR + (nr ? nd1 : nd0) + px * ROWB + (c4 & 7) * 8, v);
+                };
+                auto between = [&](int s) __attribute__((always_inline)) {
+                    if (!has_next) return;  // last tile of the run: nothing to stage (the dZ column sums must not count rows twice)
+                    if (s == 1) commit_x(0);
+                    if (s == 2) {
+    #pragma unroll
+                        for (int it = 1; it < XIT; ++it) commit_x(it);
+                    }
+                    if (s == 3) {
+    #pragma unroll
+                        for (int it = 0; it < DIT; ++it) commit_d(it);
+                    }
+                };
+                tile_mfma_r<NP, TA, TB>(acc, sX, sD, xa, db_, between);
+                __syncthreads();
+            }
+            t += run;
+        }
+
+        const int co = co0 + cob * 32 + l31;
+        store_partial<TA, TB>(acc, a, slice, ci0 + cib * 32, co, half);
+    };
     if (group == 0)
-        store_partial<0, GT0>(acc, a, slice, ci0 + cib * 32, co, half);
+        sweep(std::integral_constant<int, 0>{}, std::integral_constant<int, GT0>{});
     else
-        store_partial<GT0, GT1>(acc, a, slice, ci0 + cib * 32, co, half);
+        sweep(std::integral_constant<int, GT0>{}, std::integral_constant<int, GT1>{});
 
     if (a.bias_partial && ci_tile == 0) {  // block-uniform
         __syncthreads();
