@@ -45,6 +45,9 @@ constexpr int WTH = 2, WTW = 32, WC = 64;
 #ifndef PUNET_WGRAD_PRIO
 #define PUNET_WGRAD_PRIO 0  // 0: none, 1: waves 4-7 at priority 1, 2: waves 0-3 at priority 1
 #endif
+#ifndef PUNET_WGRAD_SB  // scheduling regions of the rolling kernel's tile: 1 = one per pixel group, 2 = per two, 0 = whole tile
+#define PUNET_WGRAD_SB 0  // (one region per pixel group was needed at 255 VGPRs; at 180 the free schedule is 0.5-1 % faster)
+#endif
 constexpr int GT0 = PUNET_WGRAD_T0, GT1 = 9 - GT0, GTMAX = GT0 > GT1 ? GT0 : GT1;
 constexpr int HTH = WTH + 2, HTW = WTW + 2;
 constexpr int NPX = HTH * HTW;   // 136 halo pixels
@@ -381,7 +384,11 @@ __device__ __forceinline__ void tile_mfma_r(f32x16 (&acc)[GTMAX], const char* sX
             acc[tt] = c;
         }
         between(s);
+#if PUNET_WGRAD_SB == 1
         __builtin_amdgcn_sched_barrier(0);
+#elif PUNET_WGRAD_SB == 2
+        if (s & 1) __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 }
 
