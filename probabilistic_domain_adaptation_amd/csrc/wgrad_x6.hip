@@ -45,6 +45,9 @@ constexpr int WTH = 2, WTW = 32, WC = 64;
 #ifndef PUNET_WGRAD_PRIO
 #define PUNET_WGRAD_PRIO 0  // 0: none, 1: waves 4-7 at priority 1, 2: waves 0-3 at priority 1
 #endif
+#ifndef PUNET_WGRAD_PREFETCH  // 1: fragment reads one step ahead of the MFMAs (hand-pipelined); 0: left to the scheduler
+#define PUNET_WGRAD_PREFETCH 1
+#endif
 #ifndef PUNET_WGRAD_SB  // scheduling regions of the rolling kernel's tile: 1 = one per pixel group, 2 = per two, 0 = whole tile
 #define PUNET_WGRAD_SB 0  // (one region per pixel group was needed at 255 VGPRs; at 180 the free schedule is 0.5-1 % faster)
 #endif
@@ -353,8 +356,59 @@ template <int NP, int T0, int NT, typename F>
 __device__ __forceinline__ void tile_mfma_r(f32x16 (&acc)[GTMAX], const char* sX, const char* sD, const int (&xa)[4],
                                             const int (&db)[2], F&& between) {
     constexpr int P1 = NP > 1 ? 1 : 0, P2 = NP > 2 ? 2 : 0;
+    constexpr int NS = NPD / 16;
+#if PUNET_WGRAD_PREFETCH
+    // Software-pipelined by hand: the fragments of step i + 1 (one tap of one 16-pixel group; the dZ fragments too where a
+    // new pixel group begins) are read BEFORE the six MFMAs of step i are issued, into the other half of a double buffer.
+    // Left to the scheduler the reads of a tap followed the previous tap's MFMAs and only their last ~170 cycles of
+    // execution hid the LDS latency: R x 6, wait, M x 6, R x 6, wait, ... - the two waves of a SIMD kept its matrix pipe
+    // 67 % busy (s_memtime, tools/trace_wgrad.sh).  Needs 24 more registers than the kernel had at 255 VGPRs.
+    Frag a[2][NP], b[2][NP];
+    auto load_b = [&](int s, Frag(&bb)[NP]) __attribute__((always_inline)) {
+        const int row = (16 * s) / WTW, col0 = (16 * s) % WTW;
 #pragma unroll
-    for (int s = 0; s < NPD / 16; ++s) {
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) bb[p].half4[r] = tr_read(sD, p * 2 * DIMGR + (col0 + 4 * r) * ROWB + db[row]);
+    };
+    auto load_a = [&](int s, int tt, Frag(&aa)[NP]) __attribute__((always_inline)) {
+        const int row = (16 * s) / WTW, col0 = (16 * s) % WTW;
+        const int t = T0 + tt, ky = t / 3, kx = t % 3;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) aa[p].half4[r] = tr_read(sX, p * 2 * XIMGR + (col0 + kx + 4 * r) * ROWB + xa[row + ky]);
+    };
+    load_b(0, b[0]);
+    load_a(0, 0, a[0]);
+#pragma unroll
+    for (int i = 0; i < NS * NT; ++i) {
+        const int s = i / NT, tt = i % NT;
+        if (i + 1 < NS * NT) {
+            const int s1 = (i + 1) / NT, tt1 = (i + 1) % NT;
+            if (tt1 == 0) load_b(s1, b[s1 & 1]);
+            load_a(s1, tt1, a[(i + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the prefetch stays in front of this step's MFMAs
+        const Frag(&aa)[NP] = a[i & 1];
+        const Frag(&bb)[NP] = b[s & 1];
+        f32x16 c = acc[tt];
+        if (NP > 2) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[P1].v, bb[P1].v, c, 0, 0, 0);  // mm
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[P2].v, bb[0].v, c, 0, 0, 0);   // lh
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[0].v, bb[P2].v, c, 0, 0, 0);   // hl
+        }
+        if (NP > 1) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[P1].v, bb[0].v, c, 0, 0, 0);  // mh
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[0].v, bb[P1].v, c, 0, 0, 0);  // hm
+        }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[0].v, bb[0].v, c, 0, 0, 0);  // hh
+        acc[tt] = c;
+        if (tt == NT - 1) between(s);
+    }
+#else
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
         const int row = (16 * s) / WTW, col0 = (16 * s) % WTW;
         Frag b[NP];
 #pragma unroll
@@ -390,6 +444,7 @@ __device__ __forceinline__ void tile_mfma_r(f32x16 (&acc)[GTMAX], const char* sX
         if (s & 1) __builtin_amdgcn_sched_barrier(0);
 #endif
     }
+#endif
 }
 
 // X16 (one plane only; the "bf16s" fast mode): the activation operand x holds bf16 - its staging is a plain 8-byte copy
@@ -503,6 +558,17 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
             __syncthreads();
 
             for (int k = 0; k < run; ++k) {
+#ifdef PUNET_WGRAD_TRACE
+                const int trace_iter = k;  // tiles 5, 6, 7 of the first run: ids 0 / 10 / 11 (+ 3 per tile)
+#define WGTR(id)                                                                                              \
+    do {                                                                                                      \
+        if (blockIdx.x == 7 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && t == t_begin && trace_iter >= 5 && trace_iter < 8) \
+            punet_wgrad_trace[(threadIdx.x >> 6) * 32 + (trace_iter - 5) * 3 + (id)] = __builtin_amdgcn_s_memtime();  \
+    } while (0)
+#else
+#define WGTR(id)
+#endif
+                WGTR(0);
                 const int ty = ty_s + k;
                 const bool has_next = k + 1 < run;  // block-uniform
                 // ring slots of this tile's rows and of the successor's two new rows
@@ -562,7 +628,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
                     }
                 };
                 tile_mfma_r<NP, TA, TB>(acc, sX, sD, xa, db_, between);
+                WGTR(1);
                 __syncthreads();
+                WGTR(2);
             }
             t += run;
         }
@@ -717,9 +785,9 @@ int main() {
     unsigned long long t[8 * 32];
     hipMemcpyFromSymbol(t, HIP_SYMBOL(punet_wgrad_trace), sizeof(t));
     printf("slices %d; stamps relative to wave 0's loop top (id 0), shader cycles (s_memtime)\n", ns);
-    for (int w = 0; w < 8; ++w) {
+    for (int w = 0; w < 8; ++w) {  // rolling kernel: tiles 5, 6, 7 of the workgroup's first run: top / barrier reached / passed
         printf("wave %d:", w);
-        for (int i : {0, 10, 11}) printf("  id %2d: %6lld", i, (long long)(t[w * 32 + i] - t[0]));
+        for (int i = 0; i < 9; ++i) printf(" %6lld%s", (long long)(t[w * 32 + i] - t[0]), i % 3 == 2 ? " |" : "");
         printf("\n");
     }
     return 0;
