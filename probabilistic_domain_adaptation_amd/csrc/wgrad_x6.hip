@@ -45,7 +45,7 @@ constexpr int WTH = 2, WTW = 32, WC = 64;
 #ifndef PUNET_WGRAD_PRIO
 #define PUNET_WGRAD_PRIO 0  // 0: none, 1: waves 4-7 at priority 1, 2: waves 0-3 at priority 1
 #endif
-#ifndef PUNET_WGRAD_PREFETCH  // 1: fragment reads one step ahead of the MFMAs (hand-pipelined); 0: left to the scheduler
+#ifndef PUNET_WGRAD_PREFETCH  // n >= 1: fragment reads n steps ahead of the MFMAs (hand-pipelined); 0: left to the scheduler
 #define PUNET_WGRAD_PREFETCH 1
 #endif
 #ifndef PUNET_WGRAD_SB  // scheduling regions of the rolling kernel's tile: 1 = one per pixel group, 2 = per two, 0 = whole tile
@@ -363,7 +363,8 @@ __device__ __forceinline__ void tile_mfma_r(f32x16 (&acc)[GTMAX], const char* sX
     // Left to the scheduler the reads of a tap followed the previous tap's MFMAs and only their last ~170 cycles of
     // execution hid the LDS latency: R x 6, wait, M x 6, R x 6, wait, ... - the two waves of a SIMD kept its matrix pipe
     // 67 % busy (s_memtime, tools/trace_wgrad.sh).  Needs 24 more registers than the kernel had at 255 VGPRs.
-    Frag a[2][NP], b[2][NP];
+    constexpr int D = PUNET_WGRAD_PREFETCH;  // steps of lookahead
+    Frag a[D + 1][NP], b[2][NP];
     auto load_b = [&](int s, Frag(&bb)[NP]) __attribute__((always_inline)) {
         const int row = (16 * s) / WTW, col0 = (16 * s) % WTW;
 #pragma unroll
@@ -380,17 +381,18 @@ __device__ __forceinline__ void tile_mfma_r(f32x16 (&acc)[GTMAX], const char* sX
             for (int r = 0; r < 2; ++r) aa[p].half4[r] = tr_read(sX, p * 2 * XIMGR + (col0 + kx + 4 * r) * ROWB + xa[row + ky]);
     };
     load_b(0, b[0]);
-    load_a(0, 0, a[0]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) load_a(j / NT, j % NT, a[j % (D + 1)]);
 #pragma unroll
     for (int i = 0; i < NS * NT; ++i) {
         const int s = i / NT, tt = i % NT;
-        if (i + 1 < NS * NT) {
-            const int s1 = (i + 1) / NT, tt1 = (i + 1) % NT;
+        if (i + D < NS * NT) {
+            const int s1 = (i + D) / NT, tt1 = (i + D) % NT;
             if (tt1 == 0) load_b(s1, b[s1 & 1]);
-            load_a(s1, tt1, a[(i + 1) & 1]);
+            load_a(s1, tt1, a[(i + D) % (D + 1)]);
         }
         __builtin_amdgcn_sched_barrier(0);  // the prefetch stays in front of this step's MFMAs
-        const Frag(&aa)[NP] = a[i & 1];
+        const Frag(&aa)[NP] = a[i % (D + 1)];
         const Frag(&bb)[NP] = b[s & 1];
         f32x16 c = acc[tt];
         if (NP > 2) {
