@@ -601,7 +601,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
                     const int u = tid + it * 512;
                     const int c4 = u % C4, pix = u / C4, nr = pix / WTW, px = pix % WTW;
                     const int gy = 2 * ty + 2 + nr, gx_ = tx0 + px;
-                    const bool in = gy < a.H && gx_ < a.W && co0 + c4 * 4 < a.cout;
+                    // (the run's last tile stages too - no branch in the MFMA stream, the rows land in ring slots nobody reads
+                    // - but its dZ rows count as outside: they must not enter the column sums a second time)
+                    const bool in = has_next && gy < a.H && gx_ < a.W && co0 + c4 * 4 < a.cout;
                     rd[it] = load_d(dbp, gy, gx_, c4);
                     inmask = in ? inmask | (1u << (XIT + it)) : inmask;
                 }
@@ -618,7 +620,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
                     put_planes(sD, DIMGR, (c4 >> 3) * DIMGR + (nr ? nd1 : nd0) + px * ROWB + (c4 & 7) * 8, v);
                 };
                 auto between = [&](int s) __attribute__((always_inline)) {
-                    if (!has_next) return;  // last tile of the run: nothing to stage (the dZ column sums must not count rows twice)
+#ifdef PUNET_WGRAD_TRACE_FINE
+                    if (blockIdx.x == 7 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && t == t_begin && trace_iter == 6)
+                        punet_wgrad_trace[(threadIdx.x >> 6) * 32 + 9 + s] = __builtin_amdgcn_s_memtime();
+#endif
                     if (s == 1) commit_x(0);
                     if (s == 2) {
     #pragma unroll
@@ -790,6 +795,10 @@ int main() {
     for (int w = 0; w < 8; ++w) {  // rolling kernel: tiles 5, 6, 7 of the workgroup's first run: top / barrier reached / passed
         printf("wave %d:", w);
         for (int i = 0; i < 9; ++i) printf(" %6lld%s", (long long)(t[w * 32 + i] - t[0]), i % 3 == 2 ? " |" : "");
+#ifdef PUNET_WGRAD_TRACE_FINE
+        printf("  tile 6, pixel groups issued:");
+        for (int i = 9; i < 13; ++i) printf(" %6lld", (long long)(t[w * 32 + i] - t[w * 32 + 3]));
+#endif
         printf("\n");
     }
     return 0;
