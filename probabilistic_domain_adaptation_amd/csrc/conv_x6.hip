@@ -521,6 +521,9 @@ __host__ __device__ constexpr int x6b_slot(int ph, int t) {
 #ifndef X6B_GENERAL_EPILOGUE  // 1 = only the general epilogue (every flag tested at run time, per store), for A/B runs
 #define X6B_GENERAL_EPILOGUE 0
 #endif
+#ifndef X6B_PIN_SPLIT
+#define X6B_PIN_SPLIT 1
+#endif
 #ifndef X6B_VECTOR_WAVE  // 1 = the wave index as a VGPR value (the form before round 2's scalar wave index), for A/B runs
 #define X6B_VECTOR_WAVE 0
 #endif
@@ -639,6 +642,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         const float4 r = xin[it] ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);
         uint2 ph_, pm, pl;
         split3_quad<NP>(r, ph_, pm, pl);
+#if X6B_PIN_SPLIT
+        // the planes are only needed by the NEXT commit: without a use here the optimiser sinks the whole split behind the
+        // chunk's last MFMA (a ~75-instruction vector blob in front of the barrier) instead of leaving it in their shadow
+        asm volatile("" : "+v"(ph_.x), "+v"(ph_.y), "+v"(pm.x), "+v"(pm.y), "+v"(pl.x), "+v"(pl.y));
+#endif
         px[it][0] = __builtin_bit_cast(bf16x4, ph_);
         if (NP > 1) px[it][NP > 1 ? 1 : 0] = __builtin_bit_cast(bf16x4, pm);
         if (NP > 2) px[it][NP > 2 ? 2 : 0] = __builtin_bit_cast(bf16x4, pl);
