@@ -45,6 +45,9 @@ constexpr int WTH = 2, WTW = 32, WC = 64;
 #ifndef PUNET_WGRAD_PRIO
 #define PUNET_WGRAD_PRIO 0  // 0: none, 1: waves 4-7 at priority 1, 2: waves 0-3 at priority 1
 #endif
+#ifndef PUNET_WGRAD_TIMING
+#define PUNET_WGRAD_TIMING 0
+#endif
 #ifndef PUNET_WGRAD_PREFETCH  // n >= 1: fragment reads n steps ahead of the MFMAs (hand-pipelined); 0: left to the scheduler
 #define PUNET_WGRAD_PREFETCH 1
 #endif
@@ -507,6 +510,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
             const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(xb) + (unsigned)((cy * a.W + cx) * a.cs + cc));
             return make_float4(__builtin_bit_cast(float, h.x), __builtin_bit_cast(float, h.y), 0.f, 0.f);
         } else {
+#if PUNET_WGRAD_TIMING & 8  // timing-only (WRONG results): operands from a cache-resident window, same instructions
+            return *reinterpret_cast<const float4*>(xb + (unsigned)((((cy * a.W + cx) & 2047)) * a.cs + cc));
+#endif
             return *reinterpret_cast<const float4*>(xb + (unsigned)((cy * a.W + cx) * a.cs + cc));
         }
     };
@@ -522,6 +528,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
     auto load_d = [&](const float* dbp, int gy, int gx_, int c4) __attribute__((always_inline)) -> float4 {
         const int c = co0 + c4 * 4;
         const int cy = min(gy, a.H - 1), cx = min(gx_, a.W - 1), cc = min(c, a.cout - 4);
+#if PUNET_WGRAD_TIMING & 8
+        return *reinterpret_cast<const float4*>(dbp + (unsigned)((((cy * a.W + cx) & 2047)) * a.cout + cc));
+#endif
         return *reinterpret_cast<const float4*>(dbp + (unsigned)((cy * a.W + cx) * a.cout + cc));
     };
 
