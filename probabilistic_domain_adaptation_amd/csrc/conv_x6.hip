@@ -521,6 +521,16 @@ __host__ __device__ constexpr int x6b_slot(int ph, int t) {
 #ifndef X6B_GENERAL_EPILOGUE  // 1 = only the general epilogue (every flag tested at run time, per store), for A/B runs
 #define X6B_GENERAL_EPILOGUE 0
 #endif
+#ifdef X6B_TRACE  // s_memtime stamps of one workgroup's chunks 8..11 (tools/trace_conv.sh): per wave, per chunk:
+__device__ unsigned long long punet_x6b_trace[4 * 16];  // top barrier passed, operand barrier passed, K-steps issued
+#define X6BT(id)                                                                                             \
+    do {                                                                                                     \
+        if (blockIdx.x == 9 && (threadIdx.x & 63) == 0 && trace_chunk >= 8 && trace_chunk < 12)              \
+            punet_x6b_trace[(threadIdx.x >> 6) * 16 + (trace_chunk - 8) * 3 + (id)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define X6BT(id)
+#endif
 #ifndef X6B_PIN_SPLIT
 #define X6B_PIN_SPLIT 1
 #endif
@@ -903,6 +913,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     };
 #undef X6B_EC
 
+#ifdef X6B_TRACE
+    int trace_chunk = 0;
+#endif
     int tile = blockIdx.x;
     if (a.xcd_remap) tile = (tile & 7) * ((int)gridDim.x >> 3) + (tile >> 3);
     if (tile >= a.ntiles) return;
@@ -926,6 +939,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         if (!has_next) nch = ch;
         if (ph == 3 && has_next && nch == 0) retarget(nti);
         __syncthreads();
+        X6BT(0);
         __builtin_amdgcn_s_setprio(3);
         commit(ph_c, ch, nch);
         __builtin_amdgcn_s_setprio(0);
@@ -933,6 +947,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         // a __syncthreads() here would drain them too (its fence waits vmcnt(0) while an LDS-DMA is pending)
         __builtin_amdgcn_s_waitcnt(XITER | (7 << 4) | (0 << 8));  // vmcnt(XITER) expcnt(7) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
+        X6BT(1);
         if (ph == 3 && ch == nchunks - 1) epilogue_prefetch(ti);  // block-uniform
         auto s0 = [&]() __attribute__((always_inline)) { split_unit(0); };
         auto s1 = [&]() __attribute__((always_inline)) {
@@ -956,6 +971,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
             kstep(X6B_K(8), s_);
         }
 #undef X6B_K
+        X6BT(2);
+#ifdef X6B_TRACE
+        ++trace_chunk;
+#endif
         if (ph == 3 && ch == nchunks - 1) {  // no barrier: the epilogue touches no LDS, waves drain into it as they finish
             epilogue(ti);
             zero_acc();
@@ -1206,3 +1225,37 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
     PUNET_LAUNCH_CHECK("conv3x3_x6");
     return PUNET_OK;
 }
+
+#ifdef X6B_TRACE_MAIN  // standalone trace driver: 256 -> 256 channels at 128 x 128, batch 4 (tools/trace_conv.sh)
+#include <cstdio>
+#include <vector>
+int main() {
+    const int B = 4, H = 128, W = 128, C = 256;
+    const size_t n = (size_t)B * H * W * C;
+    std::vector<float> h(n);
+    unsigned s = 1;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.f - (s & 1 ? 0.5f : 1.5f); }
+    float *x, *y, *w, *b;
+    __bf16* planes;
+    const size_t nw = (size_t)9 * C * C;
+    hipMalloc(&x, n * 4); hipMalloc(&y, n * 4); hipMalloc(&w, nw * 4); hipMalloc(&b, C * 4); hipMalloc(&planes, 3 * nw * 2);
+    hipMemcpy(x, h.data(), n * 4, hipMemcpyHostToDevice);
+    hipMemcpy(w, h.data(), nw * 4, hipMemcpyHostToDevice);
+    hipMemset(b, 0, C * 4);
+    punet_split_weights_x6(w, planes, (long)nw, C, C, 3, 0, nullptr);
+    for (int r = 0; r < 3; ++r) {
+        const int rc = punet_conv3x3_x6(x, C, nullptr, 0, planes, (long)nw, C, 0, b, 0, y, C, nullptr, 0, 1, B, H, W, 0, nullptr);
+        if (rc) { printf("error %d: %s\n", rc, punet_last_error()); return 1; }
+    }
+    hipDeviceSynchronize();
+    unsigned long long t[4 * 16];
+    hipMemcpyFromSymbol(t, HIP_SYMBOL(punet_x6b_trace), sizeof(t));
+    printf("chunks 8..11 of workgroup 9: top barrier passed / operand barrier passed / K-steps issued, shader cycles rel. to wave 0\n");
+    for (int wv = 0; wv < 4; ++wv) {
+        printf("wave %d:", wv);
+        for (int i = 0; i < 12; ++i) printf(" %6lld%s", (long long)(t[wv * 16 + i] - t[0]), i % 3 == 2 ? " |" : "");
+        printf("\n");
+    }
+    return 0;
+}
+#endif
