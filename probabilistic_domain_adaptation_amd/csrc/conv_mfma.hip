@@ -69,8 +69,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float sW[KK * CK * TN];
 
     const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it stays in SGPRs
-    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
 
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int ntn = (a.n_total + TN - 1) / TN;

@@ -79,8 +79,7 @@ __global__ __launch_bounds__(KS == 3 ? 512 : 256, KS == 3 ? 4 : 2) void wgrad_mf
     __shared__ __attribute__((aligned(16))) float sD[WTH * WTW * WC];
 
     const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it stays in SGPRs
-    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int pair = wave & 3, group = wave >> 2;
     const int cib = pair >> 1, cob = pair & 1;
 
