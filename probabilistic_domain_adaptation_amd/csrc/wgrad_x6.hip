@@ -43,7 +43,7 @@ constexpr int WTH = 2, WTW = 32, WC = 64;
 #define PUNET_WGRAD_T0 5
 #endif
 #ifndef PUNET_WGRAD_PRIO
-#define PUNET_WGRAD_PRIO 0  // 0: none, 1: waves 4-7 at priority 1, 2: waves 0-3 at priority 1
+#define PUNET_WGRAD_PRIO 1  // 0: none, 1: waves 4-7 at priority 1 (-0.1 ms per step in the rolling kernel), 2: waves 0-3 at 1, 3: waves 4-7 at 3
 #endif
 #ifndef PUNET_WGRAD_TIMING
 #define PUNET_WGRAD_TIMING 0
@@ -469,6 +469,13 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it stays in SGPRs
     const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int pair = wave & 3, group = wave >> 2;
+#if PUNET_WGRAD_PRIO == 1  // waves 4-7 lose the issue arbitration against 0-3 and reach the tile's barrier ~1.5k cycles later
+    if (group == 1) __builtin_amdgcn_s_setprio(1);
+#elif PUNET_WGRAD_PRIO == 2
+    if (group == 0) __builtin_amdgcn_s_setprio(1);
+#elif PUNET_WGRAD_PRIO == 3
+    if (group == 1) __builtin_amdgcn_s_setprio(3);
+#endif
     const int cib = pair >> 1, cob = pair & 1;
     const int co_tiles = (a.cout + WC - 1) / WC;
     const int ci_tile = blockIdx.y / co_tiles, co_tile = blockIdx.y % co_tiles;
