@@ -96,9 +96,11 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
     float* sWm = sW1 + CH * WP;                      // [NMID][CH][WP]
     float* sBm = sWm + NMID * CH * WP;               // [NMID][CH]
     float* sW3 = sBm + NMID * CH;                    // [CH]
-    float* sT = sW3 + CH;                            // 4 waves x 2 tiles x [32][TP]; reused for the final reduction
-    // keep the tile region 16-byte aligned
-    sT = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(sT) + 15) & ~uintptr_t(15));
+    // 4 waves x 2 tiles x [32][TP]; reused for the final reduction.  16-byte aligned by OFFSET arithmetic (smem is aligned): an
+    // integer round trip of the pointer loses its LDS address space, and every tile access became a flat_load / flat_store
+    // (160 + 167 of them) that counts on vmcnt AND lgkmcnt.
+    constexpr int T_OFF = ((CH * WP + NMID * CH * WP + NMID * CH + CH) + 3) / 4 * 4;
+    float* sT = smem + T_OFF;
 
     const int tid = threadIdx.x;
     for (int i = tid; i < CH * CH; i += 256) sW1[(i / CH) * WP + i % CH] = a.w1[i];
