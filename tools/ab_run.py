@@ -11,6 +11,7 @@ what, names = sys.argv[1], sys.argv[2:]
 cmd = {"wgrad": [sys.executable, os.path.join(ROOT, "tools", "time_wgrad.py")],
        "fcomb": [sys.executable, os.path.join(ROOT, "tools", "time_fcomb_train.py")],
        "sampler": [sys.executable, os.path.join(ROOT, "tools", "time_sampler.py")],
+       "upbwd": [sys.executable, os.path.join(ROOT, "tools", "time_upsample_bwd.py")],
        "layers": [sys.executable, os.path.join(ROOT, "tools", "bench_x6_layers.py"), "--rounds", "3"],
        "step": [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline",
                 "--no-other-configs", "--no-kernel-timing"]}[what]
