@@ -124,7 +124,8 @@ int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int cout, float
                         float* dbias, float* workspace, int nslices, int B, int H, int W, int accumulate, float scale,
                         int opts, void* stream);
 
-/* ---- K1s: first-layer 3x3 conv with cin in 1..4 (image / [image, mask], probabilistic_unet.py:39-42,118) and its
+/* ---- K1s: first-layer 3x3 conv with cin in 1..8 (image / [image, mask], probabilistic_unet.py:39-42,118; the reference's
+ *      scripts use 1..4: weights in registers; 5..8: weights in LDS / two passes over channel sub-ranges) and its
  *      weight + bias gradient (no input gradient exists). */
 int punet_conv3x3_small_fwd(const float* x, int cin, const float* w, const float* bias, float* y, int cout, int B,
                             int H, int W, int relu, void* stream);

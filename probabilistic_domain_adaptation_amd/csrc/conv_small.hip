@@ -1,5 +1,6 @@
-// K1s: first-layer 3x3 convolutions with 1..4 input channels (image, or [image, mask] of the posterior
-// encoder: probabilistic_unet.py:39-42,118) and their weight/bias gradients.
+// K1s: first-layer 3x3 convolutions with 1..8 input channels (image, or [image, mask] of the posterior
+// encoder: probabilistic_unet.py:39-42,118) and their weight/bias gradients.  1..4 channels (every reference script) keep the
+// weights in registers; 5..8 read them from LDS (forward) / take two passes over channel sub-ranges (weight gradient).
 //
 // These layers are HBM-bound (a few FLOP per output byte), so they stay on the VALU: every thread owns
 // four consecutive output channels of a pixel (Cout/4 threads per pixel -> one coalesced 16 B x Cout/4
@@ -17,13 +18,22 @@ template <int CIN, bool OUT16 = false>  // OUT16: y holds bf16 (the "bf16s" fast
 __global__ __launch_bounds__(256) void conv3x3_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ y,
                                                                int cout, int B, int H, int W, int relu, int xiter) {
+    constexpr bool WLDS = CIN > 4;  // 9 * CIN float4 weights per thread: registers up to 4 channels, LDS beyond
+    extern __shared__ __attribute__((aligned(16))) float4 swr[];  // WLDS: [9 * CIN][groups]
     const int groups = cout / 4;
     const int ppb = 256 / groups;
     const int g = threadIdx.x % groups, pl = threadIdx.x / groups;
+    if (WLDS) {
+        for (int i = threadIdx.x; i < 9 * CIN * groups; i += 256)
+            swr[i] = *reinterpret_cast<const float4*>(w + (size_t)(i / groups) * cout + (i % groups) * 4);
+        __syncthreads();
+    }
     if (pl >= ppb) return;
-    float4 wr[9 * CIN];
+    float4 wr[WLDS ? 1 : 9 * CIN];
+    if (!WLDS) {
 #pragma unroll
-    for (int i = 0; i < 9 * CIN; ++i) wr[i] = *reinterpret_cast<const float4*>(w + (size_t)i * cout + g * 4);
+        for (int i = 0; i < 9 * CIN; ++i) wr[WLDS ? 0 : i] = *reinterpret_cast<const float4*>(w + (size_t)i * cout + g * 4);
+    }
     const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (unsigned row = blockIdx.y; row < (unsigned)(B * H); row += gridDim.y) {  // b * H + py
         const int py = (int)(row % (unsigned)H);
@@ -49,7 +59,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_fwd_kernel(const float* __r
 #pragma unroll
             for (int i = 0; i < 9 * CIN; ++i) {
                 const float xv = xin[i];
-                const float4 ww = wr[i];
+                const float4 ww = WLDS ? swr[i * groups + g] : wr[WLDS ? 0 : i];
                 o.x = fmaf(xv, ww.x, o.x); o.y = fmaf(xv, ww.y, o.y);
                 o.z = fmaf(xv, ww.z, o.z); o.w = fmaf(xv, ww.w, o.w);
             }
@@ -67,9 +77,11 @@ __global__ __launch_bounds__(256) void conv3x3_small_fwd_kernel(const float* __r
 }
 
 // partial[block][9*CIN + 1][cout]: rows 0..9*CIN-1 = dW[tap][ci][:], last row = dbias
+// x holds `xs` channels per pixel, of which this launch takes [c_off, c_off + CIN) (xs = CIN, c_off = 0 for 1..4 channels)
 template <int CIN>
 __global__ __launch_bounds__(256) void conv3x3_small_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
-                                                                 float* __restrict__ partial, int cout, int B, int H, int W) {
+                                                                 float* __restrict__ partial, int cout, int B, int H, int W,
+                                                                 int xs, int c_off) {
     constexpr int ROWS = 9 * CIN + 1;
     extern __shared__ __attribute__((aligned(16))) float4 sred[];  // [4 waves][ROWS][groups]
     const int groups = cout / 4;
@@ -84,7 +96,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_wgrad_kernel(const float* _
         // ALU-bound, as in the forward)
         for (unsigned row = blockIdx.x; row < (unsigned)(B * H); row += gridDim.x) {
             const int py = (int)(row % (unsigned)H);
-            const float* xrow = x + (size_t)row * W * CIN;
+            const float* xrow = x + (size_t)row * W * xs + c_off;
             const float* drow = dz + (size_t)row * W * cout + g * 4;
             const bool up = py > 0, down = py < H - 1;
             for (int px = pl; px < W; px += ppb) {
@@ -95,7 +107,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_wgrad_kernel(const float* _
                 for (int t = 0; t < 9; ++t) {
                     const int dy = t / 3 - 1, dx = t % 3 - 1;
                     const bool in = (dy < 0 ? up : (dy > 0 ? down : true)) && px + dx >= 0 && px + dx < W;
-                    const float* xp = xrow + (in ? (dy * W + px + dx) * CIN : px * CIN);
+                    const float* xp = xrow + (in ? (dy * W + px + dx) * xs : px * xs);
 #pragma unroll
                     for (int c = 0; c < CIN; ++c) xin[t * CIN + c] = in ? xp[c] : 0.f;
                 }
@@ -139,7 +151,7 @@ static int small_fwd_launch(bool out16, const float* x, int cin, const float* w,
                             int W, int relu, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     PUNET_CHECK_ARG(x && w && y, "punet_conv3x3_small_fwd: null pointer");
-    PUNET_CHECK_ARG(cin >= 1 && cin <= 4, "punet_conv3x3_small_fwd: cin must be 1..4 (got %d)", cin);
+    PUNET_CHECK_ARG(cin >= 1 && cin <= 8, "punet_conv3x3_small_fwd: cin must be 1..8 (got %d)", cin);
     PUNET_CHECK_ARG(cout >= 4 && cout % 4 == 0 && 256 % (cout / 4) == 0 && cout <= 1024,
                     "punet_conv3x3_small_fwd: cout/4 must divide 256 (got cout=%d)", cout);
     PUNET_CHECK_ARG((unsigned long long)W * (cin > cout ? cin : cout) < (1ull << 31), "punet_conv3x3_small_fwd: image row too long");
@@ -147,16 +159,22 @@ static int small_fwd_launch(bool out16, const float* x, int cin, const float* w,
     const int xiter = 8;
     const dim3 grid(ceil_div(W, ppb * xiter), B * H < 65535 ? B * H : 65535);
     float* yf = (float*)y;
+    const size_t wlds = cin > 4 ? (size_t)9 * cin * (cout / 4) * sizeof(float4) : 0;  // 5..8 channels: weights in LDS (<= 72 KB)
+    PUNET_CHECK_ARG(wlds <= 64 * 1024, "punet_conv3x3_small_fwd: cin %d x cout %d needs more than 64 KB of LDS for the weights", cin, cout);
 #define PUNET_SMALL_FWD(CI)                                                                                          \
     do {                                                                                                             \
-        if (out16) conv3x3_small_fwd_kernel<CI, true><<<grid, 256, 0, stream>>>(x, w, bias, yf, cout, B, H, W, relu, xiter); \
-        else conv3x3_small_fwd_kernel<CI, false><<<grid, 256, 0, stream>>>(x, w, bias, yf, cout, B, H, W, relu, xiter);      \
+        if (out16) conv3x3_small_fwd_kernel<CI, true><<<grid, 256, wlds, stream>>>(x, w, bias, yf, cout, B, H, W, relu, xiter); \
+        else conv3x3_small_fwd_kernel<CI, false><<<grid, 256, wlds, stream>>>(x, w, bias, yf, cout, B, H, W, relu, xiter);      \
     } while (0)
     switch (cin) {
         case 1: PUNET_SMALL_FWD(1); break;
         case 2: PUNET_SMALL_FWD(2); break;
         case 3: PUNET_SMALL_FWD(3); break;
-        default: PUNET_SMALL_FWD(4); break;
+        case 4: PUNET_SMALL_FWD(4); break;
+        case 5: PUNET_SMALL_FWD(5); break;
+        case 6: PUNET_SMALL_FWD(6); break;
+        case 7: PUNET_SMALL_FWD(7); break;
+        default: PUNET_SMALL_FWD(8); break;
     }
 #undef PUNET_SMALL_FWD
     PUNET_LAUNCH_CHECK("conv3x3_small_fwd");
@@ -174,7 +192,7 @@ extern "C" int punet_conv3x3_small_fwd_bf16s(const float* x, int cin, const floa
 }
 
 extern "C" size_t punet_small_wgrad_workspace_floats(int cin, int cout) {
-    return (size_t)SMALL_WGRAD_BLOCKS * (9 * cin + 1) * cout;
+    return (size_t)SMALL_WGRAD_BLOCKS * (9 * cin + 1) * cout;  // (5..8 channels run as two passes of <= 4: never more than this)
 }
 
 extern "C" int punet_conv3x3_small_wgrad(const float* x, int cin, const float* dz, int cout, float* dw, float* dbias,
@@ -182,7 +200,7 @@ extern "C" int punet_conv3x3_small_wgrad(const float* x, int cin, const float* d
                                          void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     PUNET_CHECK_ARG(x && dz && dw && dbias && workspace, "punet_conv3x3_small_wgrad: null pointer");
-    PUNET_CHECK_ARG(cin >= 1 && cin <= 4, "punet_conv3x3_small_wgrad: cin must be 1..4 (got %d)", cin);
+    PUNET_CHECK_ARG(cin >= 1 && cin <= 8, "punet_conv3x3_small_wgrad: cin must be 1..8 (got %d)", cin);
     PUNET_CHECK_ARG(cout >= 4 && cout % 4 == 0 && 64 % (cout / 4) == 0,
                     "punet_conv3x3_small_wgrad: cout/4 must divide 64 (got cout=%d)", cout);
     const size_t P = (size_t)B * H * W;
@@ -190,16 +208,22 @@ extern "C" int punet_conv3x3_small_wgrad(const float* x, int cin, const float* d
     const int groups = cout / 4;
     int grid = B * H;  // one image row per block and round
     if (grid > SMALL_WGRAD_BLOCKS) grid = SMALL_WGRAD_BLOCKS;
-    const int rows = 9 * cin + 1;
-    const size_t shmem = (size_t)4 * rows * groups * sizeof(float4);
-    switch (cin) {
-        case 1: conv3x3_small_wgrad_kernel<1><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W); break;
-        case 2: conv3x3_small_wgrad_kernel<2><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W); break;
-        case 3: conv3x3_small_wgrad_kernel<3><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W); break;
-        default: conv3x3_small_wgrad_kernel<4><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W); break;
+    // channel sub-ranges of at most 4 (the accumulators of a range live in registers); the bias gradient comes from the first
+    for (int c_off = 0; c_off < cin; c_off += 4) {
+        const int cs = cin - c_off < 4 ? cin - c_off : 4;
+        const int rows = 9 * cs + 1;
+        const size_t shmem = (size_t)4 * rows * groups * sizeof(float4);
+        switch (cs) {
+            case 1: conv3x3_small_wgrad_kernel<1><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W, cin, c_off); break;
+            case 2: conv3x3_small_wgrad_kernel<2><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W, cin, c_off); break;
+            case 3: conv3x3_small_wgrad_kernel<3><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W, cin, c_off); break;
+            default: conv3x3_small_wgrad_kernel<4><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W, cin, c_off); break;
+        }
+        PUNET_LAUNCH_CHECK("conv3x3_small_wgrad");
+        const size_t slab = (size_t)rows * cout;
+        const int rc = punet_launch_reduce_slabs_pair(workspace, slab, 9 * cs, cout, cs, cin, c_off, dw, workspace + (size_t)9 * cs * cout,
+                                                      slab, c_off == 0 ? dbias : nullptr, grid, accumulate, scale, stream);
+        if (rc != PUNET_OK) return rc;
     }
-    PUNET_LAUNCH_CHECK("conv3x3_small_wgrad");
-    const size_t slab = (size_t)rows * cout;
-    return punet_launch_reduce_slabs_pair(workspace, slab, 9 * cin, cout, cin, cin, 0, dw, workspace + (size_t)9 * cin * cout, slab,
-                                          dbias, grid, accumulate, scale, stream);
+    return PUNET_OK;
 }

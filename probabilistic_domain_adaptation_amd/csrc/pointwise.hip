@@ -1054,7 +1054,7 @@ int punet_launch_reduce_slabs_pair(const float* partial_w, size_t stride_w, int 
                                    int accumulate, float scale, hipStream_t stream) {
     const size_t n = (size_t)rows * cols;
     const int vec0 = (cols % 4 == 0 && stride_w % 4 == 0 && ((uintptr_t)partial_w & 15) == 0 && ((uintptr_t)out_w & 15) == 0) ? 4 : 1;
-    const unsigned nb0 = (unsigned)((n / vec0 + 31) / 32), nb1 = (unsigned)((cols + 31) / 32);
+    const unsigned nb0 = (unsigned)((n / vec0 + 31) / 32), nb1 = out_b ? (unsigned)((cols + 31) / 32) : 0u;  // out_b may be null
     SlabJob j0{partial_w, stride_w, rows, cols, cs, cin_total, ci_off, out_w};
     SlabJob j1{partial_b, stride_b, 1, cols, 1, 1, 0, out_b};
     reduce_slabs_pair_kernel<<<nb0 + nb1, 256, 0, stream>>>(j0, j1, nb0, vec0, nslices, accumulate, scale);

@@ -53,6 +53,9 @@ class ConvP:
         return self.k * self.k * self.cin * self.cout
 
 
+SMALL_CIN = 7  # first layers (image, or [image, mask] of the posterior) with up to 7 channels run through the K1s kernels
+
+
 class ParamLayout:
     """Flat layout of all parameters; names and logical shapes follow the reference state-dict (M0)."""
 
@@ -68,8 +71,8 @@ class ParamLayout:
         if nf[0] not in (32, 64) or any(f % 8 for f in nf):
             raise ValueError("num_filters must be multiples of 8 (the MFMA kernels contract 8 channels per K block) with "
                              "num_filters[0] in {32, 64} (the Fcomb sampler keeps one pixel's channels in registers)")
-        if not 1 <= input_channels <= 3:
-            raise ValueError("input_channels must be 1..3")
+        if not (input_channels >= 1 and input_channels + num_classes <= SMALL_CIN):
+            raise ValueError(f"input_channels + num_classes must be <= {SMALL_CIN} (the first-layer kernels; the posterior sees both)")
         if no_convs_fcomb < 2:
             raise ValueError("no_convs_fcomb must be >= 2")
         self.input_channels, self.num_classes, self.nf = input_channels, num_classes, nf
@@ -300,7 +303,7 @@ class PUNetEngine:
         assert cin == c.cin, (name, cin, c.cin)
         if self._infer16 and c.k == 3:  # bf16 activation storage ("bf16s"): the gradients, if any follow, stay fp32
             y = Act(torch.empty(B, H, W, c.cout, dtype=torch.bfloat16, device=self.device), B, H, W, c.cout, relu_out=relu)
-            if cin <= 4:
+            if cin <= SMALL_CIN:
                 _lib.call("punet_conv3x3_small_fwd_bf16s", x0.ptr, cin, self._wptr(flat, c), self._bptr(flat, c), y.ptr, c.cout, B, H,
                           W, int(relu), _stream())
                 if relu and tape is not None:  # the first-layer kernel publishes no gate bits: one small pass makes them
@@ -325,7 +328,7 @@ class PUNetEngine:
                 taps["conv:" + name] = y
             return y
         y = Act(self._empty(B, H, W, c.cout), B, H, W, c.cout, relu_out=relu)
-        if cin <= 4:
+        if cin <= SMALL_CIN:
             assert x1 is None and c.k == 3
             _lib.call("punet_conv3x3_small_fwd", x0.ptr, cin, self._wptr(flat, c), self._bptr(flat, c), y.ptr, c.cout,
                       B, H, W, int(relu), _stream())
@@ -647,7 +650,7 @@ class PUNetEngine:
         B, H, W = x.B, x.H, x.W
         dw = gflat.data_ptr() + 4 * c.w_off
         db = gflat.data_ptr() + 4 * c.b_off
-        if c.cin <= 4:
+        if c.cin <= SMALL_CIN:
             ws = self.ws.get("wgrad", _lib.call("punet_small_wgrad_workspace_floats", c.cin, c.cout))
             _lib.call("punet_conv3x3_small_wgrad", x.ptr, c.cin, dz.data_ptr(), c.cout, dw, db, ws.data_ptr(), B, H, W,
                       int(accumulate), 1.0, _stream())
@@ -680,7 +683,7 @@ class PUNetEngine:
         if self._x6_table is None:
             rows, units = [], 0
             for c in self.L.convs.values():
-                if c.k == 3 and c.cin > 4:
+                if c.k == 3 and c.cin > SMALL_CIN:
                     rows.append([c.w_off, c.cin, c.cout, units])
                     units += c.w_numel // 8
             rows.append([0, 0, 0, units])
@@ -726,7 +729,7 @@ class PUNetEngine:
         for c in self.L.convs.values():
             if (self.x6 and c.k == 3) or c.name in served:
                 continue  # served by the x6 planes
-            if c.cin > 4 and c.cin % 4 == 0 and c.cout % 8 == 0:
+            if c.cin > SMALL_CIN and c.cin % 4 == 0 and c.cout % 8 == 0:
                 _lib.call("punet_flip_transpose_weights", self._wptr(flat, c), self.wT.data_ptr() + 4 * c.w_off, c.cin, c.cout,
                           c.k, _stream())
 
