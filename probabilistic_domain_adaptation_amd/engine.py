@@ -66,8 +66,8 @@ class ParamLayout:
         nf = list(num_filters)
         self.kind = kind
         pre = "unet." if kind == "punet" else ""
-        if num_classes != 1:
-            raise ValueError("the HIP path implements num_classes == 1 (every reference script uses 1)")
+        if num_classes < 1:
+            raise ValueError("num_classes must be >= 1")
         if nf[0] not in (32, 64) or any(f % 8 for f in nf):
             raise ValueError("num_filters must be multiples of 8 (the MFMA kernels contract 8 channels per K block) with "
                              "num_filters[0] in {32, 64} (the Fcomb sampler keeps one pixel's channels in registers)")
@@ -464,6 +464,15 @@ class PUNetEngine:
             stride = 0
         return c1, c3, nmid, wmid, bmid, stride
 
+    def _last_layer_rows(self, flat):
+        """fcomb.last_layer for num_classes = K > 1 (no reference script uses it): the kernels take ONE class's CH weights as
+        a contiguous row, the parameter is stored [CH][K] - per-class rows [K, CH] and biases [K] as small device copies."""
+        c3 = self.L.convs["fcomb.last_layer"]
+        K, CH = c3.cout, c3.cin
+        w = flat[c3.w_off:c3.w_off + CH * K].view(CH, K).t().contiguous()
+        b = flat[c3.b_off:c3.b_off + K].contiguous()
+        return w, b
+
     def sample(self, flat, feat: Act, z: torch.Tensor, upper=0.9, lower=0.1, masking=False, want_logits=False,
                want_consensus=True):
         """N Monte-Carlo samples through Fcomb + consensus (K7).  z: [N, B, L] latent draws.
@@ -475,18 +484,30 @@ class PUNetEngine:
         _lib.call("punet_fcomb_zbias", z.data_ptr(), self._wptr(flat, c1), self._bptr(flat, c1), zb.data_ptr(), N * B, Ld, CH,
                   _stream())
         HW = feat.H * feat.W
-        y = self._empty(B, 1, feat.H, feat.W) if want_consensus else None
-        cz = self._empty(B, 1, feat.H, feat.W) if want_consensus else None
-        logits = self._empty(N, B, 1, feat.H, feat.W) if want_logits else None
         # split-plane arithmetic on the BF16 matrix cores in every x6-family mode (always six products: parity), fp32 MFMA in "f32"
         fn = "punet_fcomb_sample_x6_bf16s" if feat.t.dtype == torch.bfloat16 else \
             ("punet_fcomb_sample_x6" if self.x6 and self.sampler_x6 else "punet_fcomb_sample")
-        _lib.call(fn, feat.ptr, self._wptr(flat, c1),
-                  zb.data_ptr(), wmid, stride, bmid, stride,
-                  self._wptr(flat, c3), self._bptr(flat, c3), y.data_ptr() if y is not None else None,
-                  cz.data_ptr() if cz is not None else None, logits.data_ptr() if logits is not None else None, N, B, HW,
-                  CH, nmid, float(upper), float(lower), int(masking), _stream())
-        return y, cz, logits
+        K = c3.cout
+        if K == 1:
+            w3s, b3s = [self._wptr(flat, c3)], [self._bptr(flat, c3)]
+        else:  # one launch per class (the hidden layers are recomputed: a rarely used configuration, kept simple)
+            w3k, b3k = self._last_layer_rows(flat)
+            w3s, b3s = [w3k[k].data_ptr() for k in range(K)], [b3k.data_ptr() + 4 * k for k in range(K)]
+        ys, czs, lgs = [], [], []
+        for k in range(K):
+            y = self._empty(B, 1, feat.H, feat.W) if want_consensus else None
+            cz = self._empty(B, 1, feat.H, feat.W) if want_consensus else None
+            logits = self._empty(N, B, 1, feat.H, feat.W) if want_logits else None
+            _lib.call(fn, feat.ptr, self._wptr(flat, c1),
+                      zb.data_ptr(), wmid, stride, bmid, stride,
+                      w3s[k], b3s[k], y.data_ptr() if y is not None else None,
+                      cz.data_ptr() if cz is not None else None, logits.data_ptr() if logits is not None else None, N, B, HW,
+                      CH, nmid, float(upper), float(lower), int(masking), _stream())
+            ys.append(y), czs.append(cz), lgs.append(logits)
+        if K == 1:
+            return ys[0], czs[0], lgs[0]
+        return (torch.cat(ys, 1) if want_consensus else None, torch.cat(czs, 1) if want_consensus else None,
+                torch.cat(lgs, 2) if want_logits else None)
 
     def reparam(self, muls: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
         """z = mu + exp(log_sigma) * eps for eps [N, B, L] (Normal.rsample; probabilistic_unet.py:302,349)."""
@@ -537,9 +558,11 @@ class PUNetEngine:
         st = {"B": B, "H": H, "W": W, "recorded": bool(record)}
         self.prepare_forward_weights(flat)
         xin = Act(x_nhwc, B, H, W, C, needs_grad=False)
-        xq_t = self._empty(B, H, W, C + 1)  # torch.cat([patch, segm], 1) (probabilistic_unet.py:118), NHWC
-        _lib.call("punet_concat_nhwc", x_nhwc.data_ptr(), C, segm.data_ptr(), 1, xq_t.data_ptr(), B * H * W, _stream())
-        xq = Act(xq_t, B, H, W, C + 1, needs_grad=False)
+        K = self.L.num_classes
+        seg_nhwc = segm if K == 1 else self.to_nhwc(segm)  # [B,1,H,W] is its own NHWC form
+        xq_t = self._empty(B, H, W, C + K)  # torch.cat([patch, segm], 1) (probabilistic_unet.py:118), NHWC
+        _lib.call("punet_concat_nhwc", x_nhwc.data_ptr(), C, seg_nhwc.data_ptr(), K, xq_t.data_ptr(), B * H * W, _stream())
+        xq = Act(xq_t, B, H, W, C + K, needs_grad=False)
         tq = [] if record else None
         tp = [] if record else None
         tu = [] if record else None
@@ -580,7 +603,8 @@ class PUNetEngine:
         _lib.call("punet_fcomb_zbias", zf.data_ptr(), self._wptr(flat, c1), self._bptr(flat, c1), zb.data_ptr(), B, Ld, CH,
                   _stream())
         nmid = len(L.fcomb_mid)
-        if (record and loss_kind == "bce" and taps is None and self.fuse_fcomb
+        K = c3.cout
+        if (record and loss_kind == "bce" and taps is None and self.fuse_fcomb and K == 1
                 and _lib.call("punet_fcomb_train_supported", CH, nmid, H * W)):
             # K7t: forward, criterion and the whole Fcomb backward in one kernel; the weight-gradient slabs wait in `ws` for
             # elbo_backward (a fresh buffer per pass: the joint trainers hold two passes' worth between forward and backward)
@@ -621,16 +645,31 @@ class PUNetEngine:
             h = self.conv(flat, nm, h, None, True, None, taps, tape_bits=record)
             hs.append(h)
         P = B * H * W
-        logits = self._empty(B, 1, H, W)
-        _lib.call("punet_dot_bias", h.ptr, self._wptr(flat, c3), self._bptr(flat, c3), logits.data_ptr(), P, CH, _stream())
-        dlogit = self._empty(B, 1, H, W) if record else None
+        # num_classes = K > 1: the last layer, the criterion and their backward run in a class-major [K, B, H, W] layout (one
+        # dot-product launch per class, the element-wise criterion over K * P elements); the facade permutes at the boundary
+        if K == 1:
+            logits = self._empty(B, 1, H, W)
+            _lib.call("punet_dot_bias", h.ptr, self._wptr(flat, c3), self._bptr(flat, c3), logits.data_ptr(), P, CH, _stream())
+            tgt_k, cm_k, lg_k = y_tgt, consm, logits
+        else:
+            w3k, b3k = self._last_layer_rows(flat)
+            lg_k = self._empty(K, B, H, W)
+            for k in range(K):
+                _lib.call("punet_dot_bias", h.ptr, w3k[k].data_ptr(), b3k.data_ptr() + 4 * k, lg_k[k].data_ptr(), P, CH, _stream())
+            tgt_k = y_tgt.permute(1, 0, 2, 3).contiguous()
+            cm_k = consm.permute(1, 0, 2, 3).contiguous() if consm is not None else None
+            logits = lg_k.permute(1, 0, 2, 3).contiguous()
+        dlogit = torch.empty_like(lg_k) if record else None
         rec = self._empty(1)
         wsl = self.ws.get("loss", _lib.call("punet_loss_workspace_floats"))
-        cm = consm.data_ptr() if consm is not None else None
+        cm = cm_k.data_ptr() if cm_k is not None else None
         if loss_kind == "bce":
-            _lib.call("punet_bce_fwd_bwd", logits.data_ptr(), y_tgt.data_ptr(), cm, float(gscale),
-                      dlogit.data_ptr() if record else None, rec.data_ptr(), wsl.data_ptr(), P, _stream())
+            _lib.call("punet_bce_fwd_bwd", lg_k.data_ptr(), tgt_k.data_ptr(), cm, float(gscale),
+                      dlogit.data_ptr() if record else None, rec.data_ptr(), wsl.data_ptr(), K * P, _stream())
         elif loss_kind == "dice":
+            if K != 1:
+                raise NotImplementedError("the Dice criterion (recalled torch_em definition, parity unpinned) is implemented for "
+                                          "num_classes == 1")
             if dlogit is None:
                 dlogit = self._empty(B, 1, H, W)
             _lib.call("punet_dice_fwd_bwd", logits.data_ptr(), y_tgt.data_ptr(), cm, float(gscale), dlogit.data_ptr(),
@@ -849,8 +888,27 @@ class PUNetEngine:
         # last layer C -> 1
         dz_h = torch.empty_like(hs[-1].t)
         ws = self.ws.get("dot", _lib.call("punet_dot_bwd_workspace_floats", CH))
-        _lib.call("punet_dot_bwd", hs[-1].ptr, st["dlogit"].data_ptr(), self._wptr(flat, c3), dz_h.data_ptr(),
-                  gflat.data_ptr() + 4 * c3.w_off, gflat.data_ptr() + 4 * c3.b_off, ws.data_ptr(), P, CH, acc, _stream())
+        K = c3.cout
+        if K == 1:
+            _lib.call("punet_dot_bwd", hs[-1].ptr, st["dlogit"].data_ptr(), self._wptr(flat, c3), dz_h.data_ptr(),
+                      gflat.data_ptr() + 4 * c3.w_off, gflat.data_ptr() + 4 * c3.b_off, ws.data_ptr(), P, CH, acc, _stream())
+        else:  # per class (dlogit is class-major [K, B, H, W]); the K contributions to d h and the [CH][K] weight layout by ATen
+            w3k, _ = self._last_layer_rows(flat)
+            dw3k, db3k, part = self._empty(K, CH), self._empty(K), torch.empty_like(dz_h)
+            for k in range(K):
+                _lib.call("punet_dot_bwd", hs[-1].ptr, st["dlogit"][k].data_ptr(), w3k[k].data_ptr(),
+                          (dz_h if k == 0 else part).data_ptr(), dw3k[k].data_ptr(), db3k.data_ptr() + 4 * k, ws.data_ptr(), P, CH,
+                          0, _stream())
+                if k:
+                    dz_h += part
+            gw = gflat[c3.w_off:c3.w_off + CH * K].view(CH, K)
+            gb = gflat[c3.b_off:c3.b_off + K]
+            if accumulate:
+                gw += dw3k.t()
+                gb += db3k
+            else:
+                gw.copy_(dw3k.t())
+                gb.copy_(db3k)
         # middle 1x1 layers, last to first
         for k in range(len(L.fcomb_mid) - 1, -1, -1):
             c = L.convs[L.fcomb_mid[k]]

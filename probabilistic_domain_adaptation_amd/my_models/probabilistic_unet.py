@@ -167,7 +167,7 @@ class ProbabilisticUnet(nn.Module):
         return eps
 
     def _b1hw(self, t, B, H, W):
-        return t.to(device=self.device, dtype=torch.float32).reshape(B, 1, H, W).contiguous()
+        return t.to(device=self.device, dtype=torch.float32).reshape(B, self.num_classes, H, W).contiguous()
 
     def forward(self, patch, segm, training=True):
         """probabilistic_unet.py:285-293.  Returns None; stores posterior_latent_space (training only),

@@ -54,7 +54,8 @@ def predict_image(model, image: np.ndarray, prior_samples: int = 8, block_shape=
     ONE all_reduce(sum) of the output; every rank returns the full map."""
     assert image.ndim == 2, "2-D single-channel images (every reference script uses input_channels=1)"
     H, W = image.shape
-    out = np.zeros((H, W), dtype="float32")
+    K = getattr(model, "num_classes", 1)
+    out = np.zeros((H, W) if K == 1 else (K, H, W), dtype="float32")  # one map per class for num_classes > 1
     oh = -(-(block_shape[0] + 2 * halo[0]) // multiple_of) * multiple_of  # outer tile (512 x 512 for 384 / 64)
     ow = -(-(block_shape[1] + 2 * halo[1]) // multiple_of) * multiple_of
     img = image.astype("float32")
@@ -78,9 +79,10 @@ def predict_image(model, image: np.ndarray, prior_samples: int = 8, block_shape=
         chunk = items[i:i + tile_batch]
         raw = torch.from_numpy(np.stack([t for _, t in chunk])[:, None]).to(dev)
         e = None if eps is None else torch.as_tensor(eps)[i:i + len(chunk)].transpose(0, 1).contiguous()  # [N, tiles, L]
-        pred = mc_prediction(model, raw, prior_samples, eps=e).cpu().numpy()[:, 0]
+        pred = mc_prediction(model, raw, prior_samples, eps=e).cpu().numpy()
+        pred = pred[:, 0] if K == 1 else pred
         for k, ((y0, y1, x0, x1), _) in enumerate(chunk):
-            out[y0:y1, x0:x1] = pred[k, halo[0]:halo[0] + (y1 - y0), halo[1]:halo[1] + (x1 - x0)]
+            out[..., y0:y1, x0:x1] = pred[k][..., halo[0]:halo[0] + (y1 - y0), halo[1]:halo[1] + (x1 - x0)]
     if world > 1:  # every pixel was written by exactly one rank, the others hold 0 there
         joined = torch.from_numpy(out).to(dev)
         dist.all_reduce(joined, op=dist.ReduceOp.SUM)
@@ -96,6 +98,8 @@ def pseudo_predict_image(model, image: np.ndarray, prior_samples: int = 8, upper
     patch = torch.from_numpy(standardize(image))[None, None].to(model.device)
     model.forward(patch, None, training=False)
     y, z = model.sample_consensus(prior_samples, upper_threshold, lower_threshold, masking=True, eps=eps)
+    if getattr(model, "num_classes", 1) > 1:
+        return y[0].cpu().numpy(), z[0].cpu().numpy().astype("uint8")
     return y[0, 0].cpu().numpy(), z[0, 0].cpu().numpy().astype("uint8")
 
 

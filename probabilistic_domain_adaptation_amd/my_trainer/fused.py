@@ -217,10 +217,10 @@ def elbo_grad_pass(model: ProbabilisticUnet, gflat, x, y, z, eps, gscale: float,
     B = x.shape[0]
     xn = eng.to_nhwc(x)
     H, W = xn.shape[1], xn.shape[2]
-    yt = y.to(device=model.device, dtype=torch.float32).reshape(B, 1, H, W).contiguous()
+    yt = y.to(device=model.device, dtype=torch.float32).reshape(B, model.num_classes, H, W).contiguous()
     cm = None
     if model.consensus_masking is True and z is not None:
-        cm = z.to(device=model.device, dtype=torch.float32).reshape(B, 1, H, W).contiguous()
+        cm = z.to(device=model.device, dtype=torch.float32).reshape(B, model.num_classes, H, W).contiguous()
     e = model._eps(1, B, eps)[0]
     st = eng.elbo_forward(model.flat_params, xn, yt, cm, e, "dice" if model.rl_swap else "bce", model.beta, gscale, True)
     started = {}

@@ -167,9 +167,10 @@ def tensor_digest(t):
     return np.concatenate([[np.sqrt((a.astype(np.float64) ** 2).sum())], a[idx].astype(np.float64)])
 
 
-def gen_model_case(name, nf, fixed, B, C, H, W, n_list, full_grads, seeds=(0, 1, 2)):
+def gen_model_case(name, nf, fixed, B, C, H, W, n_list, full_grads, seeds=(0, 1, 2), K=1):
     out = {}
-    cfg = O.PUNetConfig(C, 1, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    cfg = O.PUNetConfig(C, K, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    out["num_classes"] = np.array([K], dtype=np.int64)
     m, Pnp = make_ref_model(cfg, seeds[1], fixed)
     x, x1, x2, y = O.synth_batch(B, C, H, W, seeds[0])
     out["meta"] = np.array([B, C, H, W, seeds[0], seeds[1], seeds[2], int(fixed)] + list(nf), dtype=np.int64)
@@ -646,6 +647,9 @@ if __name__ == "__main__":
     if "--only-validate" in sys.argv:
         gen_validate_case("validate_small", [32, 64, 64, 96], B=2, H=32, W=32, n_samples=4)
         sys.exit(0)
+    if "--only-classes" in sys.argv:
+        gen_model_case("two_classes", [32, 32, 64, 64], fixed=True, B=2, C=2, H=32, W=40, n_list=[4], full_grads=False, K=2)
+        sys.exit(0)
     if "--only-unet" in sys.argv:
         gen_plain_unet_case("plain_unet_256", [64, 128, 256, 512], 256, 256)
         sys.exit(0)
@@ -661,6 +665,8 @@ if __name__ == "__main__":
     gen_model_case("fixed_rgb", [32, 32, 64, 64], fixed=True, B=1, C=3, H=48, W=88, n_list=[4], full_grads=False)
     # (4) the scripts' filters (LIVECell/livecell_punet.py:50) at a small patch
     gen_model_case("full_nf", [64, 128, 256, 512], fixed=True, B=1, C=1, H=64, W=64, n_list=[4], full_grads=False)
+    # (4b) num_classes = 2 (and two input channels): Fcomb's last layer, the posterior's input and the criterion per class
+    gen_model_case("two_classes", [32, 32, 64, 64], fixed=True, B=2, C=2, H=32, W=40, n_list=[4], full_grads=False, K=2)
     # (5) one real iteration of every PUNet trainer
     gen_trainer_case("trainers_small", [32, 64, 64, 96], B=2, H=32, W=32, n_samples=4)
     # (5b) model-API corners, validation loops, prediction bodies

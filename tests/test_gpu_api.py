@@ -246,3 +246,51 @@ def test_predict_image_reference_geometry_against_oracle_tiling(case, dev):
     ref = O.tiled_prediction(O.to_torch(case["Pnp"]), case["cfg"], img, [eps[t][:, None] for t in range(nt)])
     pred = predict_image(m, img, prior_samples=n, tile_batch=3, eps=eps)
     assert pred.shape == img.shape and np.abs(pred - ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_two_classes_facade_and_mean_teacher_step(dev, fused):
+    """num_classes = 2 with two input channels (no reference script uses it; `two_classes.npz` pins the model level against the
+    reference): the facade's sample() / sample_consensus() / elbo() shapes and values, and one Mean-Teacher iteration (fused and
+    drop-in) against the oracle's mean_teacher_step."""
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam, MeanTeacherTrainer
+    nf, B, C, K, H, W, n = [32, 32, 64, 64], 2, 2, 2, 32, 40, 4
+    cfg = O.PUNetConfig(C, K, nf, L, 3, 1.0, consensus_masking=True, rl_swap=False)
+    Pnp = O.synth_params(cfg.spec(), 31)
+    x, x1, x2, _ = O.synth_batch(B, C, H, W, 32)
+    g = lambda k, seed: torch.randn(k, B, L, generator=torch.Generator().manual_seed(seed))
+    m = ProbabilisticUnet(C, K, nf, L, 3, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in Pnp.items()})
+    Po = O.to_torch(Pnp)
+    with torch.no_grad():
+        m.forward(x1.to(dev), None, training=False)
+        lg = m.sample(testing=True, eps=g(1, 5))
+        y, z = m.sample_consensus(n, masking=True, eps=g(n, 6))
+        so = O.punet_forward(Po, cfg, x1, None, False)
+        yo, zo = O.sample_consensus(Po, cfg, x1, g(n, 6), masking=True)
+    assert tuple(y.shape) == (B, K, H, W) and tuple(z.shape) == (B, K, H, W)
+    assert tuple(lg.shape) == (B, K, H, W)
+    assert (lg.cpu() - O.punet_sample(Po, cfg, so, g(1, 5)[0])).abs().max().item() < 1e-3
+    assert (y.cpu() - yo).abs().max().item() < 1e-4 and int((z.cpu() != zo).sum()) == 0
+    # one Mean-Teacher iteration
+    opt = FusedAdam(m, lr=1e-3) if fused else torch.optim.Adam(m.parameters(), lr=1e-3)
+    tr = MeanTeacherTrainer(name=None, train_loader=[(x, x1, x2, torch.zeros(B, K, H, W))], val_loader=None, model=m, optimizer=opt,
+                            device=dev, do_consensus_masking=True)
+    tr.n_samples = n
+    tr.momentum_update_is_activated = True
+    q = {"teacher": [g(n, 7)], "student": [g(1, 8)]}
+    tr.eps_source = lambda kind, k, b: q[kind].pop(0)
+
+    class _P:
+        def update(self, *a):
+            pass
+
+    tr._train_epoch_impl(_P(), contextlib.nullcontext, lambda loss: (loss.backward(), opt.step()))
+    torch.cuda.synchronize()
+    Ps, Pt = O.to_torch(Pnp, True), O.to_torch(Pnp)
+    ref = O.mean_teacher_step(Ps, Pt, cfg, O.AdamState(Ps, lr=1e-3), x1, x2, g(n, 7), g(1, 8)[0], True)
+    np.testing.assert_allclose(float(tr.last_loss), ref["loss"].item(), rtol=2e-4)
+    sd = {k: v.detach().cpu() for k, v in tr.model.state_dict().items()}
+    for k, v in Ps.items():  # Adam's first step moves every entry by ~lr: compare the parameters after the step
+        assert (sd[k] - v.detach()).abs().max().item() <= 2.5e-4, k  # a gradient within rounding of 0 may flip sign(g): 2 lr at most

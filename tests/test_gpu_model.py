@@ -12,7 +12,7 @@ from oracle import punet_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["uniform32_literal", "fixed_small", "fixed_rgb", "full_nf"]
+CASES = ["uniform32_literal", "fixed_small", "fixed_rgb", "full_nf", "two_classes"]  # two_classes: num_classes = 2, C = 2
 LOGIT_TOL = 1e-3
 
 
@@ -33,9 +33,10 @@ def _setup(golden_dir, name, dev):
     meta = fx["meta"]
     B, C, H, W, s0, s1, s2, fixed = [int(v) for v in meta[:8]]
     nf = [int(v) for v in meta[8:]]
-    cfg = O.PUNetConfig(C, 1, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    K = int(fx["num_classes"][0]) if "num_classes" in fx.files else 1
+    cfg = O.PUNetConfig(C, K, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
     Pnp = O.synth_params(cfg.spec(), s1)
-    lay = ParamLayout(C, 1, nf, 6, 3)
+    lay = ParamLayout(C, K, nf, 6, 3)
     eng = PUNetEngine(lay, dev)
     flat = torch.zeros(lay.numel, device=dev)
     views = lay.views(flat)

@@ -8,7 +8,7 @@ import torch
 
 from oracle import punet_oracle as O
 
-CASES = ["uniform32_literal", "fixed_small", "fixed_rgb", "full_nf"]
+CASES = ["uniform32_literal", "fixed_small", "fixed_rgb", "full_nf", "two_classes"]  # two_classes: num_classes = 2, C = 2
 
 
 def _load(golden_dir, name):
@@ -19,7 +19,8 @@ def _setup(fx):
     meta = fx["meta"]
     B, C, H, W, s0, s1, s2, fixed = [int(v) for v in meta[:8]]
     nf = [int(v) for v in meta[8:]]
-    cfg = O.PUNetConfig(C, 1, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    K = int(fx["num_classes"][0]) if "num_classes" in fx.files else 1
+    cfg = O.PUNetConfig(C, K, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
     Pnp = O.synth_params(cfg.spec(), s1)
     batch = O.synth_batch(B, C, H, W, s0)
     return cfg, Pnp, batch, (B, C, H, W, s0, s1, s2)
