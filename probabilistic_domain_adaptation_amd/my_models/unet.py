@@ -54,7 +54,16 @@ class Unet(nn.Module):
         if not self.apply_last_layer:
             return feat.t.permute(0, 3, 1, 2)
         c = self.layout.convs["last_layer"]
-        out = torch.empty(B, 1, H, W, dtype=torch.float32, device=self.device)
-        _lib.call("punet_dot_bias", feat.ptr, self._flat.data_ptr() + 4 * c.w_off, self._flat.data_ptr() + 4 * c.b_off,
-                  out.data_ptr(), B * H * W, feat.C, _stream())
-        return out
+        K, CH = c.cout, c.cin
+        if K == 1:
+            out = torch.empty(B, 1, H, W, dtype=torch.float32, device=self.device)
+            _lib.call("punet_dot_bias", feat.ptr, self._flat.data_ptr() + 4 * c.w_off, self._flat.data_ptr() + 4 * c.b_off,
+                      out.data_ptr(), B * H * W, feat.C, _stream())
+            return out
+        # num_classes > 1 (no reference script): one dot product per class on its contiguous weight row (stored [CH][K])
+        w = self._flat[c.w_off:c.w_off + CH * K].view(CH, K).t().contiguous()
+        out = torch.empty(K, B, H, W, dtype=torch.float32, device=self.device)
+        for k in range(K):
+            _lib.call("punet_dot_bias", feat.ptr, w[k].data_ptr(), self._flat.data_ptr() + 4 * (c.b_off + k), out[k].data_ptr(),
+                      B * H * W, feat.C, _stream())
+        return out.permute(1, 0, 2, 3).contiguous()

@@ -226,6 +226,23 @@ def test_plain_unet_config0(golden_dir, dev):
     assert np.abs(y.cpu().numpy() - fx["logits"]).max() < 1e-3
 
 
+def test_plain_unet_three_classes_three_channels(dev):
+    """Unet(3, 3, ...): the 1x1 last layer with num_classes > 1 against the oracle's plain Unet."""
+    from probabilistic_domain_adaptation_amd.my_models import Unet
+    nf = [32, 32, 64, 64]
+    spec = O.plain_unet_spec(3, 3, nf, True)
+    Pnp = O.synth_params(spec, 5)
+    m = Unet(3, 3, nf, {'w': 'he_normal', 'b': 'normal'}, apply_last_layer=True, padding=True, device=dev, seed=0)
+    assert list(m.state_dict().keys()) == list(spec.keys())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in Pnp.items()})
+    x, _, _, _ = O.synth_batch(2, 3, 32, 48, 6)
+    y = m(x.to(dev), False)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.plain_unet_forward(O.to_torch(Pnp), x, len(nf), True)
+    assert tuple(y.shape) == (2, 3, 32, 48) and (y.cpu() - ref).abs().max().item() < 1e-3
+
+
 def _mt_trainer(case, dev, tmp_path, fused=True, n_batches=2, **kw):
     from probabilistic_domain_adaptation_amd.my_trainer import MeanTeacherTrainer
     m = _model(case, dev)
