@@ -68,9 +68,13 @@ class ParamLayout:
         pre = "unet." if kind == "punet" else ""
         if num_classes < 1:
             raise ValueError("num_classes must be >= 1")
-        if nf[0] not in (32, 64) or any(f % 8 for f in nf):
-            raise ValueError("num_filters must be multiples of 8 (the MFMA kernels contract 8 channels per K block) with "
-                             "num_filters[0] in {32, 64} (the Fcomb sampler keeps one pixel's channels in registers)")
+        if any(f % 8 or f < 8 for f in nf):
+            raise ValueError("num_filters must be multiples of 8 (the MFMA kernels contract 8 channels per K block)")
+        if nf[0] not in (8, 16, 32, 64, 128, 256):
+            raise ValueError("num_filters[0] must be a power of two in 8..256 (the first-layer kernels give every thread four "
+                             "output channels of a pixel: num_filters[0] / 4 has to divide the block)")
+        # num_filters[0] in {32, 64} (the reference's default and every script): the fused Fcomb kernels K7 / K7x / K7t, which
+        # keep one pixel's channels in registers; any other multiple of 8 runs Fcomb layer by layer (correct, not tuned)
         if not (input_channels >= 1 and input_channels + num_classes <= SMALL_CIN):
             raise ValueError(f"input_channels + num_classes must be <= {SMALL_CIN} (the first-layer kernels; the posterior sees both)")
         if no_convs_fcomb < 2:
@@ -464,6 +468,31 @@ class PUNetEngine:
             stride = 0
         return c1, c3, nmid, wmid, bmid, stride
 
+    def _fcomb_hidden(self, flat, feat: Act, zb_ptr: int, record=False, taps=None):
+        """The hidden layers of Fcomb for ONE latent sample, layer by layer (probabilistic_unet.py:200-214): layers.0 on the
+        features with the z term as a per-image bias (zb_ptr: [B][CH]), then the middle layers.  Returns their activations."""
+        L = self.L
+        B, H, W, CH = feat.B, feat.H, feat.W, L.nf[0]
+        c1 = L.convs["fcomb.layers.0"]
+        h = Act(self._empty(B, H, W, CH), B, H, W, CH, relu_out=True)
+        p1 = self._x6_1x1.get((flat.data_ptr(), 0), {}).get(c1.name) if self.x6 else None
+        if p1 is not None:
+            if record:
+                h.bits = torch.empty(_lib.call("punet_gate_dwords", B, H, W, CH), dtype=torch.int32, device=self.device)
+            self._timed("conv1x1_fwd", 2.0 * B * H * W * CH * CH, "punet_conv1x1_x6_gated", feat.ptr, CH, None, 0, p1.data_ptr(),
+                        CH * CH, CH, 0, zb_ptr, CH, h.ptr, CH, None, None,
+                        h.bits.data_ptr() if h.bits is not None else None, 0, 1, B, H, W, _stream())
+        else:
+            _lib.call("punet_conv_fwd", feat.ptr, CH, None, 0, self._wptr(flat, c1), zb_ptr, CH, h.ptr, CH, B, H, W, 1, 1,
+                      _stream())
+        hs = [h]
+        if taps is not None:
+            taps["conv:fcomb.layers.0"] = h
+        for nm in L.fcomb_mid:
+            h = self.conv(flat, nm, h, None, True, None, taps, tape_bits=record)
+            hs.append(h)
+        return hs
+
     def _last_layer_rows(self, flat):
         """fcomb.last_layer for num_classes = K > 1 (no reference script uses it): the kernels take ONE class's CH weights as
         a contiguous row, the parameter is stored [CH][K] - per-class rows [K, CH] and biases [K] as small device copies."""
@@ -488,6 +517,28 @@ class PUNetEngine:
         fn = "punet_fcomb_sample_x6_bf16s" if feat.t.dtype == torch.bfloat16 else \
             ("punet_fcomb_sample_x6" if self.x6 and self.sampler_x6 else "punet_fcomb_sample")
         K = c3.cout
+        if CH not in (32, 64):  # outside the fused sampler's domain: Fcomb layer by layer per sample, then the consensus kernel K8
+            if feat.t.dtype != torch.float32:
+                feat = Act(feat.t.float(), B, feat.H, feat.W, CH, relu_out=True)
+            P = B * HW
+            if K == 1:
+                w3s, b3s = [self._wptr(flat, c3)], [self._bptr(flat, c3)]
+            else:
+                w3k, b3k = self._last_layer_rows(flat)
+                w3s, b3s = [w3k[k].data_ptr() for k in range(K)], [b3k.data_ptr() + 4 * k for k in range(K)]
+            lg = self._empty(K, N, B, feat.H, feat.W)
+            for n in range(N):
+                h = self._fcomb_hidden(flat, feat, zb[n].data_ptr())[-1]
+                for k in range(K):
+                    _lib.call("punet_dot_bias", h.ptr, w3s[k], b3s[k], lg[k, n].data_ptr(), P, CH, _stream())
+            y = cz = None
+            if want_consensus:
+                y, cz = self._empty(K, B, feat.H, feat.W), self._empty(K, B, feat.H, feat.W)
+                for k in range(K):
+                    _lib.call("punet_consensus", lg[k].data_ptr(), N, P, float(upper), float(lower), int(masking), y[k].data_ptr(),
+                              cz[k].data_ptr(), _stream())
+                y, cz = y.permute(1, 0, 2, 3).contiguous(), cz.permute(1, 0, 2, 3).contiguous()
+            return y, cz, lg.permute(1, 2, 0, 3, 4).contiguous() if want_logits else None
         if K == 1:
             w3s, b3s = [self._wptr(flat, c3)], [self._bptr(flat, c3)]
         else:  # one launch per class (the hidden layers are recomputed: a rarely used configuration, kept simple)
@@ -627,23 +678,8 @@ class PUNetEngine:
             st["feat_f32"] = f32
             feat = f32
         # Fcomb, single sample, activations materialised for the backward
-        h = Act(self._empty(B, H, W, CH), B, H, W, CH, relu_out=True)
-        p1 = self._x6_1x1.get((flat.data_ptr(), 0), {}).get(c1.name) if self.x6 else None
-        if p1 is not None:
-            if record:
-                h.bits = torch.empty(_lib.call("punet_gate_dwords", B, H, W, CH), dtype=torch.int32, device=self.device)
-            self._timed("conv1x1_fwd", 2.0 * B * H * W * CH * CH, "punet_conv1x1_x6_gated", feat.ptr, CH, None, 0, p1.data_ptr(),
-                        CH * CH, CH, 0, zb.data_ptr(), CH, h.ptr, CH, None, None,
-                        h.bits.data_ptr() if h.bits is not None else None, 0, 1, B, H, W, _stream())
-        else:
-            _lib.call("punet_conv_fwd", feat.ptr, CH, None, 0, self._wptr(flat, c1), zb.data_ptr(), CH, h.ptr, CH, B, H, W, 1, 1,
-                      _stream())
-        hs = [h]
-        if taps is not None:
-            taps["conv:fcomb.layers.0"] = h
-        for nm in L.fcomb_mid:
-            h = self.conv(flat, nm, h, None, True, None, taps, tape_bits=record)
-            hs.append(h)
+        hs = self._fcomb_hidden(flat, feat, zb.data_ptr(), record, taps)
+        h = hs[-1]
         P = B * H * W
         # num_classes = K > 1: the last layer, the criterion and their backward run in a class-major [K, B, H, W] layout (one
         # dot-product launch per class, the element-wise criterion over K * P elements); the facade permutes at the boundary
