@@ -1,7 +1,9 @@
-"""CPU, world_size 2, gloo: the data-parallel host logic of my_trainer/fused.py (gradient all-reduce + 1/world scale,
+"""CPU, world_size 2 (and 4, 8 for the gradient all-reduce), gloo: the data-parallel host logic of my_trainer/fused.py (gradient all-reduce + 1/world scale,
 rank-local shards) and bench.py's max-over-ranks timing.  No GPU compute is called."""
 import os
 import socket
+
+import pytest
 
 import torch
 import torch.distributed as dist
@@ -283,3 +285,33 @@ def test_fit_world2_refuses_unequal_shards():
         p.join(60)
         assert p.exitcode == 0
     assert all("same number of times" in msg for _, msg in res), res
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_allreduce_grads_world_4_and_8(world):
+    """The ranks the driver's scaling run uses (N = 4, 8): plain and overlapped-slice all-reduce, 1 / world scale, max-over-ranks
+    timing reduction - on the CPU over gloo."""
+    ctx = mp.get_context("spawn")
+    for target in (_worker, _worker_split):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=180) for _ in range(world))
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        tri = world * (world + 1) // 2  # sum of (rank + 1)
+        if target is _worker:
+            for rank, scale, head, tot, tmax in res:
+                assert scale == 1.0 / world
+                assert head == [0.0, 1.0 * tri, 2.0 * tri, 3.0 * tri]
+                assert tot == float(tri) * sum(range(1000))
+                assert abs(tmax - 0.1 * world) < 1e-12
+        else:
+            for rank, scale, head, mid, tot in res:
+                assert scale == 1.0 / world
+                assert head == [0.0, float(tri)]
+                assert mid == [tri * 384.0 + world, tri * 385.0 + world]  # every rank added 1 to the remainder before reducing it
+                assert tot == float(tri) * sum(range(1000)) + world * (1000 - 384)
