@@ -19,7 +19,7 @@ def _setup(fx):
     meta = fx["meta"]
     B, C, H, W, s0, s1, s2, fixed = [int(v) for v in meta[:8]]
     nf = [int(v) for v in meta[8:]]
-    K = int(fx["num_classes"][0]) if "num_classes" in fx.files else 1
+    K = int(fx["num_classes"][0])
     cfg = O.PUNetConfig(C, K, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
     Pnp = O.synth_params(cfg.spec(), s1)
     batch = O.synth_batch(B, C, H, W, s0)
