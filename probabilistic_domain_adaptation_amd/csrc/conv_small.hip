@@ -160,11 +160,22 @@ static int small_fwd_launch(bool out16, const float* x, int cin, const float* w,
     const dim3 grid(ceil_div(W, ppb * xiter), B * H < 65535 ? B * H : 65535);
     float* yf = (float*)y;
     const size_t wlds = cin > 4 ? (size_t)9 * cin * (cout / 4) * sizeof(float4) : 0;  // 5..8 channels: weights in LDS (<= 72 KB)
-    PUNET_CHECK_ARG(wlds <= 64 * 1024, "punet_conv3x3_small_fwd: cin %d x cout %d needs more than 64 KB of LDS for the weights", cin, cout);
+    PUNET_CHECK_ARG(wlds <= 160 * 1024, "punet_conv3x3_small_fwd: cin %d x cout %d needs more than 160 KB of LDS for the weights", cin, cout);
+#define PUNET_SMALL_FWD_ATTR(K)                                                                                                \
+    if (wlds > 48 * 1024 && hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds) != hipSuccess) { \
+        (void)hipGetLastError();                                                                                               \
+        punet_set_error("punet_conv3x3_small_fwd: cannot opt in to %zu bytes of dynamic LDS", wlds);                           \
+        return PUNET_ERR_HIP;                                                                                                  \
+    }
 #define PUNET_SMALL_FWD(CI)                                                                                          \
     do {                                                                                                             \
-        if (out16) conv3x3_small_fwd_kernel<CI, true><<<grid, 256, wlds, stream>>>(x, w, bias, yf, cout, B, H, W, relu, xiter); \
-        else conv3x3_small_fwd_kernel<CI, false><<<grid, 256, wlds, stream>>>(x, w, bias, yf, cout, B, H, W, relu, xiter);      \
+        if (out16) {                                                                                                 \
+            PUNET_SMALL_FWD_ATTR((conv3x3_small_fwd_kernel<CI, true>))                                               \
+            conv3x3_small_fwd_kernel<CI, true><<<grid, 256, wlds, stream>>>(x, w, bias, yf, cout, B, H, W, relu, xiter); \
+        } else {                                                                                                     \
+            PUNET_SMALL_FWD_ATTR((conv3x3_small_fwd_kernel<CI, false>))                                              \
+            conv3x3_small_fwd_kernel<CI, false><<<grid, 256, wlds, stream>>>(x, w, bias, yf, cout, B, H, W, relu, xiter); \
+        }                                                                                                            \
     } while (0)
     switch (cin) {
         case 1: PUNET_SMALL_FWD(1); break;
@@ -177,6 +188,7 @@ static int small_fwd_launch(bool out16, const float* x, int cin, const float* w,
         default: PUNET_SMALL_FWD(8); break;
     }
 #undef PUNET_SMALL_FWD
+#undef PUNET_SMALL_FWD_ATTR
     PUNET_LAUNCH_CHECK("conv3x3_small_fwd");
     return PUNET_OK;
 }
@@ -213,12 +225,25 @@ extern "C" int punet_conv3x3_small_wgrad(const float* x, int cin, const float* d
         const int cs = cin - c_off < 4 ? cin - c_off : 4;
         const int rows = 9 * cs + 1;
         const size_t shmem = (size_t)4 * rows * groups * sizeof(float4);
+        PUNET_CHECK_ARG(shmem <= 160 * 1024, "punet_conv3x3_small_wgrad: cout %d needs %zu bytes of LDS (> 160 KB)", cout, shmem);
+        // wide first layers (num_filters[0] = 128 with 4 channels, 256 with >= 2) pass 64 KB of dynamic LDS: opt in
+#define PUNET_SMALL_WGRAD(CS)                                                                                                   \
+    do {                                                                                                                        \
+        if (shmem > 48 * 1024 && hipFuncSetAttribute((const void*)conv3x3_small_wgrad_kernel<CS>,                               \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {   \
+            (void)hipGetLastError();                                                                                            \
+            punet_set_error("punet_conv3x3_small_wgrad: cannot opt in to %zu bytes of dynamic LDS", shmem);                     \
+            return PUNET_ERR_HIP;                                                                                               \
+        }                                                                                                                       \
+        conv3x3_small_wgrad_kernel<CS><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W, cin, c_off);              \
+    } while (0)
         switch (cs) {
-            case 1: conv3x3_small_wgrad_kernel<1><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W, cin, c_off); break;
-            case 2: conv3x3_small_wgrad_kernel<2><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W, cin, c_off); break;
-            case 3: conv3x3_small_wgrad_kernel<3><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W, cin, c_off); break;
-            default: conv3x3_small_wgrad_kernel<4><<<grid, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W, cin, c_off); break;
+            case 1: PUNET_SMALL_WGRAD(1); break;
+            case 2: PUNET_SMALL_WGRAD(2); break;
+            case 3: PUNET_SMALL_WGRAD(3); break;
+            default: PUNET_SMALL_WGRAD(4); break;
         }
+#undef PUNET_SMALL_WGRAD
         PUNET_LAUNCH_CHECK("conv3x3_small_wgrad");
         const size_t slab = (size_t)rows * cout;
         const int rc = punet_launch_reduce_slabs_pair(workspace, slab, 9 * cs, cout, cs, cin, c_off, dw, workspace + (size_t)9 * cs * cout,

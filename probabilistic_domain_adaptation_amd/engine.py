@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -198,18 +199,38 @@ _X6_PRODUCTS = {"x6": 6, "x3": 3, "bf16": 1, "bf16s": 1}
 
 
 class Workspace:
-    """Grow-only scratch buffers keyed by purpose (split-K slabs, reduction partials)."""
+    """Grow-only scratch buffers keyed by purpose (split-K slabs, reduction partials).
+
+    A captured hipGraph bakes the raw pointers of these buffers into its kernel nodes (my_trainer/fused.py::GraphedStep).
+    Once a graph exists on the device (`pin_all`), a buffer that has to grow is REPLACED, never freed: the old tensor moves
+    to `retired` and stays alive for the life of the workspace, so a later eager call with a larger shape (validation or
+    prediction with a bigger batch, a second capture) cannot hand the block a graph still writes through to the caching
+    allocator."""
+
+    _live = weakref.WeakSet()
 
     def __init__(self, device):
         self.device = device
         self.bufs: Dict[str, torch.Tensor] = {}
+        self.retired: List[torch.Tensor] = []
+        self.pinned = False
+        Workspace._live.add(self)
 
     def get(self, key: str, nfloats: int) -> torch.Tensor:
         b = self.bufs.get(key)
         if b is None or b.numel() < nfloats:
+            if b is not None and self.pinned:
+                self.retired.append(b)
             b = torch.empty(max(int(nfloats), 1), dtype=torch.float32, device=self.device)
             self.bufs[key] = b
         return b
+
+    @classmethod
+    def pin_all(cls, device):
+        """Called when a graph is about to be captured on `device`: every live workspace there keeps what it has handed out."""
+        for w in list(cls._live):
+            if torch.device(w.device) == torch.device(device):
+                w.pinned = True
 
 
 class PUNetEngine:
@@ -703,13 +724,20 @@ class PUNetEngine:
             _lib.call("punet_bce_fwd_bwd", lg_k.data_ptr(), tgt_k.data_ptr(), cm, float(gscale),
                       dlogit.data_ptr() if record else None, rec.data_ptr(), wsl.data_ptr(), K * P, _stream())
         elif loss_kind == "dice":
-            if K != 1:
-                raise NotImplementedError("the Dice criterion (recalled torch_em definition, parity unpinned) is implemented for "
-                                          "num_classes == 1")
+            # [recalled torch_em definition, parity unpinned] per channel 1 - 2 sum(p t) / max(sum(p^2) + sum(t^2), eps) over
+            # batch and pixels, summed over the channels: one class = one contiguous block of the class-major layout
             if dlogit is None:
-                dlogit = self._empty(B, 1, H, W)
-            _lib.call("punet_dice_fwd_bwd", logits.data_ptr(), y_tgt.data_ptr(), cm, float(gscale), dlogit.data_ptr(),
-                      rec.data_ptr(), wsl.data_ptr(), P, _stream())
+                dlogit = torch.empty_like(lg_k)
+            if K == 1:
+                _lib.call("punet_dice_fwd_bwd", logits.data_ptr(), y_tgt.data_ptr(), cm, float(gscale), dlogit.data_ptr(),
+                          rec.data_ptr(), wsl.data_ptr(), P, _stream())
+            else:
+                per_class = self._empty(K)
+                for k in range(K):
+                    _lib.call("punet_dice_fwd_bwd", lg_k[k].data_ptr(), tgt_k[k].data_ptr(),
+                              cm_k[k].data_ptr() if cm_k is not None else None, float(gscale), dlogit[k].data_ptr(),
+                              per_class.data_ptr() + 4 * k, wsl.data_ptr(), P, _stream())
+                rec = per_class.sum().reshape(1)  # K values (no reference script uses num_classes > 1: kept simple)
         else:
             raise ValueError(loss_kind)
         st.update(z=zf, z_posterior=z, eps=eps3, kl=kl, kl_rows=kl_rows, rec=rec, logits=logits, dlogit=dlogit, hs=hs,

@@ -280,7 +280,7 @@ class ProbabilisticUnet(nn.Module):
         self.kl = es["kl"][0]
         self.reconstruction = es["logits"]
         self.reconstruction_loss = es["rec"][0]
-        self.mean_reconstruction_loss = self.reconstruction_loss / float(B * H * W) if not self.rl_swap \
+        self.mean_reconstruction_loss = self.reconstruction_loss / float(B * self.num_classes * H * W) if not self.rl_swap \
             else self.reconstruction_loss
         value = -(self.reconstruction_loss + self.beta * self.kl)
         if not record:

@@ -75,7 +75,9 @@ def broadcast_tensors(tensors, device, src=0):
 
 class RankShard:
     """View of a loader that yields every world-th batch, starting at `rank`; all ranks get the same number of batches
-    (the remainder is dropped), so that the per-step gradient all-reduce always has all its participants."""
+    (the remainder is dropped), so that the per-step gradient all-reduce always has all its participants.
+    The SLOW fallback of `shard_loader`: every rank still loads (and augments) the whole epoch and discards
+    (world - 1) / world of it - used only for loaders that are not torch DataLoaders (lists, generators with a length)."""
 
     def __init__(self, loader, rank=None, world=None):
         self.loader = loader
@@ -94,6 +96,43 @@ class RankShard:
                 yield batch
 
 
+class ShardedBatchSampler:
+    """Every world-th batch of INDICES of a batch sampler, starting at `rank` (remainder dropped): the sharding happens
+    before anything is loaded, so a rank reads and augments only its own 1 / world of the epoch.  A shuffling
+    base sampler must draw the same permutation on every rank (seed its generator identically, as for a DistributedSampler)."""
+
+    def __init__(self, batch_sampler, rank, world):
+        self.batch_sampler, self.rank, self.world = batch_sampler, rank, world
+
+    def __len__(self):
+        return len(self.batch_sampler) // self.world
+
+    def __iter__(self):
+        n = len(self) * self.world
+        for i, idx in enumerate(self.batch_sampler):
+            if i >= n:
+                break
+            if i % self.world == self.rank:
+                yield idx
+
+
+def shard_loader(loader, rank=None, world=None):
+    """The rank's shard of a common loader: a torch DataLoader is rebuilt around a ShardedBatchSampler (index level, no wasted
+    loading); anything else falls back to RankShard (batch level)."""
+    rank = dp_rank() if rank is None else rank
+    world = dp_world() if world is None else world
+    from torch.utils.data import DataLoader
+    if isinstance(loader, DataLoader) and getattr(loader, "batch_sampler", None) is not None \
+            and not isinstance(loader.batch_sampler, ShardedBatchSampler):
+        kw = dict(num_workers=loader.num_workers, collate_fn=loader.collate_fn, pin_memory=loader.pin_memory,
+                  timeout=loader.timeout, worker_init_fn=loader.worker_init_fn, generator=loader.generator,
+                  persistent_workers=loader.persistent_workers)
+        if loader.num_workers > 0:
+            kw.update(prefetch_factor=loader.prefetch_factor, multiprocessing_context=loader.multiprocessing_context)
+        return DataLoader(loader.dataset, batch_sampler=ShardedBatchSampler(loader.batch_sampler, rank, world), **kw)
+    return RankShard(loader, rank, world)
+
+
 class DefaultTrainer:
     def __init__(self, name=None, train_loader=None, val_loader=None, model=None, loss=None, optimizer=None, metric=None,
                  device=None, lr_scheduler=None, log_image_interval=100, mixed_precision=True, early_stopping=None,
@@ -101,7 +140,8 @@ class DefaultTrainer:
                  **unused):
         """shard_loaders (extension, data parallel): False = the caller hands every rank its own loader shard (e.g. a
         DistributedSampler) - fit() then checks that all ranks see the same number of batches; True = every rank was handed
-        the SAME loader and takes every world-th batch of it (RankShard)."""
+        the SAME loader and takes every world-th batch of it (shard_loader: at the index level for a torch DataLoader, so
+        nothing is loaded twice; RankShard, batch level, for other iterables)."""
         self.name = name
         self.train_loader, self.val_loader = train_loader, val_loader
         self.model, self.loss, self.optimizer, self.metric = model, loss, optimizer, metric
@@ -162,7 +202,14 @@ class DefaultTrainer:
         if self.optimizer is not None and save_dict.get("optimizer_state") is not None:
             try:
                 self.optimizer.load_state_dict(save_dict["optimizer_state"])
-            except (KeyError, ValueError, RuntimeError) as e:  # a foreign optimizer's state: keep the weights, restart the moments
+            except (KeyError, ValueError) as e:  # a foreign optimizer's state: keep the weights, restart the moments.  (Not
+                # RuntimeError: a HIP / copy failure must not be reported as a foreign checkpoint.)  FusedAdam validates every
+                # entry before it touches its buffers; any other optimizer may be left half-loaded, so it is reset explicitly.
+                reset = getattr(self.optimizer, "reset_state", None)
+                if reset is not None:
+                    reset()
+                else:
+                    self.optimizer.state.clear()
                 warnings.warn(f"optimizer_state of {path} does not fit {type(self.optimizer).__name__} ({e!r}); "
                               "continuing with fresh optimizer state")
         if self.lr_scheduler is not None and "scheduler_state" in save_dict:
@@ -213,10 +260,10 @@ class DefaultTrainer:
             self.optimizer.step_count = int(allreduce_scalars([step], self.device, "max")[0])
         for attr in ("train_loader", "val_loader", "source_train_loader", "target_train_loader"):
             ld = getattr(self, attr, None)
-            if ld is None or isinstance(ld, RankShard):
+            if ld is None or isinstance(ld, RankShard) or isinstance(getattr(ld, "batch_sampler", None), ShardedBatchSampler):
                 continue
             if self.shard_loaders:
-                setattr(self, attr, RankShard(ld))
+                setattr(self, attr, shard_loader(ld))
             else:
                 n = len(ld)
                 lo, = allreduce_scalars([n], self.device, "min")

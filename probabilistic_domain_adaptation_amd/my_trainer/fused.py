@@ -121,9 +121,18 @@ class FusedAdam(torch.optim.Optimizer):
             groups.append(d)
         return {"state": state, "param_groups": groups}
 
+    def reset_state(self):
+        """Fresh optimizer state: zero moments, step 0 (what a new FusedAdam starts with)."""
+        self.step_count = 0
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self._uploaded = None
+
     def load_state_dict(self, sd):
         """Accepts torch.optim.Adam's layout (above; also from a reference checkpoint) and this build's round-1 flat layout
-        {step, exp_avg, exp_avg_sq}."""
+        {step, exp_avg, exp_avg_sq}.  Everything is VALIDATED before anything is written: a state that does not fit raises
+        KeyError / ValueError and leaves the optimizer exactly as it was (a partial load followed by "continuing
+        with fresh state" had left stale first moments under a step count of 0)."""
         lay = self.model.layout
         if "state" in sd:
             st = sd["state"]
@@ -132,28 +141,34 @@ class FusedAdam(torch.optim.Optimizer):
             g0 = sd["param_groups"][0] if sd.get("param_groups") else {}
             if g0.get("amsgrad") or g0.get("weight_decay"):
                 raise ValueError("FusedAdam implements plain Adam (no amsgrad, no weight decay)")
-            self.step_count = 0
-            self.exp_avg.zero_()
-            self.exp_avg_sq.zero_()
+            m_views, v_views = lay.views(self.exp_avg), lay.views(self.exp_avg_sq)
+            entries, steps = [], set()
             if st:
-                m_views, v_views = lay.views(self.exp_avg), lay.views(self.exp_avg_sq)
-                steps = set()
-                with torch.no_grad():
-                    for i, name in enumerate(m_views):
-                        e = st[i] if i in st else st[str(i)]
-                        if tuple(e["exp_avg"].shape) != tuple(m_views[name].shape):
-                            raise ValueError(f"optimizer state {i} ({name}): shape {tuple(e['exp_avg'].shape)} != "
+                for i, name in enumerate(m_views):  # pass 1: look at every entry, touch nothing
+                    e = st[i] if i in st else st[str(i)]
+                    for key in ("exp_avg", "exp_avg_sq"):
+                        if tuple(e[key].shape) != tuple(m_views[name].shape):
+                            raise ValueError(f"optimizer state {i} ({name}): {key} has shape {tuple(e[key].shape)}, expected "
                                              f"{tuple(m_views[name].shape)}")
-                        m_views[name].copy_(e["exp_avg"])
-                        v_views[name].copy_(e["exp_avg_sq"])
-                        steps.add(int(float(e["step"])))
+                    steps.add(int(float(e["step"])))
+                    entries.append((name, e))
                 if len(steps) != 1:
                     raise ValueError(f"per-parameter step counts differ ({sorted(steps)}); the fused kernel keeps one")
+            self.reset_state()
+            with torch.no_grad():  # pass 2: copy
+                for name, e in entries:
+                    m_views[name].copy_(e["exp_avg"])
+                    v_views[name].copy_(e["exp_avg_sq"])
+            if st:
                 self.step_count = steps.pop()
         else:
-            self.step_count = sd["step"]
+            for key in ("exp_avg", "exp_avg_sq"):
+                if tuple(sd[key].shape) != tuple(self.exp_avg.shape):
+                    raise ValueError(f"flat optimizer state: {key} has shape {tuple(sd[key].shape)}, expected {tuple(self.exp_avg.shape)}")
+            step = int(sd["step"])
             self.exp_avg.copy_(sd["exp_avg"])
             self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            self.step_count = step
         for g, s_ in zip(self.param_groups, sd["param_groups"]):
             g.update({k: v for k, v in s_.items() if k != "params"})
         self._uploaded = None  # the device state block is rewritten before the next step
@@ -326,6 +341,10 @@ class GraphedStep:
         body(inputs)
         self._restore(snap)
         torch.cuda.synchronize(dev)
+        # the capture bakes the engines' workspace pointers into the graph: from here on a workspace that has to grow (an
+        # eager call at a larger shape) retires its old buffer instead of freeing it
+        from ..engine import Workspace
+        Workspace.pin_all(dev)
         if opt is not None:  # the device state block must be current before the capture (no uploads inside a graph)
             opt.sync_device_state(ema_momentum if ema else 0.0, 1.0 / _world(), warmup_iteration if ema else None)
         # (2) capture, cutting at collectives

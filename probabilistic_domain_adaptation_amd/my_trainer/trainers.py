@@ -16,6 +16,7 @@ Each latent draw may be injected through `self.eps_source(kind, n, batch)` for r
 from __future__ import annotations
 
 import time
+from collections import OrderedDict
 from copy import deepcopy
 
 import torch
@@ -40,7 +41,8 @@ class _PUNetTrainerBase(DefaultTrainer):
         self.graph = bool(graph)
         if self.graph and not self.fused:
             raise ValueError("graph=True needs the fused execution mode (a FusedAdam optimizer)")
-        self._graphs = {}
+        self._graphs = OrderedDict()  # captured steps, least recently used first; at most `max_graphs` are kept
+        self.max_graphs = 4           # (each holds a private memory pool the size of one step's activations)
         self.sigmoid = torch.nn.Sigmoid()
         self.eps_source = None  # callable(kind, n, batch) -> [n, batch, L] tensor, or None for fresh draws
         self.last_loss = None
@@ -63,6 +65,9 @@ class _PUNetTrainerBase(DefaultTrainer):
         if gs is None:
             static = {k: v.to(device=self.model.device, dtype=torch.float32).clone() for k, v in tensors.items()}
             gs = self._graphs[key] = FU.GraphedStep(body, static, self.optimizer, **ema)
+            while len(self._graphs) > self.max_graphs:
+                self._graphs.popitem(last=False)
+        self._graphs.move_to_end(key)
         return gs.step(warmup_iteration=ema.get("warmup_iteration"), **tensors)
 
     def _lr(self):

@@ -315,3 +315,43 @@ def test_allreduce_grads_world_4_and_8(world):
                 assert head == [0.0, float(tri)]
                 assert mid == [tri * 384.0 + world, tri * 385.0 + world]  # every rank added 1 to the remainder before reducing it
                 assert tot == float(tri) * sum(range(1000)) + world * (1000 - 384)
+
+
+def test_shard_loader_shards_indices_not_batches():
+    """a torch DataLoader is re-built around a ShardedBatchSampler, so each rank LOADS only its own every-world-th
+    batch (RankShard, the fallback for plain iterables, would load all of them and discard)."""
+    from torch.utils.data import DataLoader, Dataset
+    from probabilistic_domain_adaptation_amd.my_trainer.default_trainer import RankShard, ShardedBatchSampler, shard_loader
+
+    class Counting(Dataset):
+        def __init__(self):
+            self.loaded = []
+
+        def __len__(self):
+            return 22
+
+        def __getitem__(self, i):
+            self.loaded.append(i)
+            return torch.tensor([float(i)])
+
+    seen = []
+    for rank in range(2):
+        ds = Counting()
+        base = DataLoader(ds, batch_size=4, shuffle=False)  # 6 batches (the last one short)
+        sh = shard_loader(base, rank, 2)
+        assert isinstance(sh.batch_sampler, ShardedBatchSampler) and len(sh) == 3
+        got = [b.flatten().tolist() for b in sh]
+        assert len(got) == 3 and sorted(ds.loaded) == sorted(int(v) for b in got for v in b)  # nothing else was touched
+        seen.append(got)
+        assert shard_loader(sh, rank, 2) is not None
+    assert seen[0][0] == [0.0, 1.0, 2.0, 3.0] and seen[1][0] == [4.0, 5.0, 6.0, 7.0]
+    assert not {tuple(b) for b in seen[0]} & {tuple(b) for b in seen[1]}
+    # shuffling base sampler: the same generator seed on every rank gives disjoint shards of ONE permutation
+    parts = []
+    for rank in range(2):
+        g = torch.Generator().manual_seed(3)
+        sh = shard_loader(DataLoader(Counting(), batch_size=4, shuffle=True, generator=g, drop_last=True), rank, 2)
+        parts.append([v for b in sh for v in b.flatten().tolist()])
+    assert len(parts[0]) == len(parts[1]) == 8 and not set(parts[0]) & set(parts[1])
+    # a plain list falls back to the batch-level view
+    assert isinstance(shard_loader([1, 2, 3, 4, 5], 0, 2), RankShard) and list(shard_loader([1, 2, 3, 4, 5], 1, 2)) == [2, 4]

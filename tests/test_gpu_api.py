@@ -294,3 +294,35 @@ def test_two_classes_facade_and_mean_teacher_step(dev, fused):
     sd = {k: v.detach().cpu() for k, v in tr.model.state_dict().items()}
     for k, v in Ps.items():  # Adam's first step moves every entry by ~lr: compare the parameters after the step
         assert (sd[k] - v.detach()).abs().max().item() <= 2.5e-4, k  # a gradient within rounding of 0 may flip sign(g): 2 lr at most
+
+
+def test_two_classes_dice_criterion(dev):
+    """ProbabilisticUnet(num_classes=2, rl_swap=True).elbo() works as probabilistic_unet.py:347 builds it for any K:
+    the criterion under the RECALLED per-channel torch_em definition (parity unpinned, like K = 1) - loss scalar and all
+    gradients against the oracle's restatement of the same definition, through the facade's autograd-connected elbo()."""
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    nf, B, C, K, H, W = [32, 32, 64, 64], 2, 2, 2, 32, 40
+    cfg = O.PUNetConfig(C, K, nf, L, 3, 1.0, consensus_masking=True, rl_swap=True)
+    Pnp = O.synth_params(cfg.spec(), 41)
+    x, x1, x2, _ = O.synth_batch(B, C, H, W, 42)
+    gen = torch.Generator().manual_seed(43)
+    y = (torch.rand(B, K, H, W, generator=gen) > 0.6).float()
+    consm = (torch.rand(B, K, H, W, generator=gen) > 0.3).float()
+    eps = torch.randn(1, B, L, generator=gen)
+    m = ProbabilisticUnet(C, K, nf, L, 3, 1.0, consensus_masking=True, rl_swap=True, device=dev, seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in Pnp.items()})
+    m.forward(x2.to(dev), y.to(dev), training=True)
+    elbo = m.elbo(y.to(dev), consm.to(dev), eps=eps)
+    (-elbo).backward()
+    torch.cuda.synchronize()
+    P = O.to_torch(Pnp, requires_grad=True)
+    lo, aux = O.training_loss(P, cfg, x2, y, consm, eps[0], reg_weight=0.0)
+    go = O.grads_of(lo, P)
+    assert tuple(m.reconstruction.shape) == (B, K, H, W)
+    assert (m.reconstruction.detach().cpu() - aux["reconstruction"].detach()).abs().max().item() < 1e-3
+    assert abs(float(m.reconstruction_loss) - aux["reconstruction_loss"].item()) < 2e-5
+    np.testing.assert_allclose(-float(elbo), lo.item(), rtol=2e-4)
+    for k, p in m.named_parameters():
+        ref = go[k]
+        e = (p.grad.detach().cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-8)
+        assert e < 2e-3, (k, e)

@@ -80,7 +80,11 @@ def test_smallest_and_ragged_shapes_match_oracle(model, B, H, W, n):
                                                # weight gradient in two channel passes)
     ([16, 32, 48, 64], 32, 40, 6, 3, 1),       # num_filters[0] outside {32, 64}: Fcomb layer by layer (sampler and training)
     ([128, 64, 64, 72], 24, 40, 6, 4, 1),      # ... 128 of them, two middle layers
-], ids=["nf8", "ctor_defaults", "depth3_latent2", "depth5_fcomb2_rgb", "six_channels", "first16", "first128_fcomb4"])
+    ([128, 32, 32, 32], 16, 24, 6, 3, 3),      # 128 wide with an RGB image: the posterior's first layer has 4 channels, its weight
+                                               # gradient 75.8 KB of dynamic LDS (the > 64 KB opt-in)
+    ([256, 32, 32, 32], 16, 24, 6, 3, 1),      # 256 wide: 77.8 KB for the posterior's two channels
+], ids=["nf8", "ctor_defaults", "depth3_latent2", "depth5_fcomb2_rgb", "six_channels", "first16", "first128_fcomb4",
+        "first128_rgb", "first256"])
 def test_constructor_space_against_oracle(nf, H, W, latent, nfc, C):
     """The constructor's argument space beyond the scripts' one setting - widths that are multiples of 8 but not of 32 (they
     go through the 32x32x16 kernels; the 16x16x32 kernel needs a multiple of 32), the reference's default arguments, other

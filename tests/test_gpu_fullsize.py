@@ -61,26 +61,43 @@ def test_inference_fullsize_against_oracle(dev, channels, size, n):
     assert torch.equal(cz.cpu()[safe], ref[safe])
     # the full count, near-threshold pixels included: a pixel can only differ where some sigmoid sits within
     # rounding of 0.9 / 0.1, i.e. never more pixels than the unsafe ones
-    mism = int((cz.cpu() != ref).sum())
+    diff = cz.cpu() != ref
+    mism = int(diff.sum())
     print(f"consensus mask: {mism} of {ref.numel()} pixels differ from the oracle ({int((~safe).sum())} within 1e-5 of a threshold)")
+    # every differing pixel on the record, with the distance of its nearest sigmoid to a threshold in the oracle and the logits
+    # error of that very sample on the GPU (north_star: bit-exact masks for IDENTICAL logits)
+    dist_thr = torch.minimum((probs - 0.9).abs(), (probs - 0.1).abs())  # [n, 1, 1, H, W]
+    for idx in diff.nonzero().tolist():
+        d_n = dist_thr[(slice(None),) + tuple(idx)]
+        k = int(d_n.argmin())
+        lo_, lg_ = float(logits[(k,) + tuple(idx)]), float(lg.cpu()[(k,) + tuple(idx)])
+        print(f"  pixel {tuple(idx[-2:])}: GPU mask {int(cz.cpu()[tuple(idx)])} vs oracle {int(ref[tuple(idx)])}; sample {k}: "
+              f"|sigmoid - thr| = {float(d_n[k]):.3e}, oracle logit {lo_:.7f}, GPU logit {lg_:.7f} (diff {abs(lo_ - lg_):.2e})")
+        assert float(d_n[k]) <= 1e-5
     assert mism <= int((~safe).sum())
     assert 0.01 < ref.mean().item() < 0.99  # a non-trivial mask
     assert (ym.cpu() - probs.mean(0)).abs().max().item() < 1e-4
 
 
-def test_training_step_512_b1_against_oracle(dev):
+@pytest.mark.parametrize("B,channels,size", [(1, 1, 512), (1, 3, 704), (2, 1, 512)],
+                         ids=["512x512x1-B1", "704x704x3-B1", "512x512x1-B2"])
+def test_training_step_fullsize_against_oracle(dev, B, channels, size):
     """The production instantiations (persistent grids with tile wrap-around, 256 split-K slabs, XCD remap, fused pooling,
-    LDS-DMA weight staging) against the CPU oracle's autograd at the bench's patch size and filters: one 512 x 512 patch,
-    nf = [64, 128, 256, 512], consensus-masked BCE ELBO + L2 regulariser - loss scalars and ALL 100 parameter gradients.
+    LDS-DMA weight staging) against the CPU oracle's autograd at the bench's patch sizes and filters, nf = [64, 128, 256, 512],
+    consensus-masked BCE ELBO + L2 regulariser - loss scalars and ALL 100 parameter gradients:
+      * one 512 x 512 x 1 patch (configs[1] / [2]);
+      * one 704 x 704 x 3 patch (configs[3], adamatch_trainer.py:56-116): the 3- and 4-channel first-layer weight-gradient
+        kernels (`conv3x3_small_wgrad_kernel<3>`, `<4>`) and the non-power-of-two tiling at full size;
+      * a batch of two 512 x 512 patches: split-K slices that cross image boundaries, the per-image z term, the batch-mean KL.
     The oracle's ReLUs are gated by the GPU's own forward activations (which are checked first), so that a
     pre-activation within fp32 rounding of 0 cannot turn into an O(1) difference of single gradient entries."""
-    m = _model(dev)
+    m = _model(dev, channels=channels)
     eng, lay, flat = m.engine, m.layout, m.flat_params
-    cfg = O.PUNetConfig(1, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    cfg = O.PUNetConfig(channels, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
     P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
-    x, x1, x2, y = O.synth_batch(1, 1, 512, 512, 0)
+    x, x1, x2, y = O.synth_batch(B, channels, size, size, 0)
     g = torch.Generator().manual_seed(4)
-    eps_s = torch.randn(1, 6, generator=g)
+    eps_s = torch.randn(B, 6, generator=g)
     y_soft = (0.8 * y + 0.1 * torch.rand(y.shape, generator=g)).clamp(0, 1)  # a soft pseudo-label, as the trainers feed
     consm = (torch.rand(y.shape, generator=g) > 0.3).float()
     taps = {}
@@ -95,7 +112,7 @@ def test_training_step_512_b1_against_oracle(dev):
     torch.set_num_threads(min(16, torch.get_num_threads()))
     O.RELU_GATES = gates
     try:
-        lo, aux = O.training_loss(P, cfg, x2, y_soft, consm, eps_s[0:1].reshape(1, 6), taps=otaps)
+        lo, aux = O.training_loss(P, cfg, x2, y_soft, consm, eps_s, taps=otaps)
         go = O.grads_of(lo, P)
     finally:
         O.RELU_GATES = None
@@ -115,7 +132,7 @@ def test_training_step_512_b1_against_oracle(dev):
         worst = max(worst, e)
         if e > 5e-4:
             bad[k] = e
-    print(f"\n512x512 B=1 training step: worst gradient error {worst:.2e} of the tensor max over {len(go)} tensors")
+    print(f"\n{size}x{size}x{channels} B={B} training step: worst gradient error {worst:.2e} of the tensor max over {len(go)} tensors")
     assert len(go) == 100 and not bad, bad
 
 

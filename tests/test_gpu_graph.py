@@ -95,6 +95,46 @@ def test_mean_teacher_graph_equals_eager_with_lr_change(dev):
     assert len(b._graphs) == 1 and a.optimizer.step_count == 5
 
 
+def test_graph_survives_larger_eager_shapes_on_the_same_engine(dev):
+    """the captured graph holds raw pointers of the engines' grow-only workspaces.  A validation pass with four
+    times the pixels and twice the batch makes every workspace grow (the old buffers are retired, not freed), tensors that
+    stay alive are allocated meanwhile, and the replay afterwards still equals the eager step bit for bit; a second capture
+    at the larger shape works next to the first."""
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam, MeanTeacherTrainer
+    data = _batches(4)
+    big = [O.synth_batch(4, 1, 64, 64, 77)]
+
+    def make(graph):
+        m = _model(dev)
+        tr = MeanTeacherTrainer(name=None, train_loader=data[:2], val_loader=big, model=m, optimizer=FusedAdam(m, lr=LR), device=dev,
+                                do_consensus_masking=True, graph=graph)
+        tr.n_samples = 4
+        return tr
+
+    a, b = _pair(make)
+    keep = []
+    for tr in (a, b):
+        tr._train_epoch_impl(_P(), contextlib.nullcontext, None)
+        tr._validate_impl(contextlib.nullcontext)  # eager, larger: last_validation keeps y / z / samples alive
+        keep.append([torch.full((1 << 20,), float(i), device=dev) for i in range(8)])  # and more live allocations
+        tr.train_loader = data[2:]
+        tr._train_epoch_impl(_P(), contextlib.nullcontext, None)
+    torch.cuda.synchronize()
+    _same(a, b)
+    ws = b.model.engine.ws
+    assert ws.pinned and len(ws.retired) > 0  # the small-shape buffers the graph uses were kept
+    for tr in (a, b):  # a second capture at the larger shape, then the first graph again
+        tr.train_loader = big
+        tr._train_epoch_impl(_P(), contextlib.nullcontext, None)
+        tr.train_loader = data[:1]
+        tr._train_epoch_impl(_P(), contextlib.nullcontext, None)
+    torch.cuda.synchronize()
+    _same(a, b)
+    assert len(b._graphs) == 2
+    for i, t in enumerate(keep[1]):
+        assert float(t[0]) == float(i) and float(t[-1]) == float(i)
+
+
 def test_adamt_graph_equals_eager_with_warmup_momentum(dev):
     """AdaMT: momentum min(1 - 1/(it + 1), 0.999) changes every iteration; in the graph it comes from the device counter."""
     from probabilistic_domain_adaptation_amd.my_trainer import AdaMTTrainer, FusedAdam

@@ -315,3 +315,36 @@ def test_optimizer_state_is_torch_adam_layout(case, dev, tmp_path):
     assert f3.step_count == 3
     for (k, p), (_, v) in zip(tr2.model.named_parameters(), m3.layout.views(f3.exp_avg).items()):
         assert torch.equal(tr2.optimizer.state[p]["exp_avg"], v), k
+
+
+def test_foreign_optimizer_state_leaves_the_optimizer_untouched(case, dev, tmp_path):
+    """FusedAdam.load_state_dict validates every entry before it writes anything - a state whose LAST entry does
+    not fit raises ValueError and leaves moments and step count exactly as they were; load_checkpoint then continues with
+    genuinely fresh state (zero moments, step 0), never with a half-loaded one."""
+    import copy
+    import warnings
+    a = _mt_trainer(case, dev, tmp_path)
+    a.fit(iterations=2)
+    path = os.path.join(str(tmp_path), "checkpoints", "mt", "latest.pt")
+    ck = torch.load(path, weights_only=False)
+    bad = copy.deepcopy(ck["optimizer_state"])
+    last = max(bad["state"])
+    bad["state"][last]["exp_avg"] = torch.zeros(3)  # wrong shape at the very end: everything before it fits
+    m_before, v_before, step_before = a.optimizer.exp_avg.clone(), a.optimizer.exp_avg_sq.clone(), a.optimizer.step_count
+    assert step_before == 2 and float(m_before.abs().sum()) > 0
+    with pytest.raises(ValueError):
+        a.optimizer.load_state_dict(bad)
+    assert torch.equal(a.optimizer.exp_avg, m_before) and torch.equal(a.optimizer.exp_avg_sq, v_before)
+    assert a.optimizer.step_count == step_before
+    bad2 = copy.deepcopy(ck["optimizer_state"])
+    bad2["state"][last]["step"] = torch.tensor(7.0)  # per-parameter step counts differ
+    with pytest.raises(ValueError):
+        a.optimizer.load_state_dict(bad2)
+    assert torch.equal(a.optimizer.exp_avg, m_before) and a.optimizer.step_count == step_before
+    ck["optimizer_state"] = bad
+    torch.save(ck, path)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        a.load_checkpoint("latest")
+    assert any("fresh optimizer state" in str(x.message) for x in w)
+    assert a.optimizer.step_count == 0 and float(a.optimizer.exp_avg.abs().sum()) == 0.0 and float(a.optimizer.exp_avg_sq.abs().sum()) == 0.0
