@@ -132,6 +132,7 @@ class Runner:
         self.graphed = None
         self.it = 0
         self.engines = [self.model.engine] + ([self.teacher.engine] if self.teacher is not None else [])
+        self.initial_digest = self.checksum(self.model.flat_params)
 
     def body(self, s):
         FU, m, t, o, N = self.FU, self.model, self.teacher, self.opt, self.N
@@ -156,6 +157,44 @@ class Runner:
         self.graphed = self.FU.GraphedStep(self.body, self.t, self.opt if w != "inference" else None, ema=ema,
                                            ema_momentum=0.999 if ema else 0.0, warmup_iteration=self.it if w == "adamt" else None,
                                            extra_state=[self.teacher.flat_params] if self.teacher is not None else [])
+
+    def state_tensors(self):
+        o = self.opt
+        return [self.model.flat_params, o.exp_avg, o.exp_avg_sq, o.hstate, o.hyper] + \
+               ([self.teacher.flat_params] if self.teacher is not None else [])
+
+    @staticmethod
+    def checksum(t):
+        """Order-independent exact digest of a tensor's BITS (int64 sum of its 32-bit words, wrapping)."""
+        return int(t.detach().contiguous().view(torch.int32).to(torch.int64).sum().item())
+
+    def graph_matches_eager(self):
+        """One eager step and one replayed step from the same state and the same latent draws: bit-identical weights, Adam
+        moments and teacher?  Leaves the state as after ONE step (the replayed one).  Under torch.distributed both steps run
+        their all-reduces, so every rank must call this."""
+        if self.workload == "inference":
+            return True
+        ts = self.state_tensors()
+        o = self.opt
+        snap = [x.clone() for x in ts]
+        mirrors = (o.step_count, o._iter_mirror, o._uploaded)
+        for k in ("eps_pl", "eps_s", "eps_sup"):
+            self.t[k].normal_(generator=self.gen)
+        self.body(self.t)
+        torch.cuda.synchronize()
+        eager = [self.checksum(x) for x in (self.model.flat_params, o.exp_avg, o.exp_avg_sq)] + \
+                ([self.checksum(self.teacher.flat_params)] if self.teacher is not None else [])
+        with torch.no_grad():
+            for c, x in zip(snap, ts):
+                x.copy_(c)
+        o.step_count, o._iter_mirror, o._uploaded = mirrors
+        o._uploaded = None  # the device state block was restored under the mirrors: upload again before the replay
+        self.graphed.step(warmup_iteration=self.it if self.workload == "adamt" else None)
+        torch.cuda.synchronize()
+        replay = [self.checksum(x) for x in (self.model.flat_params, o.exp_avg, o.exp_avg_sq)] + \
+                 ([self.checksum(self.teacher.flat_params)] if self.teacher is not None else [])
+        self.it += 1
+        return eager == replay
 
     def step(self, graph):
         for k in ("eps_pl", "eps_s", "eps_sup"):  # fresh latent draws every step (device RNG, no host sync)
@@ -211,8 +250,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the timed steps eagerly from Python instead of replaying the captured hipGraph")
     ap.add_argument("--graph", action="store_true",
-                    help="replay graph segments also under torch.distributed (default there: eager launches - the step is GPU-bound "
-                         "either way and the segmented replay has only been rehearsed over gloo, never over RCCL)")
+                    help="(kept for compatibility; the segmented replay is now the default under torch.distributed too: it is used "
+                         "when a one-step self-check shows it bit-identical to the eager step on EVERY rank, else eager with a note)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -252,10 +291,11 @@ def main():
             torch.cuda.synchronize()
 
     B, H, W, N = a.batch, a.size, a.size, a.samples
-    use_graph = not a.no_graph and (world == 1 or a.graph)
+    use_graph = not a.no_graph
     run = Runner(a.workload, a, dev, rank, B, H, W, N, a.channels, a.conv_mode)
     eng = run.model.engine
     graph_note = None
+    graph_selfcheck = None
     if use_graph:
         try:
             run.capture()
@@ -264,16 +304,51 @@ def main():
             print("[bench] " + graph_note, file=sys.stderr)
             use_graph = False
             FU._CAPTURE = None
+        if world > 1:
+            # Data parallel: the capture is cut at the gradient all-reduces and the collectives run eagerly between the segment
+            # replays.  Before that path is trusted with the measurement it must reproduce the eager step bit for bit, from the
+            # same state and latent draws, on every rank (one extra eager + one replayed step; the state is restored in between).
+            ok = 0.0
+            if use_graph:
+                try:
+                    ok = 1.0 if run.graph_matches_eager() else 0.0
+                except Exception as ex:
+                    print(f"[bench] graph self-check raised {type(ex).__name__}: {ex}", file=sys.stderr)
+                    FU._CAPTURE = None
+            t = torch.tensor([ok], device=dev if a.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            graph_selfcheck = bool(t.item() == 1.0)
+            if use_graph and not graph_selfcheck:
+                graph_note = ("segmented graph replay did NOT reproduce the eager data-parallel step bit for bit on every rank (or "
+                              "could not be captured everywhere): the timed steps were launched eagerly")
+                print("[bench] " + graph_note, file=sys.stderr)
+            use_graph = use_graph and graph_selfcheck
     for _ in range(a.warmup):
         run.step(use_graph)
     comm = [] if world > 1 else None
     FU.COMM_EVENTS = comm  # HIP events around the exposed part of the gradient all-reduce (rank-local)
+    comm_host = [0.0] if world > 1 else None
+    FU.COMM_HOST_S = comm_host  # host seconds inside the collective calls of the timed region
     # ---- the timed region: K steps, barrier + synchronize on both sides, max over ranks
     dt, t_enq, ms_each = timed_region(run, a.steps, use_graph, sync, world, dev)
     FU.COMM_EVENTS = None
+    FU.COMM_HOST_S = None
     exposed_ms = None
     if comm:
         exposed_ms = round(sum(e0.elapsed_time(e1) for e0, e1 in comm) / a.steps, 3)
+    # ---- data parallel: the replicas must still be bit-identical after the timed steps (same initial weights, summed gradients,
+    # rank-local Adam / EMA on identical inputs): MIN and MAX over ranks of exact digests of the student and the teacher
+    replicas = None
+    if world > 1:
+        digests = [Runner.checksum(run.model.flat_params)] + ([Runner.checksum(run.teacher.flat_params)] if run.teacher is not None else [])
+        cdev = dev if a.backend == "nccl" else "cpu"
+        lo = torch.tensor(digests, dtype=torch.int64, device=cdev)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        moved = Runner.checksum(run.model.flat_params) != run.initial_digest  # and the weights really changed
+        replicas = {"identical": bool(torch.equal(lo, hi)), "student_digest": int(lo[0].item()),
+                    "teacher_digest": int(lo[1].item()) if len(digests) > 1 else None, "weights_moved": bool(moved)}
 
     # ---- the instrumented region: the same K steps launched eagerly with HIP events around the roofline kernel's launches
     # on the launch stream (events cannot be recorded inside a captured hipGraph on this ROCm - hipErrorInvalidHandle,
@@ -315,10 +390,17 @@ def main():
                        "ms_each_step": ms_each},
         }
         if world > 1:
+            out["replicas_identical"] = replicas["identical"]
+            out["world_size_seen"] = dist.get_world_size()
             out["config"]["distributed"] = {
                 "world_size_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                "replicas": replicas, "graph_selfcheck_bit_identical_to_eager_on_every_rank": graph_selfcheck,
                 "allreduce": "flat fp32 gradient, U-Net slice launched under the encoders' backward + remainder after the regulariser",
                 "exposed_allreduce_ms_per_step_rank0": exposed_ms,
+                "host_ms_per_step_inside_collective_calls_rank0": round(1e3 * comm_host[0] / a.steps, 3),
+                "host_launch_ms_per_step_rank0": round(1e3 * (t_enq - comm_host[0]) / a.steps, 3),
+                "host_note": "host_enqueue_ms_per_step = launch work + time inside the collective calls; gloo BLOCKS the host in the "
+                             "call until the gradient exists and has crossed the host, RCCL only enqueues",
                 "exposed_note": "HIP events on the launch stream around the point where the step waits for the gradient all-reduce "
                                 "(remainder + whatever of the overlapped U-Net slice is still in flight)"}
         out["config"]["conv_arithmetic"] = {
@@ -350,10 +432,17 @@ def main():
                 if a.workload == "mean_teacher" and (B, H, W, N) == (4, 512, 512, 8) and eng.conv_mode in ("x6", "f32"):
                     fn, key = {"x6": ("pmc_hbm_traffic_x6.json", "conv3x3_x6b_kernel<3, false>"),
                                "f32": ("pmc_hbm_traffic.json", "conv_mfma_kernel<3, false>")}[eng.conv_mode]
-                    rdir = "r02" if os.path.exists(os.path.join(ROOT, "profiles", "r02", fn)) else "r01"
+                    rdir = next(r for r in ("r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", r, fn)))
                     pm = json.load(open(os.path.join(ROOT, "profiles", rdir, fn)))
                     traffic = round(pm["kernels"][key]["hbm_bytes_per_launch"])
-                    traffic_note = (f"NOT measured in this run: read from profiles/{rdir}/{fn} = rocprofv3 --pmc FETCH_SIZE (x2, gfx950 "
+                    import hashlib
+                    hh = hashlib.sha256()
+                    for f_ in ("conv_x6.hip", "wgrad_x6.hip", "common.h"):
+                        hh.update(open(os.path.join(ROOT, "probabilistic_domain_adaptation_amd", "csrc", f_), "rb").read())
+                    same = pm.get("kernel_sources_sha16") == hh.hexdigest()[:16]
+                    traffic_note = (f"NOT measured in this run: read from profiles/{rdir}/{fn}, collected at commit {pm.get('git_head', 'unknown (pre-r03 file)')}; "
+                                    f"kernel sources unchanged since that collection: {same if 'kernel_sources_sha16' in pm else 'unknown (pre-r03 file)'}; "
+                                    "= rocprofv3 --pmc FETCH_SIZE (x2, gfx950 "
                                     "correction) + WRITE_SIZE in separate passes of this same command, bytes per launch, mean over the "
                                     "launches of the forward instantiation (algorithmic mean over the forward launches: 265 MB = 144 MB "
                                     "activations in + weight planes, 121 MB out); FETCH_SIZE includes the 1.33x halo re-reads of the "
@@ -416,6 +505,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        if not replicas["identical"] or not replicas["weights_moved"]:
+            print("[bench] FAILED: the data-parallel replicas diverged (or never moved): " + json.dumps(replicas), file=sys.stderr)
+            sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -11,6 +11,7 @@ gradients are averaged over ranks (DDP convention) - see DESIGN.md §6.
 """
 from __future__ import annotations
 
+import time
 from typing import Optional
 
 import torch
@@ -186,6 +187,8 @@ def _world():
 
 _CAPTURE = None  # the GraphedStep being captured (module state of the capture in progress; captures are not re-entrant)
 COMM_EVENTS = None  # when a list (bench.py): (start, end) HIP events around the exposed part of every gradient all-reduce
+COMM_HOST_S = None  # when a one-element list (bench.py): host seconds spent INSIDE the collective calls (gloo blocks the host
+#                     until the gradient exists - RCCL only enqueues; the rest of a step's host time is launch work)
 
 
 def allreduce_grads(gflat: torch.Tensor, started: Optional[dict] = None) -> float:
@@ -201,11 +204,14 @@ def allreduce_grads(gflat: torch.Tensor, started: Optional[dict] = None) -> floa
             if ev is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
+            t0 = time.perf_counter() if COMM_HOST_S is not None else 0.0
             if started:
                 dist.all_reduce(gflat[started["numel"]:], op=dist.ReduceOp.SUM)
                 started["work"].wait()
             else:
                 dist.all_reduce(gflat, op=dist.ReduceOp.SUM)
+            if COMM_HOST_S is not None:
+                COMM_HOST_S[0] += time.perf_counter() - t0
             if ev is not None:  # the launch stream now waits for the collective: e1 - e0 = what the overlap did not hide
                 e1.record()
                 ev.append((e0, e1))
@@ -244,7 +250,10 @@ def elbo_grad_pass(model: ProbabilisticUnet, gflat, x, y, z, eps, gscale: float,
         n = model.layout.unet_numel
 
         def launch():
+            t0 = time.perf_counter() if COMM_HOST_S is not None else 0.0
             started["work"] = dist.all_reduce(gflat[:n], op=dist.ReduceOp.SUM, async_op=True)
+            if COMM_HOST_S is not None:
+                COMM_HOST_S[0] += time.perf_counter() - t0
 
         def hook():
             started["numel"] = n

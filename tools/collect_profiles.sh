@@ -3,6 +3,8 @@
 # in separate passes - never combined with tracing domains other than --kernel-trace -, the other workloads, the graph probe).
 out=${1:-gpurun_out/prof_r02}
 mkdir -p $out
+# what the counters belong to: the commit handed in by the caller (the box has no .git) and a digest of the kernel sources here
+echo "${PUNET_GIT_HEAD:-unknown} $(cat probabilistic_domain_adaptation_amd/csrc/conv_x6.hip probabilistic_domain_adaptation_amd/csrc/wgrad_x6.hip probabilistic_domain_adaptation_amd/csrc/common.h | sha256sum | cut -c1-16)" > $out/collected_at.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python3 tools/probe_graph_events.py > $out/graph_event_probe.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py > $out/bench_under_rocprof.json 2> $out/stats.err

@@ -42,7 +42,17 @@ def main():
         out[short(k)] = {"launches": n, "fetch_bytes_per_launch": 2.0 * 1024.0 * f[0] / max(f[1], 1),
                          "write_bytes_per_launch": 1024.0 * w[0] / max(w[1], 1)}
         out[short(k)]["hbm_bytes_per_launch"] = out[short(k)]["fetch_bytes_per_launch"] + out[short(k)]["write_bytes_per_launch"]
-    json.dump({"note": "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM; separate --pmc passes", "kernels": out},
+    # what the numbers belong to: the commit the collecting script was handed ($PUNET_GIT_HEAD; the GPU box has no .git) and a
+    # digest of the kernel sources as they were when the counters ran - bench.py compares it with the sources it runs
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("conv_x6.hip", "wgrad_x6.hip", "common.h"):
+        h.update(open(os.path.join(root, "probabilistic_domain_adaptation_amd", "csrc", f), "rb").read())
+    json.dump({"note": "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM; separate --pmc passes", "kernels": out,
+               "git_head": os.environ.get("PUNET_GIT_HEAD", "unknown"),
+               "kernel_sources_sha16": os.environ.get("PUNET_SOURCES_SHA16") or h.hexdigest()[:16]},
               open(sys.argv[3], "w"), indent=1, sort_keys=True)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]:
         print(f"{k:40s} launches {v['launches']:4d}  fetch {v['fetch_bytes_per_launch']/1e6:9.1f} MB  write "

@@ -57,6 +57,13 @@ json.dump({"kernel": "conv3x3_x6b_kernel<3, false>",
 
 subprocess.check_call([sys.executable, os.path.join(here, "pmc_mfma.py"), one("pmc_mfma/*/*_counter_collection.csv"),
                        os.path.join(dst, "pmc_mfma_util_x6.json")])
+# stamp the traffic file with the commit the collection ran at (tools/collect_profiles.sh records HEAD of the pushed snapshot in
+# collected_at.txt: "<git head> <sha16 of the kernel sources on the box>")
+env = dict(os.environ)
+stamp = os.path.join(src, "collected_at.txt")
+if os.path.exists(stamp):
+    head, sha = open(stamp).read().split()[:2]
+    env.update(PUNET_GIT_HEAD=head, PUNET_SOURCES_SHA16=sha)
 subprocess.check_call([sys.executable, os.path.join(here, "pmc_traffic.py"), one("pmc_fetch/*/*_counter_collection.csv"),
-                       one("pmc_write/*/*_counter_collection.csv"), os.path.join(dst, "pmc_hbm_traffic_x6.json")])
+                       one("pmc_write/*/*_counter_collection.csv"), os.path.join(dst, "pmc_hbm_traffic_x6.json")], env=env)
 print(open(os.path.join(dst, "default_command_headline_part_roofline_kernel.json")).read())
