@@ -260,6 +260,37 @@ int punet_fcomb_sample_x6_bf16s(const void* feat, const float* w1, const float* 
                                 float* logits, int N, int B, int HW, int CH, int nmid, float upper, float lower, int masking,
                                 void* stream);
 
+/* ---- fp16-operand fast modes (the reference scripts' mixed_precision=True, LIVECell/livecell_mt.py:107, is fp16
+ *      autocast + GradScaler).  "f16x3": every fp32 operand = two fp16 planes h + l, products hh + hl + lh on
+ *      v_mfma_f32_*_f16 with fp32 accumulation (22-23 significand bits at half the matrix-pipe time of the six-product parity
+ *      arithmetic); "f16": one plane (11 bits, what autocast computes with).  fp16 has 5 exponent bits, so every tensor is
+ *      brought into range by an EXACT power of two from its amax: an amax slot is one device float holding (a bound of) max |v|,
+ *      published by the producing kernel with an order-independent atomic max (bit-reproducible); the consumer scales by
+ *      2^(14 - floor(log2 amax)) before the split and the epilogue rescales by the exact inverse - the per-tensor counterpart of
+ *      the reference's one global loss scale, with no overflow and no skipped steps.  NOT parity modes.
+ *      Weight planes: punet_split_weights_f16[_batch] = amax per slab (slot j of wamax for table row j) + planes in the layout
+ *      of punet_split_weights_x6 (16-bit elements, planes 0 and 1).  amax_* arguments may be NULL (scale 1 / not published);
+ *      a slot that receives a publication must have been zeroed (or hold an earlier bound of the same tensor). */
+int punet_split_weights_f16(const float* w, void* planes, long plane_stride, int cin, int cout, int mode, float* amax_w,
+                            void* stream);
+int punet_split_weights_f16_batch(const float* flat, void* planes, const long* table, int nconv, long total_units, int mode,
+                                  float* wamax, int compute_amax, void* stream);
+/* forward (bias / relu / gate_out / pool_out) or input gradient (mask | gate_bits, accumulate) as punet_conv3x3_x6_gated /
+ * _pooled; planes = 2 ("f16x3") or 1 ("f16") */
+int punet_conv3x3_f16(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride, int n_row,
+                      int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
+                      const void* gate_bits, void* gate_out, float* pool_out, int accumulate, int relu, int B, int H, int W,
+                      int planes, const float* amax_x0, const float* amax_x1, const float* amax_w, float* amax_y, void* stream);
+/* weight (+ bias) gradient as punet_conv_wgrad_x6; x16 != 0: x is STORED as fp16 (planes = 1, unscaled) */
+int punet_conv_wgrad_f16(const void* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off, float* dbias,
+                         float* workspace, int nslices, int B, int H, int W, int accumulate, float scale, int planes, int x16,
+                         const float* amax_x, const float* amax_dz, void* stream);
+/* slot = max(slot, max |x|) over n floats (x 16-byte aligned; zero_first != 0 clears the slot first) - for tensors whose producer
+ * publishes no amax; and a BOUND composed from other slots, out = ca * a + cb * b (a or b may be NULL; out may alias b): e.g. the
+ * average-pool backward's output is bounded by |dy| / 4 (+ what it accumulates onto), the x2 up-sampling backward's by 4 |dy| */
+int punet_amax(const float* x, long n, float* slot, int zero_first, void* stream);
+int punet_amax_bound(const float* a, float ca, const float* b, float cb, float* out, void* stream);
+
 /* ---- K8: the reduction half of K7 on given logits[N][P] (unit parity of the consensus rule) */
 int punet_consensus(const float* logits, int N, long P, float upper, float lower, int masking, float* y, float* z,
                     void* stream);

@@ -30,6 +30,12 @@ _SIGS = {
     "punet_gate_dwords": (_sz, [_i, _i, _i, _i]),
     "punet_conv3x3_x6_gated": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "punet_conv3x3_x6_pooled": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "punet_conv3x3_f16": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "punet_split_weights_f16": (_i, [_p, _p, _l, _i, _i, _i, _p, _p]),
+    "punet_split_weights_f16_batch": (_i, [_p, _p, _p, _i, _l, _i, _p, _i, _p]),
+    "punet_conv_wgrad_f16": (_i, [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p, _p]),
+    "punet_amax": (_i, [_p, _l, _p, _i, _p]),
+    "punet_amax_bound": (_i, [_p, _f, _p, _f, _p, _p]),
     "punet_conv1x1_x6_gated": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "punet_wgrad_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "punet_wgrad_slices": (_i, [_i, _i, _i, _i, _i]),

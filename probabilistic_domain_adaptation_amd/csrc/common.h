@@ -95,3 +95,69 @@ __device__ __forceinline__ void split3_quad(const float4& r, uint2& h, uint2& m,
     split3_pair<NP>(r.x, r.y, h.x, m.x, l.x);
     split3_pair<NP>(r.z, r.w, h.y, m.y, l.y);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp16-operand arithmetic ("f16x3" = two fp16 planes, hh + hl + lh: 22-23 significand bits; "f16" = one plane: the analogue of
+// the reference scripts' fp16 autocast, LIVECell/livecell_mt.py:107).  fp16 has 5 exponent bits, so every tensor is brought into
+// range by an EXACT power of two taken from its amax (max |v|, published by the producing kernel into a device slot with an
+// order-independent atomic max on the float's bits): s = 2^(14 - floor(log2(amax))), i.e. the largest magnitude lands in
+// [2^14, 2^15) and everything down to 2^-24 (fp16's smallest subnormal) of that keeps absolute precision 2^-25 - 39 binades
+// below the tensor's maximum.  Products are rescaled by the exact inverse in the epilogue.  (The reference's GradScaler does
+// the same job with one global loss scale; a per-tensor scale cannot overflow and needs no skipped steps.)
+typedef _Float16 punet_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 punet_f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 punet_bf16x8 __attribute__((ext_vector_type(8)));
+
+// scale (a power of two) for a tensor whose amax slot holds `amax` (>= 0; 0 or non-finite -> 1)
+__device__ __forceinline__ float punet_f16_scale_of(float amax) {
+    const unsigned b = __builtin_bit_cast(unsigned, amax);
+    const int e = (int)((b >> 23) & 0xffu);            // biased exponent of amax (0: zero / subnormal, 255: inf / nan)
+    if (e == 0 || e == 255) return 1.f;
+    int se = 127 + 14 - (e - 127);                     // biased exponent of 2^(14 - floor(log2 amax))
+    se = se < 1 ? 1 : (se > 254 ? 254 : se);
+    return __builtin_bit_cast(float, (unsigned)se << 23);
+}
+__device__ __forceinline__ float punet_f16_scale_from(const float* slot) { return slot ? punet_f16_scale_of(*slot) : 1.f; }
+
+// amax slot update: |v| as unsigned bits (monotone for non-negative floats); NaN-free inputs assumed (a NaN would publish a
+// huge pattern -> scale 2^-113..: the consumer's values underflow to zero, the NaN itself still propagates through the MFMAs)
+__device__ __forceinline__ void punet_amax_publish(float* slot, float wave_local_max) {
+    float m = wave_local_max;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, m));
+}
+
+// scaled fp32 -> fp16 planes h (+ l) of a PAIR of values (v_pk_mul_f32, v_cvt_pk_f16_f32, one v_pk_fma_f32 for the residual)
+template <int NP>
+__device__ __forceinline__ void splitf16_pair(float a, float b, float s, unsigned& h, unsigned& l) {
+    const punet_f32x2 x = {a * s, b * s};
+    const punet_f16x2 h2 = __builtin_convertvector(x, punet_f16x2);
+    h = __builtin_bit_cast(unsigned, h2);
+    l = 0u;
+    if (NP > 1) {
+        const punet_f32x2 r = x - __builtin_convertvector(h2, punet_f32x2);
+        l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, punet_f16x2));
+    }
+}
+template <int NP>
+__device__ __forceinline__ void splitf16_quad(const float4& r, float s, uint2& h, uint2& l) {
+    splitf16_pair<NP>(r.x, r.y, s, h.x, l.x);
+    splitf16_pair<NP>(r.z, r.w, s, h.y, l.y);
+}
+
+// one MFMA on 16-byte fragments held as uint4, element type selected at compile time
+template <bool F16>
+__device__ __forceinline__ f32x4 punet_mfma16(const uint4& a, const uint4& b, f32x4 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(punet_f16x8, a), __builtin_bit_cast(punet_f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(punet_bf16x8, a), __builtin_bit_cast(punet_bf16x8, b), c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 punet_mfma32(const uint4& a, const uint4& b, f32x16 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(punet_f16x8, a), __builtin_bit_cast(punet_f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(punet_bf16x8, a), __builtin_bit_cast(punet_bf16x8, b), c, 0, 0, 0);
+}

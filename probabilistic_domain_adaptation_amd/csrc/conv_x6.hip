@@ -56,6 +56,12 @@ struct ConvX6Args {
     int accumulate, relu;
     int B, H, W, ntiles;
     int xcd_remap;
+    // fp16-operand instantiations (F16; common.h): amax slots of the two sources and of the weight slab (device floats; nullptr =
+    // scale 1) and the slot the output's amax is published to (nullable)
+    const float* amax_x0;
+    const float* amax_x1;
+    const float* amax_w;
+    float* amax_out;
     unsigned m_ntn, m_tx, m_ty;  // floor(2^32 / d) + 1 for d = channel blocks, tiles per row, tile rows: n / d = mulhi(n, m)
 };                               // exactly while n * d < 2^32 (host check) - the tile decode without a division
 
@@ -86,9 +92,15 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
 // KS = 3 or 1 (the Fcomb layers): with one tap the "last tap, two chunks per K-step" pairing is the whole K loop.
 // IO16 (one-plane forward only; the opt-in "bf16s" fast mode): the activation tensors x0, x1, y and pool_out hold bf16 instead
 // of fp32 - the staging loads are half the bytes and need no conversion, the epilogue stores 8 instead of 16 bytes per quad.
-template <int NP, bool DGRAD, int KS = 3, bool IO16 = false>
+// F16: fp16 instead of bf16 planes (NP <= 2), operands scaled by exact powers of two from their amax slots (common.h), the
+// epilogue rescales and publishes the output's amax.  IO16 && F16: the activation tensors hold fp16 (UNscaled, as under the
+// reference's fp16 autocast; outputs are clamped to fp16's range).
+template <int NP, bool DGRAD, int KS = 3, bool IO16 = false, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
-    static_assert(!IO16 || (NP == 1 && !DGRAD), "bf16 activation storage exists for the one-plane forward kernel only");
+    static_assert(!IO16 || (NP == 1 && !DGRAD), "16-bit activation storage exists for the one-plane forward kernel only");
+    static_assert(!F16 || NP <= 2, "fp16 operands: one or two planes");
+    typedef typename std::conditional<F16, _Float16, __bf16>::type S16;  // element type of 16-bit activation storage
+    typedef S16 s16x4 __attribute__((ext_vector_type(4)));
     constexpr int KK = KS * KS, PAD = KS / 2;
     constexpr int HTH = TH + KS - 1, HTW = TW + KS - 1;
     constexpr int NPIX = HTH * HTW;
@@ -116,6 +128,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
     const int N = a.n_total;
     const int K = a.c0 + a.c1;
     const int nchunks = K / CK;
+    float sx = 1.f, inv = 1.f, amax_run = 0.f;  // F16: operand scale, its inverse incl. the weights', running |output| maximum
+    if constexpr (F16) {
+        if (a.amax_x0 || a.amax_x1) sx = punet_f16_scale_of(fmaxf(a.amax_x0 ? *a.amax_x0 : 0.f, a.amax_x1 ? *a.amax_x1 : 0.f));
+        inv = 1.f / (sx * punet_f16_scale_from(a.amax_w));
+    }
 
     auto decode = [&](int tile) {
         TileInfo t;
@@ -185,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
         // raw value: the out-of-image zeroing happens where the register is consumed (split_unit) - a select right here
         // would make the wave wait for the load it has just issued
         if constexpr (IO16) {
-            const __bf16* s16 = reinterpret_cast<const __bf16*>(kbase < a.c0 ? a.x0 : a.x1) + (size_t)xb * ((size_t)(a.H * a.W) * cs);
+            const S16* s16 = reinterpret_cast<const S16*>(kbase < a.c0 ? a.x0 : a.x1) + (size_t)xb * ((size_t)(a.H * a.W) * cs);
             rx16[it] = *reinterpret_cast<const uint2*>(s16 + (unsigned)(xpix[it] * cs + coff + q * 4));
             return make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
@@ -218,8 +235,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
             return;
         }
         const float4 r = xin[it] ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding outside the image
-        uint2 ph, pm, pl;
-        split3_quad<NP>(r, ph, pm, pl);
+        uint2 ph, pm, pl = make_uint2(0u, 0u);
+        if constexpr (F16) splitf16_quad<NP>(r, sx, ph, pm); else split3_quad<NP>(r, ph, pm, pl);
         px[it][0] = __builtin_bit_cast(bf16x4, ph);
         if (NP > 1) px[it][NP > 1 ? 1 : 0] = __builtin_bit_cast(bf16x4, pm);
         if (NP > 2) px[it][NP > 2 ? 2 : 0] = __builtin_bit_cast(bf16x4, pl);
@@ -261,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
         // uniform 64-bit base of image ti.b in the output-shaped tensors; offsets inside the image stay 32-bit
         const size_t img = (size_t)ti.b * ((size_t)(a.H * a.W) * N);
         // (IO16: y / pool_out hold bf16 - the element offsets below are halved in bytes by addressing through __bf16*)
-        float* const yb = IO16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(a.y) + img) : a.y + img;
+        float* const yb = IO16 ? reinterpret_cast<float*>(reinterpret_cast<S16*>(a.y) + img) : a.y + img;
         const float* const mb = a.mask ? a.mask + img : nullptr;
         // all eight bias quads first (one latency; per-quad loads inside the store loop had been a chain of 16 dependent L2
         // round trips per tile - 16k cycles, 17 % of a 64-channel layer's tile)
@@ -288,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
             const unsigned pbase1 = pbase0 + (unsigned)(a.W * N);
             const unsigned qbase = (unsigned)(((gy0 >> 1) * (a.W >> 1) + (gx >> 1)) * N + ti.n0 + 4 * half);
             float* const qb = !a.pool_out ? nullptr  // the pooled image has a quarter of the pixels
-                              : IO16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(a.pool_out) + (img >> 2)) : a.pool_out + (img >> 2);
+                              : IO16 ? reinterpret_cast<float*>(reinterpret_cast<S16*>(a.pool_out) + (img >> 2)) : a.pool_out + (img >> 2);
             unsigned gout0 = 0u, gout1 = 0u;
             auto partner = [](float v) __attribute__((always_inline)) {  // value of lane ^ 1 (quad_perm [1, 0, 3, 2])
                 return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
@@ -302,6 +319,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                     float4 v0 = make_float4(acc[0][nb][4 * rg + 0], acc[0][nb][4 * rg + 1], acc[0][nb][4 * rg + 2], acc[0][nb][4 * rg + 3]);
                     float4 v1 = make_float4(acc[1][nb][4 * rg + 0], acc[1][nb][4 * rg + 1], acc[1][nb][4 * rg + 2], acc[1][nb][4 * rg + 3]);
                     const float4 bq = bq4[nb][rg];
+                    if constexpr (F16) {  // exact: inv is a power of two
+                        v0.x *= inv; v0.y *= inv; v0.z *= inv; v0.w *= inv;
+                        v1.x *= inv; v1.y *= inv; v1.z *= inv; v1.w *= inv;
+                    }
                     v0.x += bq.x; v0.y += bq.y; v0.z += bq.z; v0.w += bq.w;
                     v1.x += bq.x; v1.y += bq.y; v1.z += bq.z; v1.w += bq.w;
                     if (a.relu) {
@@ -310,13 +331,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                     }
                     auto store4 = [](float* base, unsigned off, const float4& v) __attribute__((always_inline)) {
                         if constexpr (IO16) {
-                            bf16x4 o;
-                            o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-                            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + off) = o;
+                            s16x4 o;
+                            if constexpr (F16) {  // fp16 storage: saturate instead of producing inf (65504 = fp16's largest finite value)
+                                o[0] = (S16)__builtin_amdgcn_fmed3f(v.x, -65504.f, 65504.f); o[1] = (S16)__builtin_amdgcn_fmed3f(v.y, -65504.f, 65504.f);
+                                o[2] = (S16)__builtin_amdgcn_fmed3f(v.z, -65504.f, 65504.f); o[3] = (S16)__builtin_amdgcn_fmed3f(v.w, -65504.f, 65504.f);
+                            } else {
+                                o[0] = (S16)v.x; o[1] = (S16)v.y; o[2] = (S16)v.z; o[3] = (S16)v.w;
+                            }
+                            *reinterpret_cast<s16x4*>(reinterpret_cast<S16*>(base) + off) = o;
                         } else {
                             *reinterpret_cast<float4*>(base + off) = v;
                         }
                     };
+                    if constexpr (F16) {
+                        if (in0 && okc) amax_run = fmaxf(fmaxf(amax_run, fmaxf(fabsf(v0.x), fabsf(v0.y))), fmaxf(fabsf(v0.z), fabsf(v0.w)));
+                        if (in1 && okc) amax_run = fmaxf(fmaxf(amax_run, fmaxf(fabsf(v1.x), fabsf(v1.y))), fmaxf(fabsf(v1.z), fabsf(v1.w)));
+                    }
                     if (in0 && okc) {
                         store4(yb, pbase0 + ch, v0);
                         gout0 |= ((v0.x > 0.f ? 1u : 0u) | (v0.y > 0.f ? 2u : 0u) | (v0.z > 0.f ? 4u : 0u) | (v0.w > 0.f ? 8u : 0u))
@@ -357,6 +387,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                     const int ch = nb * 32 + rg * 8;  // + 4 * half + e
                     const bool ok = pix_in && ti.n0 + ch + 4 * half < N;  // N is a multiple of 4
                     float4 v = make_float4(acc[m][nb][4 * rg + 0], acc[m][nb][4 * rg + 1], acc[m][nb][4 * rg + 2], acc[m][nb][4 * rg + 3]);
+                    if constexpr (F16) { v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv; }
                     if (!DGRAD) {
                         v.x += bq4[nb][rg].x; v.y += bq4[nb][rg].y; v.z += bq4[nb][rg].z; v.w += bq4[nb][rg].w;
                         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -376,6 +407,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
                             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                         }
                         *reinterpret_cast<float4*>(yb + pbase + ch) = v;
+                        if constexpr (F16) amax_run = fmaxf(fmaxf(amax_run, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                         if (!DGRAD)
                             gout |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u))
                                     << (16 * nb + 4 * rg);
@@ -419,15 +451,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
             for (int nb = 0; nb < 2; ++nb) {
                 f32x16 c = acc[m][nb];
                 if (NP > 2) {
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[P1][nb].v, av[P1][m].v, c, 0, 0, 0);  // mm
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[0][nb].v, av[P2][m].v, c, 0, 0, 0);   // lh
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[P2][nb].v, av[0][m].v, c, 0, 0, 0);   // hl
+                    c = punet_mfma32<F16>(bv[P1][nb].u, av[P1][m].u, c);  // mm
+                    c = punet_mfma32<F16>(bv[0][nb].u, av[P2][m].u, c);   // lh
+                    c = punet_mfma32<F16>(bv[P2][nb].u, av[0][m].u, c);   // hl
                 }
                 if (NP > 1) {
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[0][nb].v, av[P1][m].v, c, 0, 0, 0);  // mh
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[P1][nb].v, av[0][m].v, c, 0, 0, 0);  // hm
+                    c = punet_mfma32<F16>(bv[0][nb].u, av[P1][m].u, c);  // mh
+                    c = punet_mfma32<F16>(bv[P1][nb].u, av[0][m].u, c);  // hm
                 }
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[0][nb].v, av[0][m].v, c, 0, 0, 0);  // hh
+                c = punet_mfma32<F16>(bv[0][nb].u, av[0][m].u, c);  // hh
                 acc[m][nb] = c;
             }
     };
@@ -489,6 +521,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
         if (ch == 0) continue;  // odd chunk count: the tile ended on an even chunk, the next tile starts even again
         if (phase(std::integral_constant<int, 1>{})) break;
     }
+    if constexpr (F16) {
+        if (a.amax_out) punet_amax_publish(a.amax_out, amax_run);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -537,8 +572,11 @@ __device__ unsigned long long punet_x6b_trace[4 * 16];  // top barrier passed, o
 #ifndef X6B_VECTOR_WAVE  // 1 = the wave index as a VGPR value (the form before round 2's scalar wave index), for A/B runs
 #define X6B_VECTOR_WAVE 0
 #endif
-template <int NP, bool DGRAD>
+// F16: fp16 planes (NP = 2: h + l, products hh + hl + lh; NP = 1: h) with power-of-two scaling from the operands' amax slots
+// (common.h) instead of bf16 planes; the epilogue rescales by the exact inverse and publishes the output's amax.
+template <int NP, bool DGRAD, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
+    static_assert(!F16 || NP <= 2, "fp16 operands: one or two planes");
     constexpr int KS = 3, KK = 9, PAD = 1;
     constexpr int HTH = TH + KS - 1, HTW = TW + KS - 1;
     constexpr int NPIX = HTH * HTW;
@@ -573,6 +611,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     const int N = a.n_total;
     const int K = a.c0 + a.c1;
     const int nchunks = K / CK;  // a multiple of 4 (host check)
+    // F16: operand scales (exact powers of two; block-uniform scalars) and the running |output| maximum of this thread
+    float sx = 1.f, inv = 1.f, amax_run = 0.f;
+    if constexpr (F16) {
+        if (a.amax_x0 || a.amax_x1) sx = punet_f16_scale_of(fmaxf(a.amax_x0 ? *a.amax_x0 : 0.f, a.amax_x1 ? *a.amax_x1 : 0.f));
+        inv = 1.f / (sx * punet_f16_scale_from(a.amax_w));
+    }
 
     // block-uniform and scalar: tile -> (channel block, tile column, tile row, image) by multiplications with the host's
     // reciprocals (s_mul_hi_u32) - integer division has no scalar instruction and compiles to ~30 vector instructions each
@@ -650,8 +694,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     bf16x4 px[XITER][NP];
     auto split_unit = [&](int it) __attribute__((always_inline)) {
         const float4 r = xin[it] ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);
-        uint2 ph_, pm, pl;
-        split3_quad<NP>(r, ph_, pm, pl);
+        uint2 ph_, pm, pl = make_uint2(0u, 0u);
+        if constexpr (F16) splitf16_quad<NP>(r, sx, ph_, pm); else split3_quad<NP>(r, ph_, pm, pl);
 #if X6B_PIN_SPLIT
         // the planes are only needed by the NEXT commit: without a use here the optimiser sinks the whole split behind the
         // chunk's last MFMA (a ~75-instruction vector blob in front of the barrier) instead of leaving it in their shadow
@@ -747,15 +791,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
             for (int cb = 0; cb < 4; ++cb) {
                 f32x4 c = acc[pb][cb];
                 if (NP > 2) {
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[P1][cb].v, A[P1].v, c, 0, 0, 0);  // mm
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0][cb].v, A[P2].v, c, 0, 0, 0);   // lh
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[P2][cb].v, A[0].v, c, 0, 0, 0);   // hl
+                    c = punet_mfma16<F16>(bw[P1][cb].u, A[P1].u, c);  // mm
+                    c = punet_mfma16<F16>(bw[0][cb].u, A[P2].u, c);   // lh
+                    c = punet_mfma16<F16>(bw[P2][cb].u, A[0].u, c);   // hl
                 }
                 if (NP > 1) {
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0][cb].v, A[P1].v, c, 0, 0, 0);  // mh
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[P1][cb].v, A[0].v, c, 0, 0, 0);  // hm
+                    c = punet_mfma16<F16>(bw[0][cb].u, A[P1].u, c);  // mh
+                    c = punet_mfma16<F16>(bw[P1][cb].u, A[0].u, c);  // hm
                 }
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0][cb].v, A[0].v, c, 0, 0, 0);  // hh
+                c = punet_mfma16<F16>(bw[0][cb].u, A[0].u, c);  // hh
                 acc[pb][cb] = c;
             }
             if (pb == 1) mid();  // staging work of the next chunk, in the shadow of this K-step's MFMAs
@@ -840,6 +884,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
                     const bool ok = F || (pix_in && cq + 16 * cb < N);
                     const int sh = 16 * (cb >> 1) + 8 * (cb & 1) + 4 * (g >> 1);  // this quad's nibble in its dword
                     f32x4 v = acc[2 * m + h][cb];
+                    if constexpr (F16) v *= inv;  // exact: inv is a power of two
                     if (!DGRAD) {
                         v += bq[cb];
                         if (f_relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
@@ -859,6 +904,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
                         if (v[0] == 1.2345e-30f)
 #endif
                         *reinterpret_cast<f32x4*>(yb + pbase + 16 * cb) = v;
+                        if constexpr (F16) amax_run = fmaxf(fmaxf(amax_run, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                         if (!DGRAD) gout |= nibble(v) << sh;
                     }
                 }
@@ -875,7 +921,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
                 float* const qb = a.pool_out + (img >> 2);  // the pooled image has a quarter of the pixels
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
-                    f32x4 v0 = acc[h][cb] + bq[cb], v1 = acc[2 + h][cb] + bq[cb], q;  // recomputed: no live copies of the rows
+                    f32x4 v0 = acc[h][cb], v1 = acc[2 + h][cb], q;  // recomputed: no live copies of the rows
+                    if constexpr (F16) { v0 *= inv; v1 *= inv; }
+                    v0 += bq[cb]; v1 += bq[cb];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (f_relu) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
@@ -990,6 +1038,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         if (phase(std::integral_constant<int, 2>{})) break;
         if (phase(std::integral_constant<int, 3>{})) break;
     }
+    if constexpr (F16) {
+        if (a.amax_out) punet_amax_publish(a.amax_out, amax_run);
+    }
 }
 
 // planes[p][t'][k/8][n][8] <- split(w) ; mode 0 (forward): k = cin, n = cout, t' = t ;
@@ -1058,7 +1109,157 @@ __global__ __launch_bounds__(256) void split_weights_x6_batch_kernel(const float
     }
 }
 
+// ---- fp16 planes of the weight slabs ("f16x3" / "f16"): per-slab amax first (slot j of wamax), then h (+ l) of w * 2^k with
+// the slab's power-of-two scale (common.h); same [plane][t'][k/8][n][8] layout and placement as the bf16 planes (16-bit
+// elements), plane 2 unused.  A unit of the amax pass is 8 CONSECUTIVE floats of the slab (any partition does for a maximum).
+__global__ __launch_bounds__(256) void slab_amax_batch_kernel(const float* __restrict__ flat, const long* __restrict__ table, int nconv,
+                                                              float* __restrict__ wamax) {
+    const long total = table[(size_t)nconv * 4 + 3];
+    const long rounds = (total + (long)gridDim.x * blockDim.x - 1) / ((long)gridDim.x * blockDim.x);
+    for (long r = 0; r < rounds; ++r) {  // whole waves stay in the loop (the wave-level reduction needs every lane)
+        const long i = r * (long)gridDim.x * blockDim.x + (long)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool live = i < total;
+        int lo = 0;
+        float m = 0.f;
+        if (live) {
+            int hi = nconv - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (table[(size_t)mid * 4 + 3] <= i) lo = mid; else hi = mid - 1;
+            }
+            const float4* w = reinterpret_cast<const float4*>(flat + table[(size_t)lo * 4 + 0] + 8 * (i - table[(size_t)lo * 4 + 3]));
+            const float4 a = w[0], b = w[1];
+            m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                      fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+        }
+        const int lo0 = __builtin_amdgcn_readfirstlane(lo);
+        if (__all(live && lo == lo0)) {  // the whole wave inside one slab (all but the waves that straddle a slab boundary)
+            punet_amax_publish(wamax + lo0, m);
+        } else if (live) {
+            atomicMax(reinterpret_cast<unsigned*>(wamax + lo), __builtin_bit_cast(unsigned, m));
+        }
+    }
+}
+
+template <int NPL>
+__device__ __forceinline__ void splitf16_store(const float (&v)[8], float sc, __bf16* dst, long plane_stride) {
+    uint4 h, l;
+    unsigned* hp = reinterpret_cast<unsigned*>(&h);
+    unsigned* lp = reinterpret_cast<unsigned*>(&l);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) splitf16_pair<NPL>(v[2 * e], v[2 * e + 1], sc, hp[e], lp[e]);
+    *reinterpret_cast<uint4*>(dst) = h;
+    if (NPL > 1) *reinterpret_cast<uint4*>(dst + plane_stride) = l;
+}
+
+__global__ __launch_bounds__(256) void split_weights_f16_batch_kernel(const float* __restrict__ flat, __bf16* __restrict__ planes,
+                                                                      const long* __restrict__ table, int nconv, int mode,
+                                                                      const float* __restrict__ wamax) {
+    const long total = table[(size_t)nconv * 4 + 3];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = nconv - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (table[(size_t)mid * 4 + 3] <= i) lo = mid; else hi = mid - 1;
+        }
+        const long w_off = table[(size_t)lo * 4 + 0];
+        const int cin = (int)table[(size_t)lo * 4 + 1], cout = (int)table[(size_t)lo * 4 + 2];
+        const long u = i - table[(size_t)lo * 4 + 3];
+        const float* w = flat + w_off;
+        __bf16* pl = planes + 3 * w_off;
+        const long plane_stride = 9l * cin * cout;
+        const int K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+        const int KC = K / 8;
+        const int n = (int)(u % N);
+        const int kc = (int)((u / N) % KC);
+        const int tp = (int)(u / ((long)N * KC));
+        const int t = mode == 0 ? tp : 8 - tp;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = kc * 8 + e;
+            v[e] = mode == 0 ? w[((size_t)t * cin + k) * cout + n] : w[((size_t)t * cin + n) * cout + k];
+        }
+        splitf16_store<2>(v, punet_f16_scale_of(wamax[lo]), pl + u * 8, plane_stride);
+    }
+}
+
+// one slab (unit tests / callers with their own layout): amax into slot[0], then the planes
+__global__ __launch_bounds__(256) void slab_amax_kernel(const float* __restrict__ w, size_t n, float* __restrict__ slot) {
+    float m = 0.f;
+    const size_t rounds = (n + (size_t)gridDim.x * blockDim.x - 1) / ((size_t)gridDim.x * blockDim.x);
+    for (size_t r = 0; r < rounds; ++r) {
+        const size_t i = r * (size_t)gridDim.x * blockDim.x + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < n) m = fmaxf(m, fabsf(w[i]));
+    }
+    punet_amax_publish(slot, m);
+}
+
+__global__ __launch_bounds__(256) void split_weights_f16_kernel(const float* __restrict__ w, __bf16* __restrict__ planes,
+                                                                long plane_stride, int cin, int cout, int kk, int mode,
+                                                                const float* __restrict__ slot) {
+    const int K = mode == 0 ? cin : cout, N = mode == 0 ? cout : cin;
+    const int KC = K / 8;
+    const size_t total = (size_t)kk * KC * N;
+    const float sc = punet_f16_scale_of(slot[0]);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N);
+        const int kc = (int)((i / N) % KC);
+        const int tp = (int)(i / ((size_t)N * KC));
+        const int t = mode == 0 ? tp : kk - 1 - tp;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = kc * 8 + e;
+            v[e] = mode == 0 ? w[((size_t)t * cin + k) * cout + n] : w[((size_t)t * cin + n) * cout + k];
+        }
+        splitf16_store<2>(v, sc, planes + i * 8, plane_stride);
+    }
+}
+
 }  // namespace
+
+extern "C" int punet_split_weights_f16(const float* w, void* planes, long plane_stride, int cin, int cout, int mode, float* amax_w,
+                                       void* stream) {
+    PUNET_CHECK_ARG(w && planes && amax_w && cin > 0 && cout > 0 && (mode == 0 || mode == 1), "punet_split_weights_f16: bad args");
+    PUNET_CHECK_ARG((mode == 0 ? cin : cout) % 8 == 0, "punet_split_weights_f16: the contracted channel count must be a multiple of 8");
+    PUNET_CHECK_ARG(plane_stride >= 9l * cin * cout, "punet_split_weights_f16: plane_stride too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(amax_w, 0, sizeof(float), st) != hipSuccess) {
+        punet_set_error("punet_split_weights_f16: memset failed");
+        return PUNET_ERR_HIP;
+    }
+    const size_t n = (size_t)9 * cin * cout;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    slab_amax_kernel<<<grid, 256, 0, st>>>(w, n, amax_w);
+    PUNET_LAUNCH_CHECK("slab_amax");
+    grid = (int)((n / 8 + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    split_weights_f16_kernel<<<grid, 256, 0, st>>>(w, (__bf16*)planes, plane_stride, cin, cout, 9, mode, amax_w);
+    PUNET_LAUNCH_CHECK("split_weights_f16");
+    return PUNET_OK;
+}
+
+extern "C" int punet_split_weights_f16_batch(const float* flat, void* planes, const long* table, int nconv, long total_units,
+                                             int mode, float* wamax, int compute_amax, void* stream) {
+    PUNET_CHECK_ARG(flat && planes && table && wamax && nconv > 0 && total_units > 0 && (mode == 0 || mode == 1),
+                    "punet_split_weights_f16_batch: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    long grid = (total_units + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (compute_amax) {  // (the forward and the input-gradient orientation of one weight state share the slots: compute once)
+        if (hipMemsetAsync(wamax, 0, sizeof(float) * (size_t)nconv, st) != hipSuccess) {
+            punet_set_error("punet_split_weights_f16_batch: memset failed");
+            return PUNET_ERR_HIP;
+        }
+        slab_amax_batch_kernel<<<(int)grid, 256, 0, st>>>(flat, table, nconv, wamax);
+        PUNET_LAUNCH_CHECK("slab_amax_batch");
+    }
+    split_weights_f16_batch_kernel<<<(int)grid, 256, 0, st>>>(flat, (__bf16*)planes, table, nconv, mode, wamax);
+    PUNET_LAUNCH_CHECK("split_weights_f16_batch");
+    return PUNET_OK;
+}
 
 extern "C" int punet_split_weights_x6(const float* w, void* planes, long plane_stride, int cin, int cout, int ksize, int mode,
                                       void* stream) {
@@ -1097,10 +1298,18 @@ extern "C" int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1
                                   nullptr, nullptr, accumulate, relu, B, H, W, opts, stream);
 }
 
+struct F16Scales {  // fp16-operand arithmetic (planes = 2 or 1; 0 = the bf16 split-plane arithmetic): amax slots, see ConvX6Args
+    int planes = 0;
+    const float* amax_x0 = nullptr;
+    const float* amax_x1 = nullptr;
+    const float* amax_w = nullptr;
+    float* amax_out = nullptr;
+};
+
 static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
                           int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
                           const void* gate_bits, void* gate_out, int accumulate, int relu, int B, int H, int W, int opts,
-                          void* stream, float* pool_out = nullptr);
+                          void* stream, float* pool_out = nullptr, const F16Scales& f16 = F16Scales());
 
 extern "C" int punet_conv3x3_x6_gated(const float* x0, int c0, const float* x1, int c1, const void* wplanes,
                                       long plane_stride, int n_row, int n_off, const float* bias, int bias_img_stride,
@@ -1125,6 +1334,20 @@ extern "C" int punet_conv1x1_x6_gated(const float* x0, int c0, const float* x1, 
                                       int accumulate, int relu, int B, int H, int W, void* stream) {
     return conv_x6_launch(1, x0, c0, x1, c1, wplanes, plane_stride, n_row, n_off, bias, bias_img_stride, y, n_out, mask, gate_bits,
                           gate_out, accumulate, relu, B, H, W, 0, stream);
+}
+
+// fp16-operand convolution / input gradient ("f16x3": planes = 2, "f16": planes = 1); everything else as punet_conv3x3_x6_gated /
+// _pooled (pool_out nullable)
+extern "C" int punet_conv3x3_f16(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride, int n_row,
+                                 int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
+                                 const void* gate_bits, void* gate_out, float* pool_out, int accumulate, int relu, int B, int H, int W,
+                                 int planes, const float* amax_x0, const float* amax_x1, const float* amax_w, float* amax_y,
+                                 void* stream) {
+    PUNET_CHECK_ARG(planes == 1 || planes == 2, "punet_conv3x3_f16: planes must be 2 or 1 (got %d)", planes);
+    F16Scales f;
+    f.planes = planes; f.amax_x0 = amax_x0; f.amax_x1 = amax_x1; f.amax_w = amax_w; f.amax_out = amax_y;
+    return conv_x6_launch(3, x0, c0, x1, c1, wplanes, plane_stride, n_row, n_off, bias, bias_img_stride, y, n_out, mask, gate_bits,
+                          gate_out, accumulate, relu, B, H, W, 0, stream, pool_out, f);
 }
 
 // One-plane forward convolution on bf16 activation tensors (the "bf16s" fast mode: opt-in, reduced precision): x0 / x1 / y /
@@ -1162,8 +1385,10 @@ extern "C" int punet_conv3x3_bf16s(const void* x0, int c0, const void* x1, int c
 static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
                           int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
                           const void* gate_bits, void* gate_out, int accumulate, int relu, int B, int H, int W, int opts,
-                          void* stream, float* pool_out) {
+                          void* stream, float* pool_out, const F16Scales& f16) {
     PUNET_CHECK_ARG(x0 && wplanes && y, "punet_conv3x3_x6: null pointer");
+    PUNET_CHECK_ARG(f16.planes == 0 || ((f16.planes == 1 || f16.planes == 2) && ksize == 3),
+                    "punet_conv3x3_f16: planes must be 2 (hh + hl + lh) or 1, 3x3 only");
     const int planes = punet_x6_planes_of(opts), shape = punet_x6_shape_of(opts);
     PUNET_CHECK_ARG(planes > 0 && shape > 0, "punet_conv3x3_x6: bad options word 0x%x (PUNET_X6_OPTS(products 6|3|1, shape 16|32))", opts);
     PUNET_CHECK_ARG(!pool_out || (H % 2 == 0 && W % 2 == 0 && !mask && !gate_bits && !accumulate),
@@ -1205,7 +1430,18 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
                     "punet_conv3x3_x6: bias/relu/gate_out (forward) cannot be combined with mask/gate_bits/accumulate (input gradient)");
     hipStream_t st = (hipStream_t)stream;
     a.xcd_remap = grid % 8 == 0;  // same-process A/B: +0.5-0.8 % (the tensors of this workload fit the Infinity Cache)
-    if (ksize == 1) {  // the two Fcomb layers: always the parity arithmetic (they are a rounding error of the step time)
+    a.amax_x0 = f16.amax_x0; a.amax_x1 = f16.amax_x1; a.amax_w = f16.amax_w; a.amax_out = f16.amax_out;
+    if (f16.planes == 2) {  // "f16x3": the 16 x 16 x 32 kernel where the channel count allows, as for the bf16 planes
+        if (shape == 16 && (c0 + c1) % 32 == 0) {
+            if (dgrad) conv3x3_x6b_kernel<2, true, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6b_kernel<2, false, true><<<grid, 256, 0, st>>>(a);
+        } else {
+            if (dgrad) conv3x3_x6_kernel<2, true, 3, false, true><<<grid, 256, 0, st>>>(a);
+            else conv3x3_x6_kernel<2, false, 3, false, true><<<grid, 256, 0, st>>>(a);
+        }
+    } else if (f16.planes == 1) {  // "f16": one fp16 product
+        if (dgrad) conv3x3_x6_kernel<1, true, 3, false, true><<<grid, 256, 0, st>>>(a);
+        else conv3x3_x6_kernel<1, false, 3, false, true><<<grid, 256, 0, st>>>(a);
+    } else if (ksize == 1) {  // the two Fcomb layers: always the parity arithmetic (they are a rounding error of the step time)
         if (dgrad) conv3x3_x6_kernel<3, true, 1><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<3, false, 1><<<grid, 256, 0, st>>>(a);
     } else if (shape == 16 && (c0 + c1) % 32 == 0 && planes >= 2) {
         // 16 x 16 x 32 MFMAs: four {tap, 8 channels} blocks per instruction.  (Not for the one-plane fast mode: that one is

@@ -1062,7 +1062,47 @@ int punet_launch_reduce_slabs_pair(const float* partial_w, size_t stride_w, int 
     return PUNET_OK;
 }
 
+// ---- amax slots of the fp16-operand modes (common.h): max |x| of a tensor (standalone pass, for producers that do not publish
+// it themselves) and an upper BOUND composed from other slots, out = ca * a + cb * b (pool / up-sampling backward: the output's
+// magnitude follows from the input's; a bound costs range, not precision - the scaled values keep 39 binades below the bound)
+__global__ __launch_bounds__(256) void amax_kernel(const float4* __restrict__ x, size_t n4, const float* __restrict__ tail, int ntail,
+                                                   float* __restrict__ slot) {
+    float m = 0.f;
+    const size_t rounds = (n4 + (size_t)gridDim.x * blockDim.x - 1) / ((size_t)gridDim.x * blockDim.x);
+    for (size_t r = 0; r < rounds; ++r) {
+        const size_t i = r * (size_t)gridDim.x * blockDim.x + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < n4) {
+            const float4 v = x[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) m = fmaxf(m, fabsf(tail[threadIdx.x]));
+    punet_amax_publish(slot, m);
+}
+__global__ void amax_bound_kernel(const float* a, float ca, const float* b, float cb, float* out) {
+    out[0] = (a ? ca * a[0] : 0.f) + (b ? cb * b[0] : 0.f);
+}
+
 #define STREAM ((hipStream_t)stream)
+
+extern "C" int punet_amax(const float* x, long n, float* slot, int zero_first, void* stream) {
+    PUNET_CHECK_ARG(x && slot && n > 0 && ((uintptr_t)x & 15) == 0, "punet_amax: bad args (x must be 16-byte aligned)");
+    if (zero_first && hipMemsetAsync(slot, 0, sizeof(float), STREAM) != hipSuccess) {
+        punet_set_error("punet_amax: memset failed");
+        return PUNET_ERR_HIP;
+    }
+    const size_t n4 = (size_t)n / 4;
+    amax_kernel<<<ew_grid(n4 ? n4 : 1, 2048), EW_BLOCK, 0, STREAM>>>((const float4*)x, n4, x + 4 * n4, (int)(n - 4 * (long)n4), slot);
+    PUNET_LAUNCH_CHECK("amax");
+    return PUNET_OK;
+}
+
+extern "C" int punet_amax_bound(const float* a, float ca, const float* b, float cb, float* out, void* stream) {
+    PUNET_CHECK_ARG(out && (a || b), "punet_amax_bound: bad args");
+    amax_bound_kernel<<<1, 1, 0, STREAM>>>(a, ca, b, cb, out);
+    PUNET_LAUNCH_CHECK("amax_bound");
+    return PUNET_OK;
+}
 
 extern "C" int punet_pool2x2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
     PUNET_CHECK_ARG(x && y && C % 4 == 0 && B > 0 && H > 0 && W > 0, "punet_pool2x2_fwd: bad args (C=%d)", C);

@@ -70,6 +70,8 @@ struct WgradX6Args {
     float* partial;
     float* bias_partial;
     int B, H, W, nslices;
+    const float* amax_x;   // fp16-operand instantiations (F16; common.h): amax slots of the two operands, nullptr = scale 1
+    const float* amax_dz;
 };
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
@@ -83,6 +85,7 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
 union Frag {
     bf16x8 v;
     s16x4 half4[2];
+    uint4 u;
 };
 
 __device__ __forceinline__ s16x4 tr_read(const char* lds_base, int byte_off) {
@@ -134,14 +137,15 @@ __device__ __forceinline__ void tile_mfma(f32x16 (&acc)[GTMAX], const char* sX, 
 }
 
 template <int T0, int NT>
-__device__ __forceinline__ void store_partial(const f32x16 (&acc)[GTMAX], const WgradX6Args& a, int slice, int ci_base, int co, int half) {
+__device__ __forceinline__ void store_partial(const f32x16 (&acc)[GTMAX], const WgradX6Args& a, int slice, int ci_base, int co, int half,
+                                              float inv = 1.f) {  // inv: exact power of two (fp16 operands), 1 otherwise
     if (co >= a.cout) return;
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = ci_base + mfma32_row(r, half);
-            if (ci < a.cs) a.partial[(((size_t)slice * 9 + T0 + tt) * a.cs + ci) * a.cout + co] = acc[tt][r];
+            if (ci < a.cs) a.partial[(((size_t)slice * 9 + T0 + tt) * a.cs + ci) * a.cout + co] = acc[tt][r] * inv;
         }
 }
 
@@ -355,7 +359,7 @@ constexpr int DIMGR = DSLOTS * WTW * ROWB;  // one (plane, co block) ring image:
 
 // xa / db: per-lane byte offsets of the tile's four X rows / two dZ rows, INCLUDING the wave's channel-block image (the
 // remaining compile-time part - plane, column, tap - then fits the 16-bit offset field of the LDS instruction)
-template <int NP, int T0, int NT, typename F>
+template <int NP, int T0, int NT, bool F16, typename F>
 __device__ __forceinline__ void tile_mfma_r(f32x16 (&acc)[GTMAX], const char* sX, const char* sD, const int (&xa)[4],
                                             const int (&db)[2], F&& between) {
     constexpr int P1 = NP > 1 ? 1 : 0, P2 = NP > 2 ? 2 : 0;
@@ -399,15 +403,15 @@ __device__ __forceinline__ void tile_mfma_r(f32x16 (&acc)[GTMAX], const char* sX
         const Frag(&bb)[NP] = b[s & 1];
         f32x16 c = acc[tt];
         if (NP > 2) {
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[P1].v, bb[P1].v, c, 0, 0, 0);  // mm
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[P2].v, bb[0].v, c, 0, 0, 0);   // lh
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[0].v, bb[P2].v, c, 0, 0, 0);   // hl
+            c = punet_mfma32<F16>(aa[P1].u, bb[P1].u, c);  // mm
+            c = punet_mfma32<F16>(aa[P2].u, bb[0].u, c);   // lh
+            c = punet_mfma32<F16>(aa[0].u, bb[P2].u, c);   // hl
         }
         if (NP > 1) {
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[P1].v, bb[0].v, c, 0, 0, 0);  // mh
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[0].v, bb[P1].v, c, 0, 0, 0);  // hm
+            c = punet_mfma32<F16>(aa[P1].u, bb[0].u, c);  // mh
+            c = punet_mfma32<F16>(aa[0].u, bb[P1].u, c);  // hm
         }
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[0].v, bb[0].v, c, 0, 0, 0);  // hh
+        c = punet_mfma32<F16>(aa[0].u, bb[0].u, c);  // hh
         acc[tt] = c;
         if (tt == NT - 1) between(s);
     }
@@ -431,15 +435,15 @@ __device__ __forceinline__ void tile_mfma_r(f32x16 (&acc)[GTMAX], const char* sX
                     a[p].half4[r] = tr_read(sX, p * 2 * XIMGR + (col0 + kx + 4 * r) * ROWB + xa[row + ky]);
             f32x16 c = acc[tt];
             if (NP > 2) {
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P1].v, b[P1].v, c, 0, 0, 0);  // mm
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P2].v, b[0].v, c, 0, 0, 0);   // lh
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[P2].v, c, 0, 0, 0);   // hl
+                c = punet_mfma32<F16>(a[P1].u, b[P1].u, c);  // mm
+                c = punet_mfma32<F16>(a[P2].u, b[0].u, c);   // lh
+                c = punet_mfma32<F16>(a[0].u, b[P2].u, c);   // hl
             }
             if (NP > 1) {
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[P1].v, b[0].v, c, 0, 0, 0);  // mh
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[P1].v, c, 0, 0, 0);  // hm
+                c = punet_mfma32<F16>(a[P1].u, b[0].u, c);  // mh
+                c = punet_mfma32<F16>(a[0].u, b[P1].u, c);  // hm
             }
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].v, b[0].v, c, 0, 0, 0);  // hh
+            c = punet_mfma32<F16>(a[0].u, b[0].u, c);  // hh
             acc[tt] = c;
         }
         between(s);
@@ -452,10 +456,18 @@ __device__ __forceinline__ void tile_mfma_r(f32x16 (&acc)[GTMAX], const char* sX
 #endif
 }
 
-// X16 (one plane only; the "bf16s" fast mode): the activation operand x holds bf16 - its staging is a plain 8-byte copy
-template <int NP, bool X16 = false>
+// X16 (one plane only; the "bf16s" / "f16s" fast modes): the activation operand x holds bf16 / fp16 - its staging is a plain
+// 8-byte copy.  F16: fp16 planes (NP <= 2) scaled by exact powers of two from the operands' amax slots (common.h; an operand
+// STORED as fp16 is unscaled), the slabs are written rescaled.
+template <int NP, bool X16 = false, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
-    static_assert(!X16 || NP == 1, "bf16 activation storage exists for the one-plane arithmetic only");
+    static_assert(!X16 || NP == 1, "16-bit activation storage exists for the one-plane arithmetic only");
+    static_assert(!F16 || NP <= 2, "fp16 operands: one or two planes");
+    float sxs = 1.f, sds = 1.f;  // F16: operand scales (block-uniform)
+    if constexpr (F16) {
+        if (!X16) sxs = punet_f16_scale_from(a.amax_x);
+        sds = punet_f16_scale_from(a.amax_dz);
+    }
     constexpr int C4 = WC / 4;                                   // float4 units per pixel
     constexpr int XNEW = 2 * HTW * C4, DNEW = 2 * WTW * C4;      // units of a tile's two new rows: 1,088 and 1,024
     constexpr int XIT = (XNEW + 511) / 512, DIT = DNEW / 512;    // 3 and 2 staging registers per thread
@@ -496,7 +508,14 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
     const int lane_off = (8 * half + q) * ROWB + (16 * cb + 4 * p4) * 2;
 
     // fp32 -> planes of one float4 unit, written at byte offset `off` inside the (plane, block 0) image of `img` bytes each
-    auto put_planes = [&](char* base, int img, int off, const float4& r) __attribute__((always_inline)) {
+    auto put_planes = [&](char* base, int img, int off, const float4& r, float sc) __attribute__((always_inline)) {
+        if constexpr (F16) {
+            uint2 h, l;
+            splitf16_quad<NP>(r, sc, h, l);
+            *reinterpret_cast<uint2*>(base + off) = h;
+            if (NP > 1) *reinterpret_cast<uint2*>(base + (NP > 1) * 2 * img + off) = l;
+            return;
+        }
         const float xv[4] = {r.x, r.y, r.z, r.w};
         bf16x4 ph, pm, pl;
 #pragma unroll
@@ -529,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
             const uint2 h = in ? make_uint2(__builtin_bit_cast(unsigned, r.x), __builtin_bit_cast(unsigned, r.y)) : make_uint2(0u, 0u);
             *reinterpret_cast<uint2*>(sX + off) = h;
         } else {
-            put_planes(sX, XIMGR, off, in ? r : make_float4(0.f, 0.f, 0.f, 0.f));
+            put_planes(sX, XIMGR, off, in ? r : make_float4(0.f, 0.f, 0.f, 0.f), sxs);
         }
     };
     auto load_d = [&](const float* dbp, int gy, int gx_, int c4) __attribute__((always_inline)) -> float4 {
@@ -571,7 +590,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
                 float4 v = load_d(dbp, gy, gx_, c4);
                 if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
-                put_planes(sD, DIMGR, (c4 >> 3) * DIMGR + (row * WTW + px) * ROWB + (c4 & 7) * 8, v);
+                put_planes(sD, DIMGR, (c4 >> 3) * DIMGR + (row * WTW + px) * ROWB + (c4 & 7) * 8, v, sds);
             }
             __syncthreads();
 
@@ -633,7 +652,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
                     const int c4 = u % C4, pix = u / C4, nr = pix / WTW, px = pix % WTW;
                     const float4 v = (inmask >> (XIT + it)) & 1u ? rd[it] : make_float4(0.f, 0.f, 0.f, 0.f);
                     bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
-                    put_planes(sD, DIMGR, (c4 >> 3) * DIMGR + (nr ? nd1 : nd0) + px * ROWB + (c4 & 7) * 8, v);
+                    put_planes(sD, DIMGR, (c4 >> 3) * DIMGR + (nr ? nd1 : nd0) + px * ROWB + (c4 & 7) * 8, v, sds);
                 };
                 auto between = [&](int s) __attribute__((always_inline)) {
 #ifdef PUNET_WGRAD_TRACE_FINE
@@ -650,7 +669,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
                         for (int it = 0; it < DIT; ++it) commit_d(it);
                     }
                 };
-                tile_mfma_r<NP, TA, TB>(acc, sX, sD, xa, db_, between);
+                tile_mfma_r<NP, TA, TB, F16>(acc, sX, sD, xa, db_, between);
                 WGTR(1);
                 __syncthreads();
                 WGTR(2);
@@ -659,7 +678,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
         }
 
         const int co = co0 + cob * 32 + l31;
-        store_partial<TA, TB>(acc, a, slice, ci0 + cib * 32, co, half);
+        store_partial<TA, TB>(acc, a, slice, ci0 + cib * 32, co, half, F16 ? 1.f / (sxs * sds) : 1.f);
     };
     if (group == 0)
         sweep(std::integral_constant<int, 0>{}, std::integral_constant<int, GT0>{});
@@ -704,6 +723,17 @@ int launch_wgrad_x16(const WgradX6Args& a, dim3 grid, hipStream_t stream) {
     return PUNET_OK;
 }
 
+template <int NP, bool X16>
+int launch_wgrad_f16(const WgradX6Args& a, dim3 grid, hipStream_t stream) {
+    if (hipFuncSetAttribute((const void*)wgrad3x3_x6r_kernel<NP, X16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes_r(NP)) !=
+        hipSuccess) {
+        punet_set_error("punet_conv_wgrad_f16: cannot reserve %d bytes of LDS", smem_bytes_r(NP));
+        return PUNET_ERR_HIP;
+    }
+    wgrad3x3_x6r_kernel<NP, X16, true><<<grid, 512, smem_bytes_r(NP), stream>>>(a);
+    return PUNET_OK;
+}
+
 template <int NP>
 int launch_wgrad(const WgradX6Args& a, dim3 grid, hipStream_t stream) {
 #if PUNET_WGRAD_ROLLING
@@ -736,7 +766,7 @@ extern "C" int punet_wgrad_x6_slices(int cs, int cout, int B, int H, int W) {
 
 static int wgrad_x6_impl(bool x16, const float* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off,
                          float* dbias, float* workspace, int nslices, int B, int H, int W, int accumulate, float scale, int opts,
-                         void* stream_);
+                         void* stream_, int f16planes = 0, const float* amax_x = nullptr, const float* amax_dz = nullptr);
 
 extern "C" int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off,
                                    float* dbias, float* workspace, int nslices, int B, int H, int W, int accumulate,
@@ -753,9 +783,19 @@ extern "C" int punet_conv_wgrad_bf16s(const void* x, int cs, const float* dz, in
                          scale, PUNET_X6_OPTS(1, 16), stream_);
 }
 
+// fp16-operand weight gradient ("f16x3": planes = 2, "f16": planes = 1; x16 != 0: x is STORED as fp16, planes = 1 only);
+// amax_x / amax_dz: the operands' amax slots (common.h; nullptr = scale 1)
+extern "C" int punet_conv_wgrad_f16(const void* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off,
+                                    float* dbias, float* workspace, int nslices, int B, int H, int W, int accumulate, float scale,
+                                    int planes, int x16, const float* amax_x, const float* amax_dz, void* stream_) {
+    PUNET_CHECK_ARG((planes == 1 || planes == 2) && !(x16 && planes != 1), "punet_conv_wgrad_f16: planes must be 2 or 1 (fp16 storage: 1)");
+    return wgrad_x6_impl(x16 != 0, (const float*)x, cs, dz, cout, dw, cin_total, ci_off, dbias, workspace, nslices, B, H, W, accumulate,
+                         scale, PUNET_X6_OPTS(planes == 2 ? 3 : 1, 16), stream_, planes, amax_x, amax_dz);
+}
+
 static int wgrad_x6_impl(bool x16, const float* x, int cs, const float* dz, int cout, float* dw, int cin_total, int ci_off,
                          float* dbias, float* workspace, int nslices, int B, int H, int W, int accumulate, float scale, int opts,
-                         void* stream_) {
+                         void* stream_, int f16planes, const float* amax_x, const float* amax_dz) {
     hipStream_t stream = (hipStream_t)stream_;
     const int planes = punet_x6_planes_of(opts);
     PUNET_CHECK_ARG(planes > 0, "punet_conv_wgrad_x6: bad options word 0x%x", opts);
@@ -771,8 +811,11 @@ static int wgrad_x6_impl(bool x16, const float* x, int cs, const float* dz, int 
     a.partial = workspace;
     a.bias_partial = dbias ? workspace + (size_t)nslices * 9 * cs * cout : nullptr;
     a.B = B; a.H = H; a.W = W; a.nslices = nslices;
+    a.amax_x = amax_x; a.amax_dz = amax_dz;
     dim3 grid(nslices, ceil_div(cs, WC) * ceil_div(cout, WC));
-    const int rc0 = x16 ? launch_wgrad_x16(a, grid, stream)
+    const int rc0 = f16planes == 2 ? launch_wgrad_f16<2, false>(a, grid, stream)
+                    : f16planes == 1 ? (x16 ? launch_wgrad_f16<1, true>(a, grid, stream) : launch_wgrad_f16<1, false>(a, grid, stream))
+                    : x16 ? launch_wgrad_x16(a, grid, stream)
                     : planes == 3 ? launch_wgrad<3>(a, grid, stream)
                     : planes == 2 ? launch_wgrad<2>(a, grid, stream) : launch_wgrad<1>(a, grid, stream);
     if (rc0 != PUNET_OK) return rc0;

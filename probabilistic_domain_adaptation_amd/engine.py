@@ -178,12 +178,13 @@ class ParamLayout:
 # --------------------------------------------------------------------------------------------
 class Act:
     """An NHWC activation tensor with its geometry; relu_out marks tensors whose gradient must be gated by (t > 0)."""
-    __slots__ = ("t", "B", "H", "W", "C", "relu_out", "needs_grad", "bits")
+    __slots__ = ("t", "B", "H", "W", "C", "relu_out", "needs_grad", "bits", "amax")
 
     def __init__(self, t, B, H, W, C, relu_out=False, needs_grad=True):
         self.t, self.B, self.H, self.W, self.C = t, B, H, W, C
         self.relu_out, self.needs_grad = relu_out, needs_grad
         self.bits = None  # (t > 0) as bits (layout: punet_gate_dwords) when the producing kernel published them
+        self.amax = None  # fp16-operand modes: one-element device tensor holding (a bound of) max |t|, see csrc/common.h
 
     @property
     def ptr(self):
@@ -195,7 +196,15 @@ def _stream():
 
 
 # bf16 products per fp32 product in the split-plane kernels; handed to the library with every call (options word)
-_X6_PRODUCTS = {"x6": 6, "x3": 3, "bf16": 1, "bf16s": 1}
+_X6_PRODUCTS = {"x6": 6, "x3": 3, "bf16": 1, "bf16s": 1, "f16x3": 3, "f16": 1}
+# fp16 planes per operand of the fp16-operand modes (csrc/common.h): "f16x3" = h + l, products hh + hl + lh (22-23 significand
+# bits at x3's cost); "f16" = one plane, the analogue of the reference scripts' fp16 autocast (LIVECell/livecell_mt.py:107)
+_F16_PLANES = {"f16x3": 2, "f16": 1}
+
+
+def _aptr(t):
+    """Pointer of an amax slot (one-element tensor) or None."""
+    return t.data_ptr() if t is not None else None
 
 
 class Workspace:
@@ -253,8 +262,12 @@ class PUNetEngine:
         # bits, more than the fp16 autocast of the reference), "bf16" = one plane.  Storage stays fp32 in every mode.
         self.conv_mode = conv_mode or os.environ.get("PUNET_CONV_MODE", "x6")
         if self.conv_mode not in _X6_PRODUCTS and self.conv_mode != "f32":
-            raise ValueError("PUNET_CONV_MODE must be one of 'x6', 'f32', 'x3', 'bf16', 'bf16s'")
+            raise ValueError("PUNET_CONV_MODE must be one of 'x6', 'f32', 'x3', 'bf16', 'bf16s', 'f16x3', 'f16'")
         self.x6 = self.conv_mode in _X6_PRODUCTS  # the split-plane kernel family
+        self.f16 = _F16_PLANES.get(self.conv_mode, 0)  # fp16 planes per operand (0: the bf16 planes of the x6 family)
+        self._wamax = {}  # flat.data_ptr() -> device float [nconv]: amax slot per 3x3 weight slab (fp16-operand modes)
+        self._x6_index = {}  # conv name -> row of the split table (= index of its slot in _wamax)
+        self._amax_pool, self._amax_next = None, 0
         # "bf16s" = "bf16" + bf16 STORAGE of the activations wherever no backward follows (forward_features: inference, the
         # teacher / weak pass): half the activation traffic, no fp32 -> bf16 conversion in the conv loaders
         self.act16 = self.conv_mode == "bf16s"
@@ -289,6 +302,23 @@ class PUNetEngine:
     # ---------------------------------------------------------------- helpers
     def _empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def _slot(self):
+        """A zeroed amax slot (one-element view of a pool tensor that stays alive as long as a slot of it is referenced)."""
+        if self._amax_pool is None or self._amax_next >= self._amax_pool.numel():
+            self._amax_pool, self._amax_next = torch.zeros(256, dtype=torch.float32, device=self.device), 0
+        v = self._amax_pool[self._amax_next:self._amax_next + 1]
+        self._amax_next += 1
+        return v
+
+    def _amax_of(self, t: torch.Tensor):
+        """Standalone amax pass over a tensor whose producer does not publish it (first-layer conv, Fcomb / latent-head backward)."""
+        sl = self._slot()
+        _lib.call("punet_amax", t.data_ptr(), t.numel(), sl.data_ptr(), 0, _stream())
+        return sl
+
+    def _wamax_ptr(self, flat, conv: "ConvP"):
+        return self._wamax[flat.data_ptr()].data_ptr() + 4 * self._x6_index[conv.name]
 
     def _wptr(self, flat, conv: ConvP):
         return flat.data_ptr() + 4 * conv.w_off
@@ -357,6 +387,25 @@ class PUNetEngine:
             assert x1 is None and c.k == 3
             _lib.call("punet_conv3x3_small_fwd", x0.ptr, cin, self._wptr(flat, c), self._bptr(flat, c), y.ptr, c.cout,
                       B, H, W, int(relu), _stream())
+            if self.f16:
+                y.amax = self._amax_of(y.t)
+        elif self.f16 and c.k == 3:  # fp16 planes scaled by powers of two from the operands' amax slots; publishes y's amax
+            planes = self._x6[(flat.data_ptr(), 0)]
+            if relu and (tape is not None or tape_bits):
+                y.bits = torch.empty(_lib.call("punet_gate_dwords", B, H, W, c.cout), dtype=torch.int32, device=self.device)
+            q = None
+            if pooled is not None and H % 2 == 0 and W % 2 == 0:
+                q = Act(self._empty(B, H // 2, W // 2, c.cout), B, H // 2, W // 2, c.cout)
+                pooled.append(q)
+            y.amax = self._slot()
+            if q is not None:
+                q.amax = y.amax  # an average never exceeds the maximum
+            self._timed("conv3x3_fwd", 2.0 * B * H * W * cin * c.cout * 9, "punet_conv3x3_f16", x0.ptr, x0.C,
+                        x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0, planes.data_ptr() + 2 * 3 * c.w_off,
+                        c.w_numel, c.cout, 0, self._bptr(flat, c), 0, y.ptr, c.cout, None, None,
+                        y.bits.data_ptr() if y.bits is not None else None, q.ptr if q is not None else None, 0, int(relu), B, H, W,
+                        self.f16, _aptr(x0.amax), _aptr(x1.amax) if x1 is not None else None, self._wamax_ptr(flat, c),
+                        y.amax.data_ptr(), _stream())
         elif self.x6 and c.k == 3:
             planes = self._x6[(flat.data_ptr(), 0)]
             if relu and (tape is not None or tape_bits):  # a backward will follow: publish the ReLU gate of y as bits
@@ -395,6 +444,7 @@ class PUNetEngine:
         OH, OW = (x.H + 1) // 2, (x.W + 1) // 2
         y = Act(self._empty(x.B, OH, OW, x.C), x.B, OH, OW, x.C)
         _lib.call("punet_pool2x2_fwd", x.ptr, y.ptr, x.B, x.H, x.W, x.C, _stream())
+        y.amax = x.amax  # a bound: an average never exceeds the maximum
         if tape is not None:
             tape.append(("pool", x, y))
         return y
@@ -407,6 +457,7 @@ class PUNetEngine:
                 tape.append(("up", x, y))
             return y
         y = Act(self._empty(x.B, 2 * x.H, 2 * x.W, x.C), x.B, 2 * x.H, 2 * x.W, x.C)
+        y.amax = x.amax  # a bound: bilinear interpolation is a convex combination
         _lib.call("punet_upsample2x_fwd", x.ptr, y.ptr, x.B, x.H, x.W, x.C, _stream())
         if tape is not None:
             tape.append(("up", x, y))
@@ -761,6 +812,11 @@ class PUNetEngine:
         x6 = self.x6 and c.k == 3
         ns = _lib.call("punet_wgrad_x6_slices" if x6 else "punet_wgrad_slices", x.C, c.cout, B, H, W)
         ws = self.ws.get("wgrad", _lib.call("punet_wgrad_workspace_floats", x.C, c.cout, c.k, ns))
+        if x6 and self.f16 and x.t.dtype == torch.float32:
+            self._timed("conv3x3_wgrad", 2.0 * B * H * W * x.C * c.cout * 9, "punet_conv_wgrad_f16", x.ptr, x.C, dz.data_ptr(),
+                        c.cout, dw, c.cin, ci_off, db if with_bias else None, ws.data_ptr(), ns, B, H, W, int(accumulate), 1.0,
+                        self.f16, 0, _aptr(x.amax), _aptr(getattr(dz, "punet_amax", None)), _stream())
+            return
         if x6 and x.t.dtype == torch.bfloat16:
             self._timed("conv3x3_wgrad", 2.0 * B * H * W * x.C * c.cout * 9, "punet_conv_wgrad_bf16s", x.ptr, x.C, dz.data_ptr(),
                         c.cout, dw, c.cin, ci_off, db if with_bias else None, ws.data_ptr(), ns, B, H, W, int(accumulate), 1.0,
@@ -787,11 +843,19 @@ class PUNetEngine:
             rows, units = [], 0
             for c in self.L.convs.values():
                 if c.k == 3 and c.cin > SMALL_CIN:
+                    self._x6_index[c.name] = len(rows)
                     rows.append([c.w_off, c.cin, c.cout, units])
                     units += c.w_numel // 8
             rows.append([0, 0, 0, units])
             self._x6_table = (torch.tensor(rows, dtype=torch.int64, device=self.device), len(rows) - 1, units)
         table, nconv, units = self._x6_table
+        if self.f16:  # fp16 planes h (+ l) of w * 2^k, k from the slab's amax (one slot per slab, recomputed with the planes)
+            wam = self._wamax.get(flat.data_ptr())
+            if wam is None:
+                wam = self._wamax[flat.data_ptr()] = torch.zeros(nconv, dtype=torch.float32, device=self.device)
+            _lib.call("punet_split_weights_f16_batch", flat.data_ptr(), planes.data_ptr(), table.data_ptr(), nconv, units, mode,
+                      wam.data_ptr(), 1, _stream())
+            return planes
         _lib.call("punet_split_weights_x6_batch", flat.data_ptr(), planes.data_ptr(), table.data_ptr(), nconv, units, mode,
                   _stream())
         return planes
@@ -840,7 +904,16 @@ class PUNetEngine:
         """dx[..., cin_off : cin_off + cin] of conv c given dz (epilogue: ReLU gate by `mask` - or by its bit form `bits`
         where the kernel takes it -, accumulate)."""
         flops = 2.0 * B * H * W * cin * c.cout * c.k * c.k
-        if self.x6 and c.k == 3:
+        if self.f16 and c.k == 3:
+            planes = self._x6[(flat.data_ptr(), 1)]
+            use_bits = bits is not None and mask_ptr is not None
+            if getattr(dx, "punet_amax", None) is None:
+                dx.punet_amax = self._slot()  # (accumulating into dx: the slot keeps max(previous, new total) - a bound)
+            self._timed("conv3x3_dgrad", flops, "punet_conv3x3_f16", dz.data_ptr(), c.cout, None, 0,
+                        planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cin, cin_off, None, 0, dx.data_ptr(), cin,
+                        None if use_bits else mask_ptr, bits.data_ptr() if use_bits else None, None, None, acc, 0, B, H, W, self.f16,
+                        _aptr(getattr(dz, "punet_amax", None)), None, self._wamax_ptr(flat, c), dx.punet_amax.data_ptr(), _stream())
+        elif self.x6 and c.k == 3:
             planes = self._x6[(flat.data_ptr(), 1)]
             use_bits = bits is not None and mask_ptr is not None
             self._timed("conv3x3_dgrad", flops, "punet_conv3x3_x6_gated", dz.data_ptr(), c.cout, None, 0,
@@ -894,6 +967,11 @@ class PUNetEngine:
                 bits = x.bits.data_ptr() if (x.relu_out and x.bits is not None) else None
                 _lib.call("punet_pool2x2_bwd_gated", dy.data_ptr(), x.ptr if (x.relu_out and bits is None) else None, bits,
                           g.data_ptr(), x.B, x.H, x.W, x.C, acc, _stream())
+                if self.f16:  # |dx| <= |dy| / 4 (+ what was there): a bound from the slots, no pass over the tensor
+                    prev = getattr(g, "punet_amax", None) if acc else None
+                    sl = prev if prev is not None else self._slot()
+                    _lib.call("punet_amax_bound", _aptr(getattr(dy, "punet_amax", None)), 0.25, _aptr(prev), 1.0, sl.data_ptr(), _stream())
+                    g.punet_amax = sl
             else:
                 _, x, y = op
                 dy = gm.pop(id(y))
@@ -902,6 +980,9 @@ class PUNetEngine:
                 bits = x.bits.data_ptr() if (x.relu_out and x.bits is not None) else None
                 _lib.call("punet_upsample2x_bwd_gated", dy.data_ptr(), x.ptr if (x.relu_out and bits is None) else None, bits,
                           g.data_ptr(), x.B, x.H, x.W, x.C, _stream())
+                if self.f16:  # the transposed x2 interpolation sums weights of at most 2 per dimension: |dx| <= 4 max |dy|
+                    g.punet_amax = self._slot()
+                    _lib.call("punet_amax_bound", _aptr(getattr(dy, "punet_amax", None)), 4.0, None, 0.0, g.punet_amax.data_ptr(), _stream())
 
     def elbo_backward(self, flat, gflat, st, accumulate=False, after_unet=None):
         """Gradient of gscale * (reconstruction_loss + beta * kl) w.r.t. every parameter into gflat
@@ -932,6 +1013,9 @@ class PUNetEngine:
             gm_u = {id(feat): st["dfeat"]}
         else:
             dz, gm_u = self._fcomb_backward_ops(flat, gflat, st, accumulate)
+        if self.f16:  # d loss / d features comes from the Fcomb kernels (fp32 / six-product arithmetic): they publish no amax
+            dfeat_t = gm_u[id(feat)]
+            dfeat_t.punet_amax = self._amax_of(dfeat_t)
         self._backward_tape(flat, gflat, st["tapes"][2], gm_u, accumulate)
         if after_unet is not None:
             after_unet()
@@ -1022,6 +1106,8 @@ class PUNetEngine:
                 _lib.call("punet_latent_head_bwd", d.data_ptr(), mean.data_ptr(), self._wptr(flat, c), enc.ptr,
                           gflat.data_ptr() + 4 * c.w_off, gflat.data_ptr() + 4 * c.b_off, dmean.data_ptr(), denc.data_ptr(), B,
                           enc.H * enc.W, enc.C, c.cout, acc, _stream())
+            if self.f16:
+                denc.punet_amax = self._amax_of(denc)
             self._backward_tape(flat, gflat, tape, gm, accumulate)
 
     # ---------------------------------------------------------------- regulariser / optimiser
