@@ -128,6 +128,18 @@ __device__ __forceinline__ void punet_amax_publish(float* slot, float wave_local
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, m));
 }
 
+// the same with ONE atomic per 256-thread workgroup: `lds` = 4 floats of LDS nobody else touches any more (the caller has passed a
+// barrier behind the last use of that memory); every thread of the workgroup must call
+__device__ __forceinline__ void punet_amax_publish_block256(float* slot, float thread_local_max, float* lds) {
+    float m = thread_local_max;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3]))));
+}
+
 // scaled fp32 -> fp16 planes h (+ l) of a PAIR of values (v_pk_mul_f32, v_cvt_pk_f16_f32, one v_pk_fma_f32 for the residual)
 template <int NP>
 __device__ __forceinline__ void splitf16_pair(float a, float b, float s, unsigned& h, unsigned& l) {

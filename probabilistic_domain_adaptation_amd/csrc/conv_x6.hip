@@ -522,7 +522,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6_kernel(ConvX6Args a) {
         if (phase(std::integral_constant<int, 1>{})) break;
     }
     if constexpr (F16) {
-        if (a.amax_out) punet_amax_publish(a.amax_out, amax_run);
+        if (a.amax_out) {  // block-uniform: the workgroup leaves the tile loop together
+            __syncthreads();  // the slower waves' last fragment reads are done: the operand images are free
+            punet_amax_publish_block256(a.amax_out, amax_run, reinterpret_cast<float*>(smem));
+        }
     }
 }
 
@@ -1039,7 +1042,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         if (phase(std::integral_constant<int, 3>{})) break;
     }
     if constexpr (F16) {
-        if (a.amax_out) punet_amax_publish(a.amax_out, amax_run);
+        if (a.amax_out) {  // block-uniform: the workgroup leaves the tile loop together
+            __syncthreads();  // the slower waves' last fragment reads are done: the operand images are free
+            punet_amax_publish_block256(a.amax_out, amax_run, reinterpret_cast<float*>(smem));
+        }
     }
 }
 
@@ -1114,30 +1120,31 @@ __global__ __launch_bounds__(256) void split_weights_x6_batch_kernel(const float
 // elements), plane 2 unused.  A unit of the amax pass is 8 CONSECUTIVE floats of the slab (any partition does for a maximum).
 __global__ __launch_bounds__(256) void slab_amax_batch_kernel(const float* __restrict__ flat, const long* __restrict__ table, int nconv,
                                                               float* __restrict__ wamax) {
+    // every block owns a CONTIGUOUS range of units (so that it touches one slab, rarely two or three): per-thread running
+    // maxima, published when the slab changes and at the end - a few atomics per block instead of one per wave and round
+    // (42 hot addresses: contended atomics serialise at the memory side)
     const long total = table[(size_t)nconv * 4 + 3];
-    const long rounds = (total + (long)gridDim.x * blockDim.x - 1) / ((long)gridDim.x * blockDim.x);
-    for (long r = 0; r < rounds; ++r) {  // whole waves stay in the loop (the wave-level reduction needs every lane)
-        const long i = r * (long)gridDim.x * blockDim.x + (long)blockIdx.x * blockDim.x + threadIdx.x;
-        const bool live = i < total;
-        int lo = 0;
+    const long per = (total + gridDim.x - 1) / gridDim.x;
+    const long u0 = (long)blockIdx.x * per, u1 = u0 + per < total ? u0 + per : total;
+    if (u0 >= u1) return;  // (block-uniform)
+    int lo = 0, hi = nconv - 1;  // slab of the block's first unit
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[(size_t)mid * 4 + 3] <= u0) lo = mid; else hi = mid - 1;
+    }
+    long ub = u0;
+    while (ub < u1) {  // block-uniform loop over the slabs the range touches
+        const long slab_end = table[(size_t)(lo + 1) * 4 + 3];  // first unit of the next slab (row nconv holds the total)
+        const long ue = slab_end < u1 ? slab_end : u1;
+        const float4* w = reinterpret_cast<const float4*>(flat + table[(size_t)lo * 4 + 0] + 8 * (ub - table[(size_t)lo * 4 + 3]));
         float m = 0.f;
-        if (live) {
-            int hi = nconv - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (table[(size_t)mid * 4 + 3] <= i) lo = mid; else hi = mid - 1;
-            }
-            const float4* w = reinterpret_cast<const float4*>(flat + table[(size_t)lo * 4 + 0] + 8 * (i - table[(size_t)lo * 4 + 3]));
-            const float4 a = w[0], b = w[1];
-            m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
-                      fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+        for (long i = threadIdx.x; i < 2 * (ue - ub); i += 256) {  // 2 float4 per unit, consecutive in memory
+            const float4 a = w[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
         }
-        const int lo0 = __builtin_amdgcn_readfirstlane(lo);
-        if (__all(live && lo == lo0)) {  // the whole wave inside one slab (all but the waves that straddle a slab boundary)
-            punet_amax_publish(wamax + lo0, m);
-        } else if (live) {
-            atomicMax(reinterpret_cast<unsigned*>(wamax + lo), __builtin_bit_cast(unsigned, m));
-        }
+        punet_amax_publish(wamax + lo, m);
+        ub = ue;
+        ++lo;
     }
 }
 
@@ -1253,7 +1260,7 @@ extern "C" int punet_split_weights_f16_batch(const float* flat, void* planes, co
             punet_set_error("punet_split_weights_f16_batch: memset failed");
             return PUNET_ERR_HIP;
         }
-        slab_amax_batch_kernel<<<(int)grid, 256, 0, st>>>(flat, table, nconv, wamax);
+        slab_amax_batch_kernel<<<total_units / 2048 < 2048 ? (int)(total_units / 2048 + 1) : 2048, 256, 0, st>>>(flat, table, nconv, wamax);
         PUNET_LAUNCH_CHECK("slab_amax_batch");
     }
     split_weights_f16_batch_kernel<<<(int)grid, 256, 0, st>>>(flat, (__bf16*)planes, table, nconv, mode, wamax);

@@ -1068,16 +1068,28 @@ int punet_launch_reduce_slabs_pair(const float* partial_w, size_t stride_w, int 
 __global__ __launch_bounds__(256) void amax_kernel(const float4* __restrict__ x, size_t n4, const float* __restrict__ tail, int ntail,
                                                    float* __restrict__ slot) {
     float m = 0.f;
-    const size_t rounds = (n4 + (size_t)gridDim.x * blockDim.x - 1) / ((size_t)gridDim.x * blockDim.x);
-    for (size_t r = 0; r < rounds; ++r) {
-        const size_t i = r * (size_t)gridDim.x * blockDim.x + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (i < n4) {
-            const float4 v = x[i];
-            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-        }
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {  // four independent 16-byte loads in flight per thread
+        const float4 a = x[i], b = x[i + stride], c = x[i + 2 * stride], d = x[i + 3 * stride];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(b.x), fabsf(b.y))), fmaxf(fabsf(b.z), fabsf(b.w)));
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(c.x), fabsf(c.y))), fmaxf(fabsf(c.z), fabsf(c.w)));
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(d.x), fabsf(d.y))), fmaxf(fabsf(d.z), fabsf(d.w)));
+    }
+    for (; i < n4; i += stride) {
+        const float4 a = x[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
     }
     if (blockIdx.x == 0 && (int)threadIdx.x < ntail) m = fmaxf(m, fabsf(tail[threadIdx.x]));
-    punet_amax_publish(slot, m);
+    // one atomic per block (LDS across the four waves): 2,048 waves on one address would queue at the memory side
+    __shared__ float sm[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]))));
 }
 __global__ void amax_bound_kernel(const float* a, float ca, const float* b, float cb, float* out) {
     out[0] = (a ? ca * a[0] : 0.f) + (b ? cb * b[0] : 0.f);
@@ -1092,7 +1104,7 @@ extern "C" int punet_amax(const float* x, long n, float* slot, int zero_first, v
         return PUNET_ERR_HIP;
     }
     const size_t n4 = (size_t)n / 4;
-    amax_kernel<<<ew_grid(n4 ? n4 : 1, 2048), EW_BLOCK, 0, STREAM>>>((const float4*)x, n4, x + 4 * n4, (int)(n - 4 * (long)n4), slot);
+    amax_kernel<<<ew_grid(n4 ? (n4 + 3) / 4 : 1, 2048), EW_BLOCK, 0, STREAM>>>((const float4*)x, n4, x + 4 * n4, (int)(n - 4 * (long)n4), slot);
     PUNET_LAUNCH_CHECK("amax");
     return PUNET_OK;
 }

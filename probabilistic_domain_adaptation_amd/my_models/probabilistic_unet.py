@@ -80,9 +80,10 @@ class ProbabilisticUnet(nn.Module):
     def __init__(self, input_channels=1, num_classes=1, num_filters=[32, 64, 128, 192], latent_dim=6, no_convs_fcomb=4,
                  beta=10.0, consensus_masking=False, rl_swap=False, device=None, seed: Optional[int] = None,
                  conv_mode: Optional[str] = None):
-        """conv_mode (extension): None = $PUNET_CONV_MODE or "x6" (fp32-accurate); "x3" / "bf16" / "bf16s" (bf16 arithmetic and
-        bf16 activation storage on the no-gradient passes) are the opt-in fast modes standing in for the reference's
-        mixed_precision=True (engine.PUNetEngine)."""
+        """conv_mode (extension): None = $PUNET_CONV_MODE or "x6" (fp32-accurate).  Opt-in fast modes (engine.PUNetEngine):
+        "f16x3" (two fp16 planes, per-tensor power-of-two scaling: logits within 1e-4 of the reference's - what the trainers'
+        mixed_precision=True selects), "f16" (one fp16 plane: the arithmetic of the reference's fp16 autocast), "x3" / "bf16" /
+        "bf16s" (bf16 planes; bf16s also stores activations as bf16)."""
         super().__init__()
         self.input_channels = input_channels
         self.num_classes = num_classes
@@ -139,6 +140,16 @@ class ProbabilisticUnet(nn.Module):
                     b = torch.empty(shape)
                     nn.init.trunc_normal_(b, std=0.001, a=-0.002, b=0.002, generator=g)
                     v.copy_(b)
+
+    def set_conv_mode(self, conv_mode: str):
+        """Switch the 3x3 conv arithmetic of this model (engine.PUNetEngine: "x6" parity default, "f32", or a fast mode -
+        "f16x3", "f16", "x3", "bf16", "bf16s").  The engine holds no weights, so a new one is built; cached forward state is
+        dropped.  Trainers call this for mixed_precision=True (my_trainer/default_trainer.py)."""
+        if conv_mode != self.engine.conv_mode:
+            self.engine = PUNetEngine(self.layout, self.device, conv_mode)
+            self._state = None
+            self._features_nchw = None
+        return self
 
     def __deepcopy__(self, memo):
         """deepcopy(model) -> teacher (mean_teacher_trainer.py:40): a new flat buffer with the same values."""
