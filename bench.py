@@ -245,7 +245,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--samples", type=int, default=8)
-    ap.add_argument("--conv-mode", default=None, choices=["x6", "f32", "x3", "bf16", "bf16s", "f16x3", "f16"],
+    ap.add_argument("--conv-mode", default=None, choices=["x6", "f32", "x3", "bf16", "bf16s", "f16x3", "f16", "f16s"],
                     help="3x3 conv arithmetic (default: $PUNET_CONV_MODE or x6); x3/bf16 are reduced-precision fast modes")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the timed steps eagerly from Python instead of replaying the captured hipGraph")
@@ -380,7 +380,8 @@ def main():
                       "f16x3": "f16x3 (fp32 storage, two fp16 planes per operand with per-tensor power-of-two scaling, 3 MFMAs per "
                                "product: 22-23 significand bits; reduced precision)",
                       "f16": "f16 (fp32 storage, fp16 operands with per-tensor power-of-two scaling - the analogue of the reference's "
-                             "fp16 autocast; reduced precision)"}[eng.conv_mode],
+                             "fp16 autocast; reduced precision)",
+                      "f16s": "f16 (fp16 operands AND fp16 activation storage, fp32 gradients scaled per tensor; reduced precision)"}[eng.conv_mode],
             "data": "synthetic",
             "config": {"workload": f"PUNet {a.workload} step: nf={NF}, latent 6, fcomb 3, BCE+KL, consensus masking, "
                                    f"{H}x{W}x{a.channels} patches, batch {B}/GPU, N={N} MC samples, Adam lr 1e-5, EMA 0.999",
@@ -421,7 +422,9 @@ def main():
                      "(h + l, products hh + hl + lh on v_mfma_f32_*_f16), every tensor scaled by an exact power of two from its amax "
                      "(published by the producing kernel), fp32 accumulate and storage; 1x1 convs six-product bf16 / fp32 MFMA",
             "f16": "REDUCED PRECISION fast mode (the reference's mixed_precision=True analogue: fp16 operands, fp32 accumulate): one "
-                   "fp16 MFMA per product, per-tensor power-of-two scaling from amax instead of a global loss scale, fp32 storage"}[eng.conv_mode]
+                   "fp16 MFMA per product, per-tensor power-of-two scaling from amax instead of a global loss scale, fp32 storage",
+            "f16s": "REDUCED PRECISION fast mode: as f16, plus fp16 STORAGE of every activation (unscaled, saturating - as under "
+                    "autocast); gradients fp32 in memory, scaled per tensor in the kernels' loaders"}[eng.conv_mode]
         if prof:
             out["config"]["instrumented_eager_region"] = {
                 "ms_per_step": round(1e3 * dt_eager / a.steps, 3), "host_enqueue_ms_per_step": round(1e3 * t_enq_eager / a.steps, 2),
@@ -462,7 +465,7 @@ def main():
                 ach = k3[0] / k3[1] / 1e12
                 if eng.x6:
                     # n bf16 MFMAs per product: the roofline of THIS arithmetic is the bf16 dense peak / n
-                    n = {"x6": 6, "x3": 3, "bf16": 1, "bf16s": 1, "f16x3": 3, "f16": 1}[eng.conv_mode]
+                    n = {"x6": 6, "x3": 3, "bf16": 1, "bf16s": 1, "f16x3": 3, "f16": 1, "f16s": 1}[eng.conv_mode]
                     peak = BF16_MFMA_PEAK_TFLOPS / n
                     et = "f16" if eng.f16 else "bf16"
                     kname = (f"conv3x3_x6b_kernel<{(n + 1) // 2 if n > 1 else 1} planes, {et}> (3x3 NHWC direct conv forward, "

@@ -129,6 +129,9 @@ int punet_conv_wgrad_x6(const float* x, int cs, const float* dz, int cout, float
  *      weight + bias gradient (no input gradient exists). */
 int punet_conv3x3_small_fwd(const float* x, int cin, const float* w, const float* bias, float* y, int cout, int B,
                             int H, int W, int relu, void* stream);
+/* the same, publishing max |y| into an amax slot (fp16-operand modes, below) */
+int punet_conv3x3_small_fwd_amax(const float* x, int cin, const float* w, const float* bias, float* y, int cout, int B, int H,
+                                 int W, int relu, float* amax_y, void* stream);
 size_t punet_small_wgrad_workspace_floats(int cin, int cout);
 int punet_conv3x3_small_wgrad(const float* x, int cin, const float* dz, int cout, float* dw, float* dbias,
                               float* workspace, int B, int H, int W, int accumulate, float scale, void* stream);
@@ -290,6 +293,27 @@ int punet_conv_wgrad_f16(const void* x, int cs, const float* dz, int cout, float
  * average-pool backward's output is bounded by |dy| / 4 (+ what it accumulates onto), the x2 up-sampling backward's by 4 |dy| */
 int punet_amax(const float* x, long n, float* slot, int zero_first, void* stream);
 int punet_amax_bound(const float* a, float ca, const float* b, float cb, float* out, void* stream);
+
+/* "f16s" = "f16" + fp16 STORAGE of the activations ([B,H,W,C] fp16, unscaled as under the reference's autocast, saturating at
+ * fp16's largest finite value; gradients stay fp32 and are scaled per tensor): the twins of the punet_*_bf16s entry points above
+ * (the weight gradient with a stored-fp16 operand is punet_conv_wgrad_f16(..., planes = 1, x16 = 1, NULL, amax_dz)) */
+int punet_conv3x3_small_fwd_f16s(const float* x, int cin, const float* w, const float* bias, void* y, int cout, int B, int H, int W,
+                                 int relu, void* stream);
+int punet_conv3x3_f16s(const void* x0, int c0, const void* x1, int c1, const void* wplanes, long plane_stride, int n_row, int n_off,
+                       const float* bias, void* y, int n_out, void* gate_out, void* pool_out, int relu, int B, int H, int W,
+                       const float* amax_w, void* stream);
+int punet_fcomb_train_fwd_bwd_f16s(const void* feat, const float* w1, const float* zb, const float* wmid, const float* bmid,
+                                   const float* w3, const float* b3, const float* target, const float* consm, float gscale,
+                                   float* logits, float* dfeat, float* loss_sum, float* workspace, int B, int HW, int CH, int nmid,
+                                   void* stream);
+int punet_gate_bits_f16(const void* y, void* bits, int B, int H, int W, int C, void* stream);
+int punet_upsample2x_fwd_f16s(const void* x, void* y, int B, int H, int W, int C, void* stream);
+int punet_latent_head_fwd_f16s(const void* enc, const float* w, const float* bias, float* mean, float* muls, float* workspace, int B,
+                               int P, int C, int J, void* stream);
+int punet_fcomb_sample_x6_f16s(const void* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
+                               const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z,
+                               float* logits, int N, int B, int HW, int CH, int nmid, float upper, float lower, int masking,
+                               void* stream);
 
 /* ---- K8: the reduction half of K7 on given logits[N][P] (unit parity of the consensus rule) */
 int punet_consensus(const float* logits, int N, long P, float upper, float lower, int masking, float* y, float* z,

@@ -43,6 +43,7 @@ _SIGS = {
     "punet_conv_wgrad": (_i, [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
     "punet_conv_wgrad_x6": (_i, [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "punet_conv3x3_small_fwd": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "punet_conv3x3_small_fwd_amax": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "punet_small_wgrad_workspace_floats": (_sz, [_i, _i]),
     "punet_conv3x3_small_wgrad": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "punet_pool2x2_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
@@ -85,6 +86,13 @@ _SIGS = {
     "punet_upsample2x_fwd_bf16s": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "punet_latent_head_fwd_bf16s": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "punet_fcomb_sample_x6_bf16s": (_i, [_p, _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
+    "punet_conv3x3_small_fwd_f16s": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "punet_conv3x3_f16s": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "punet_fcomb_train_fwd_bwd_f16s": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "punet_gate_bits_f16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "punet_upsample2x_fwd_f16s": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "punet_latent_head_fwd_f16s": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "punet_fcomb_sample_x6_f16s": (_i, [_p, _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "punet_consensus": (_i, [_p, _i, _l, _f, _f, _i, _p, _p, _p]),
     "punet_loss_workspace_floats": (_sz, []),
     "punet_bce_fwd_bwd": (_i, [_p, _p, _p, _f, _p, _p, _p, _l, _p]),

@@ -6,6 +6,7 @@
 // four consecutive output channels of a pixel (Cout/4 threads per pixel -> one coalesced 16 B x Cout/4
 // store per pixel), keeps its 9*CIN weight float4s in registers and walks a strip of pixels.
 // No input gradient exists for them (the image needs none).
+#include <type_traits>
 #include "common.h"
 #include "punet_hip.h"
 
@@ -14,10 +15,15 @@ namespace {
 // grid = (ceil(W / (ppb * XITER)), rows <= 65535): a block walks XITER strips of ppb pixels of ONE image row, so the
 // row / batch decomposition is block-uniform and the per-pixel index arithmetic is a handful of 32-bit adds (two 32-bit
 // divisions per pixel had made this store-bound kernel ALU-bound: 3.0 TB/s of stores, r02)
-template <int CIN, bool OUT16 = false>  // OUT16: y holds bf16 (the "bf16s" fast mode)
+template <int CIN, int OUT16 = 0>  // OUT16: y holds 1 = bf16 (the "bf16s" fast mode), 2 = fp16 ("f16s", saturating)
 __global__ __launch_bounds__(256) void conv3x3_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ y,
-                                                               int cout, int B, int H, int W, int relu, int xiter) {
+                                                               int cout, int B, int H, int W, int relu, int xiter,
+                                                               float* __restrict__ amax_out) {
+    // amax_out (nullable): max |y| is published there (atomic max on the bits; the fp16-operand modes scale the next layer's
+    // operand by it, common.h) - every thread reaches the end of the kernel (256 % groups == 0: no thread is surplus)
+    __shared__ float sam[4];
+    float am = 0.f;
     constexpr bool WLDS = CIN > 4;  // 9 * CIN float4 weights per thread: registers up to 4 channels, LDS beyond
     extern __shared__ __attribute__((aligned(16))) float4 swr[];  // WLDS: [9 * CIN][groups]
     const int groups = cout / 4;
@@ -28,8 +34,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_fwd_kernel(const float* __r
             swr[i] = *reinterpret_cast<const float4*>(w + (size_t)(i / groups) * cout + (i % groups) * 4);
         __syncthreads();
     }
-    if (pl >= ppb) return;
-    float4 wr[WLDS ? 1 : 9 * CIN];
+    float4 wr[WLDS ? 1 : 9 * CIN];  // (pl < ppb for every thread: the host checks 256 % groups == 0)
     if (!WLDS) {
 #pragma unroll
         for (int i = 0; i < 9 * CIN; ++i) wr[WLDS ? 0 : i] = *reinterpret_cast<const float4*>(w + (size_t)i * cout + g * 4);
@@ -38,7 +43,8 @@ __global__ __launch_bounds__(256) void conv3x3_small_fwd_kernel(const float* __r
     for (unsigned row = blockIdx.y; row < (unsigned)(B * H); row += gridDim.y) {  // b * H + py
         const int py = (int)(row % (unsigned)H);
         const float* xrow = x + (size_t)row * W * CIN;  // 64-bit base per row, 32-bit offsets inside
-        float* yrow = OUT16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(y) + (size_t)row * W * cout + g * 4)
+        typedef typename std::conditional<OUT16 == 2, _Float16, __bf16>::type o16;
+        float* yrow = OUT16 ? reinterpret_cast<float*>(reinterpret_cast<o16*>(y) + (size_t)row * W * cout + g * 4)
                             : y + (size_t)row * W * cout + g * 4;
         const bool up = py > 0, down = py < H - 1;
         for (int it = 0; it < xiter; ++it) {
@@ -64,16 +70,22 @@ __global__ __launch_bounds__(256) void conv3x3_small_fwd_kernel(const float* __r
                 o.z = fmaf(xv, ww.z, o.z); o.w = fmaf(xv, ww.w, o.w);
             }
             if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-            if constexpr (OUT16) {
-                typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
-                bf16x4_ ob;
-                ob[0] = (__bf16)o.x; ob[1] = (__bf16)o.y; ob[2] = (__bf16)o.z; ob[3] = (__bf16)o.w;
-                *reinterpret_cast<bf16x4_*>(reinterpret_cast<__bf16*>(yrow) + (size_t)px * cout) = ob;
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+            if constexpr (OUT16 != 0) {
+                typedef o16 o16x4 __attribute__((ext_vector_type(4)));
+                if constexpr (OUT16 == 2) {  // fp16's largest finite value instead of inf
+                    o.x = __builtin_amdgcn_fmed3f(o.x, -65504.f, 65504.f); o.y = __builtin_amdgcn_fmed3f(o.y, -65504.f, 65504.f);
+                    o.z = __builtin_amdgcn_fmed3f(o.z, -65504.f, 65504.f); o.w = __builtin_amdgcn_fmed3f(o.w, -65504.f, 65504.f);
+                }
+                o16x4 ob;
+                ob[0] = (o16)o.x; ob[1] = (o16)o.y; ob[2] = (o16)o.z; ob[3] = (o16)o.w;
+                *reinterpret_cast<o16x4*>(reinterpret_cast<o16*>(yrow) + (size_t)px * cout) = ob;
             } else {
                 *reinterpret_cast<float4*>(yrow + (size_t)px * cout) = o;
             }
         }
     }
+    if (amax_out) punet_amax_publish_block256(amax_out, am, sam);  // (block-uniform)
 }
 
 // partial[block][9*CIN + 1][cout]: rows 0..9*CIN-1 = dW[tap][ci][:], last row = dbias
@@ -147,8 +159,8 @@ constexpr int SMALL_WGRAD_BLOCKS = 1024;
 
 }  // namespace
 
-static int small_fwd_launch(bool out16, const float* x, int cin, const float* w, const float* bias, void* y, int cout, int B, int H,
-                            int W, int relu, void* stream_) {
+static int small_fwd_launch(int out16, const float* x, int cin, const float* w, const float* bias, void* y, int cout, int B, int H,
+                            int W, int relu, void* stream_, float* amax_y = nullptr) {
     hipStream_t stream = (hipStream_t)stream_;
     PUNET_CHECK_ARG(x && w && y, "punet_conv3x3_small_fwd: null pointer");
     PUNET_CHECK_ARG(cin >= 1 && cin <= 8, "punet_conv3x3_small_fwd: cin must be 1..8 (got %d)", cin);
@@ -169,12 +181,15 @@ static int small_fwd_launch(bool out16, const float* x, int cin, const float* w,
     }
 #define PUNET_SMALL_FWD(CI)                                                                                          \
     do {                                                                                                             \
-        if (out16) {                                                                                                 \
-            PUNET_SMALL_FWD_ATTR((conv3x3_small_fwd_kernel<CI, true>))                                               \
-            conv3x3_small_fwd_kernel<CI, true><<<grid, 256, wlds, stream>>>(x, w, bias, yf, cout, B, H, W, relu, xiter); \
+        if (out16 == 2) {                                                                                            \
+            PUNET_SMALL_FWD_ATTR((conv3x3_small_fwd_kernel<CI, 2>))                                                  \
+            conv3x3_small_fwd_kernel<CI, 2><<<grid, 256, wlds, stream>>>(x, w, bias, yf, cout, B, H, W, relu, xiter, amax_y); \
+        } else if (out16 == 1) {                                                                                     \
+            PUNET_SMALL_FWD_ATTR((conv3x3_small_fwd_kernel<CI, 1>))                                                  \
+            conv3x3_small_fwd_kernel<CI, 1><<<grid, 256, wlds, stream>>>(x, w, bias, yf, cout, B, H, W, relu, xiter, amax_y); \
         } else {                                                                                                     \
-            PUNET_SMALL_FWD_ATTR((conv3x3_small_fwd_kernel<CI, false>))                                              \
-            conv3x3_small_fwd_kernel<CI, false><<<grid, 256, wlds, stream>>>(x, w, bias, yf, cout, B, H, W, relu, xiter); \
+            PUNET_SMALL_FWD_ATTR((conv3x3_small_fwd_kernel<CI, 0>))                                                  \
+            conv3x3_small_fwd_kernel<CI, 0><<<grid, 256, wlds, stream>>>(x, w, bias, yf, cout, B, H, W, relu, xiter, amax_y); \
         }                                                                                                            \
     } while (0)
     switch (cin) {
@@ -195,12 +210,24 @@ static int small_fwd_launch(bool out16, const float* x, int cin, const float* w,
 
 extern "C" int punet_conv3x3_small_fwd(const float* x, int cin, const float* w, const float* bias, float* y, int cout,
                                        int B, int H, int W, int relu, void* stream) {
-    return small_fwd_launch(false, x, cin, w, bias, y, cout, B, H, W, relu, stream);
+    return small_fwd_launch(0, x, cin, w, bias, y, cout, B, H, W, relu, stream);
+}
+
+// the same, publishing max |y| into the amax slot amax_y (fp16-operand modes: the next layer scales its operand by it)
+extern "C" int punet_conv3x3_small_fwd_amax(const float* x, int cin, const float* w, const float* bias, float* y, int cout, int B,
+                                            int H, int W, int relu, float* amax_y, void* stream) {
+    PUNET_CHECK_ARG(amax_y, "punet_conv3x3_small_fwd_amax: null amax slot");
+    return small_fwd_launch(0, x, cin, w, bias, y, cout, B, H, W, relu, stream, amax_y);
 }
 
 extern "C" int punet_conv3x3_small_fwd_bf16s(const float* x, int cin, const float* w, const float* bias, void* y, int cout, int B,
                                              int H, int W, int relu, void* stream) {
-    return small_fwd_launch(true, x, cin, w, bias, y, cout, B, H, W, relu, stream);
+    return small_fwd_launch(1, x, cin, w, bias, y, cout, B, H, W, relu, stream);
+}
+
+extern "C" int punet_conv3x3_small_fwd_f16s(const float* x, int cin, const float* w, const float* bias, void* y, int cout, int B,
+                                            int H, int W, int relu, void* stream) {
+    return small_fwd_launch(2, x, cin, w, bias, y, cout, B, H, W, relu, stream);
 }
 
 extern "C" size_t punet_small_wgrad_workspace_floats(int cin, int cout) {

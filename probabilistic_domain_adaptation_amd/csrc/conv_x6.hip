@@ -1389,6 +1389,40 @@ extern "C" int punet_conv3x3_bf16s(const void* x0, int c0, const void* x1, int c
     return PUNET_OK;
 }
 
+// One-plane forward convolution on fp16 activation tensors (the "f16s" fast mode): x0 / x1 / y / pool_out are [B,H,W,C] fp16,
+// UNscaled (as under the reference's fp16 autocast; outputs saturate at fp16's largest finite value); weights = plane 0 of
+// punet_split_weights_f16 with their slab's amax slot amax_w.
+extern "C" int punet_conv3x3_f16s(const void* x0, int c0, const void* x1, int c1, const void* wplanes, long plane_stride, int n_row,
+                                  int n_off, const float* bias, void* y, int n_out, void* gate_out, void* pool_out, int relu, int B,
+                                  int H, int W, const float* amax_w, void* stream) {
+    PUNET_CHECK_ARG(!gate_out || relu, "punet_conv3x3_f16s: gate_out is the ReLU gate of the output and needs relu != 0");
+    PUNET_CHECK_ARG(x0 && wplanes && y && amax_w, "punet_conv3x3_f16s: null pointer");
+    PUNET_CHECK_ARG(c0 > 0 && c0 % CK == 0 && c1 >= 0 && c1 % CK == 0 && (c1 == 0 || x1),
+                    "punet_conv3x3_f16s: source channels must be multiples of %d (c0=%d c1=%d)", CK, c0, c1);
+    PUNET_CHECK_ARG(n_out > 0 && n_out % 4 == 0 && n_off >= 0 && n_off + n_out <= n_row, "punet_conv3x3_f16s: bad output-channel window");
+    PUNET_CHECK_ARG(B > 0 && H > 0 && W > 0 && (!pool_out || (H % 2 == 0 && W % 2 == 0)), "punet_conv3x3_f16s: bad shape %dx%d", H, W);
+    {
+        const unsigned long long px = (unsigned long long)H * W;
+        const int cmax = c0 > c1 ? (c0 > n_out ? c0 : n_out) : (c1 > n_out ? c1 : n_out);
+        PUNET_CHECK_ARG(px * cmax < (1ull << 31) && (unsigned long long)B * px < (1ull << 31), "punet_conv3x3_f16s: image too large");
+    }
+    ConvX6Args a{};
+    a.x0 = (const float*)x0; a.x1 = (const float*)x1; a.c0 = c0; a.c1 = c1;
+    a.wp = (const __bf16*)wplanes; a.plane_stride = plane_stride; a.n_row = n_row; a.n_off = n_off;
+    a.bias = bias; a.bias_img_stride = 0;
+    a.y = (float*)y; a.n_total = n_out; a.relu = relu; a.pool_out = (float*)pool_out; a.gate_out = (unsigned*)gate_out;
+    a.B = B; a.H = H; a.W = W;
+    a.ntiles = B * ceil_div(H, TH) * ceil_div(W, TW) * ceil_div(n_out, TN);
+    a.m_ntn = x6_magic(ceil_div(n_out, TN)); a.m_tx = x6_magic(ceil_div(W, TW)); a.m_ty = x6_magic(ceil_div(H, TH));
+    a.amax_w = amax_w;
+    const int cap = WG_PER_CU * punet_num_cus();
+    const int grid = a.ntiles < cap ? a.ntiles : cap;
+    a.xcd_remap = grid % 8 == 0;
+    conv3x3_x6_kernel<1, false, 3, true, true><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+    PUNET_LAUNCH_CHECK("conv3x3_f16s");
+    return PUNET_OK;
+}
+
 static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
                           int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
                           const void* gate_bits, void* gate_out, int accumulate, int relu, int B, int H, int W, int opts,

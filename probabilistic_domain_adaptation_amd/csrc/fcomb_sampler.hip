@@ -194,7 +194,7 @@ __device__ __forceinline__ f32x16 mfma6(const bf16x8s (&wa)[3], const Planes& xb
 #ifndef PUNET_K7X_WGS
 #define PUNET_K7X_WGS 2  // workgroups per CU the register allocation aims at (tools/ab_variants.sh experiment knob)
 #endif
-template <int NBLK, bool F16 = false>  // F16: a.feat holds bf16 (the "bf16s" fast mode)
+template <int NBLK, int F16 = 0>  // F16: a.feat holds 1 = bf16 (the "bf16s" fast mode), 2 = fp16 ("f16s")
 __global__ __launch_bounds__(256, PUNET_K7X_WGS) void fcomb_sampler_x6_kernel(SamplerArgs a) {
     constexpr int CH = 32 * NBLK, KB = CH / 16;
     constexpr int LAYER = 3 * KB * 2 * CH;  // uint4 (8 x bf16) units per layer: [plane][K block][half][co]
@@ -246,7 +246,13 @@ __global__ __launch_bounds__(256, PUNET_K7X_WGS) void fcomb_sampler_x6_kernel(Sa
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             Planes xb;
-            if constexpr (F16) {  // already bf16: plane 0 is the value, the other planes are zero
+            if constexpr (F16 == 2) {  // fp16 storage: 11 significand bits = exactly two bf16 planes; the generic split does it
+                typedef _Float16 f16x4s __attribute__((ext_vector_type(4)));
+                const _Float16* f16 = reinterpret_cast<const _Float16*>(a.feat) + pix * CH + 16 * j + 4 * half;
+                const f16x4s g0 = *reinterpret_cast<const f16x4s*>(f16), g1 = *reinterpret_cast<const f16x4s*>(f16 + 8);
+                const float fv[8] = {(float)g0[0], (float)g0[1], (float)g0[2], (float)g0[3], (float)g1[0], (float)g1[1], (float)g1[2], (float)g1[3]};
+                xb = split8(fv);
+            } else if constexpr (F16 == 1) {  // already bf16: plane 0 is the value, the other planes are zero
                 typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
                 const __bf16* f16 = reinterpret_cast<const __bf16*>(a.feat) + pix * CH + 16 * j + 4 * half;
                 const bf16x4s g0 = *reinterpret_cast<const bf16x4s*>(f16), g1 = *reinterpret_cast<const bf16x4s*>(f16 + 8);
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(256, PUNET_K7X_WGS) void fcomb_sampler_x6_kernel(Sa
 
 }  // namespace
 
-static int fcomb_sample_launch(bool x6, bool f16, const float* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
+static int fcomb_sample_launch(bool x6, int f16, const float* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
                                const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z, float* logits,
                                int N, int B, int HW, int CH, int nmid, float upper, float lower, int masking, void* stream) {
     PUNET_CHECK_ARG(feat && w1 && zb && w3 && b3, "punet_fcomb_sample: null pointer");
@@ -354,13 +360,19 @@ static int fcomb_sample_launch(bool x6, bool f16, const float* feat, const float
         }
     }
     if (x6 && f16) {
-        const void* fn16 = CH == 64 ? (const void*)fcomb_sampler_x6_kernel<2, true> : (const void*)fcomb_sampler_x6_kernel<1, true>;
+        const void* fn16 = f16 == 2 ? (CH == 64 ? (const void*)fcomb_sampler_x6_kernel<2, 2> : (const void*)fcomb_sampler_x6_kernel<1, 2>)
+                                    : (CH == 64 ? (const void*)fcomb_sampler_x6_kernel<2, 1> : (const void*)fcomb_sampler_x6_kernel<1, 1>);
         if (shmem > 48 * 1024 && hipFuncSetAttribute(fn16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {
             punet_set_error("punet_fcomb_sample: cannot reserve %zu bytes of LDS", shmem);
             return PUNET_ERR_HIP;
         }
-        if (CH == 64) fcomb_sampler_x6_kernel<2, true><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
-        else fcomb_sampler_x6_kernel<1, true><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
+        if (f16 == 2) {
+            if (CH == 64) fcomb_sampler_x6_kernel<2, 2><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
+            else fcomb_sampler_x6_kernel<1, 2><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
+        } else {
+            if (CH == 64) fcomb_sampler_x6_kernel<2, 1><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
+            else fcomb_sampler_x6_kernel<1, 1><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
+        }
     } else if (x6) {
         if (CH == 64) fcomb_sampler_x6_kernel<2><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
         else fcomb_sampler_x6_kernel<1><<<grid, 256, shmem, (hipStream_t)stream>>>(a);
@@ -375,14 +387,14 @@ static int fcomb_sample_launch(bool x6, bool f16, const float* feat, const float
 extern "C" int punet_fcomb_sample(const float* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
                                   const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z, float* logits, int N, int B, int HW,
                                   int CH, int nmid, float upper, float lower, int masking, void* stream) {
-    return fcomb_sample_launch(false, false, feat, w1, zb, wmid, wmid_stride, bmid, bmid_stride, w3, b3, y, z, logits, N, B, HW, CH, nmid,
+    return fcomb_sample_launch(false, 0, feat, w1, zb, wmid, wmid_stride, bmid, bmid_stride, w3, b3, y, z, logits, N, B, HW, CH, nmid,
                                upper, lower, masking, stream);
 }
 
 extern "C" int punet_fcomb_sample_x6(const float* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
                                      const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z, float* logits, int N, int B,
                                      int HW, int CH, int nmid, float upper, float lower, int masking, void* stream) {
-    return fcomb_sample_launch(true, false, feat, w1, zb, wmid, wmid_stride, bmid, bmid_stride, w3, b3, y, z, logits, N, B, HW, CH, nmid,
+    return fcomb_sample_launch(true, 0, feat, w1, zb, wmid, wmid_stride, bmid, bmid_stride, w3, b3, y, z, logits, N, B, HW, CH, nmid,
                                upper, lower, masking, stream);
 }
 
@@ -391,6 +403,15 @@ extern "C" int punet_fcomb_sample_x6_bf16s(const void* feat, const float* w1, co
                                            const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z,
                                            float* logits, int N, int B, int HW, int CH, int nmid, float upper, float lower, int masking,
                                            void* stream) {
-    return fcomb_sample_launch(true, true, (const float*)feat, w1, zb, wmid, wmid_stride, bmid, bmid_stride, w3, b3, y, z, logits, N, B, HW,
+    return fcomb_sample_launch(true, 1, (const float*)feat, w1, zb, wmid, wmid_stride, bmid, bmid_stride, w3, b3, y, z, logits, N, B, HW,
+                               CH, nmid, upper, lower, masking, stream);
+}
+
+// ... stored as fp16 (the "f16s" fast mode)
+extern "C" int punet_fcomb_sample_x6_f16s(const void* feat, const float* w1, const float* zb, const float* wmid, long wmid_stride,
+                                          const float* bmid, long bmid_stride, const float* w3, const float* b3, float* y, float* z,
+                                          float* logits, int N, int B, int HW, int CH, int nmid, float upper, float lower, int masking,
+                                          void* stream) {
+    return fcomb_sample_launch(true, 2, (const float*)feat, w1, zb, wmid, wmid_stride, bmid, bmid_stride, w3, b3, y, z, logits, N, B, HW,
                                CH, nmid, upper, lower, masking, stream);
 }

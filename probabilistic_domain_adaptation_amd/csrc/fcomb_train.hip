@@ -17,6 +17,7 @@
 // (they are L1/L2-resident: the same wave has just loaded them).
 // Determinism: no atomics.  Per-workgroup partial slabs (waves summed in order) + per-tile column sums, reduced by the usual
 // fixed-order second pass on the host side of this file.
+#include <type_traits>
 #include "common.h"
 #include "punet_hip.h"
 
@@ -70,21 +71,22 @@ __device__ __forceinline__ auto& pick(A& a, B& b) {
     if constexpr (FIRST) return a; else return b;
 }
 
-// F16: a.feat holds bf16 (the "bf16s" fast mode)
-template <int NBLK, int NMID, bool F16 = false>
+// F16: a.feat holds 1 = bf16 (the "bf16s" fast mode), 2 = fp16 ("f16s")
+template <int NBLK, int NMID, int F16 = 0>
 __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
+    typedef typename std::conditional<F16 == 2, _Float16, __bf16>::type ft_t16;
     // four consecutive channels of one pixel / one channel of one pixel, from either storage
     auto ldf4 = [&](size_t e) __attribute__((always_inline)) -> float4 {
-        if constexpr (F16) {
-            typedef __bf16 ft_bf16x4 __attribute__((ext_vector_type(4)));
-            const ft_bf16x4 h = *reinterpret_cast<const ft_bf16x4*>(reinterpret_cast<const __bf16*>(a.feat) + e);
+        if constexpr (F16 != 0) {
+            typedef ft_t16 ft_bf16x4 __attribute__((ext_vector_type(4)));
+            const ft_bf16x4 h = *reinterpret_cast<const ft_bf16x4*>(reinterpret_cast<const ft_t16*>(a.feat) + e);
             return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
         } else {
             return *reinterpret_cast<const float4*>(a.feat + e);
         }
     };
     auto ldf1 = [&](size_t e) __attribute__((always_inline)) -> float {
-        if constexpr (F16) return (float)reinterpret_cast<const __bf16*>(a.feat)[e];
+        if constexpr (F16 != 0) return (float)reinterpret_cast<const ft_t16*>(a.feat)[e];
         else return a.feat[e];
     };
     constexpr int CH = 32 * NBLK;
@@ -443,7 +445,7 @@ extern "C" size_t punet_fcomb_train_workspace_floats(int B, int HW, int CH, int 
     return (size_t)grid * slab_floats(CH, nmid) + (size_t)ntiles * CH + (size_t)grid + 4;
 }
 
-static int fcomb_train_impl(bool f16, const float* feat, const float* w1, const float* zb, const float* wmid, const float* bmid,
+static int fcomb_train_impl(int f16, const float* feat, const float* w1, const float* zb, const float* wmid, const float* bmid,
                             const float* w3, const float* b3, const float* target, const float* consm, float gscale, float* logits,
                             float* dfeat, float* loss_sum, float* workspace, int B, int HW, int CH, int nmid, void* stream_);
 
@@ -451,7 +453,7 @@ extern "C" int punet_fcomb_train_fwd_bwd(const float* feat, const float* w1, con
                                          const float* w3, const float* b3, const float* target, const float* consm, float gscale,
                                          float* logits, float* dfeat, float* loss_sum, float* workspace, int B, int HW, int CH,
                                          int nmid, void* stream_) {
-    return fcomb_train_impl(false, feat, w1, zb, wmid, bmid, w3, b3, target, consm, gscale, logits, dfeat, loss_sum, workspace, B, HW,
+    return fcomb_train_impl(0, feat, w1, zb, wmid, bmid, w3, b3, target, consm, gscale, logits, dfeat, loss_sum, workspace, B, HW,
                             CH, nmid, stream_);
 }
 
@@ -459,11 +461,19 @@ extern "C" int punet_fcomb_train_fwd_bwd_bf16s(const void* feat, const float* w1
                                                const float* bmid, const float* w3, const float* b3, const float* target,
                                                const float* consm, float gscale, float* logits, float* dfeat, float* loss_sum,
                                                float* workspace, int B, int HW, int CH, int nmid, void* stream_) {
-    return fcomb_train_impl(true, (const float*)feat, w1, zb, wmid, bmid, w3, b3, target, consm, gscale, logits, dfeat, loss_sum,
+    return fcomb_train_impl(1, (const float*)feat, w1, zb, wmid, bmid, w3, b3, target, consm, gscale, logits, dfeat, loss_sum,
                             workspace, B, HW, CH, nmid, stream_);
 }
 
-static int fcomb_train_impl(bool f16, const float* feat, const float* w1, const float* zb, const float* wmid, const float* bmid,
+extern "C" int punet_fcomb_train_fwd_bwd_f16s(const void* feat, const float* w1, const float* zb, const float* wmid,
+                                              const float* bmid, const float* w3, const float* b3, const float* target,
+                                              const float* consm, float gscale, float* logits, float* dfeat, float* loss_sum,
+                                              float* workspace, int B, int HW, int CH, int nmid, void* stream_) {
+    return fcomb_train_impl(2, (const float*)feat, w1, zb, wmid, bmid, w3, b3, target, consm, gscale, logits, dfeat, loss_sum,
+                            workspace, B, HW, CH, nmid, stream_);
+}
+
+static int fcomb_train_impl(int f16, const float* feat, const float* w1, const float* zb, const float* wmid, const float* bmid,
                             const float* w3, const float* b3, const float* target, const float* consm, float gscale, float* logits,
                             float* dfeat, float* loss_sum, float* workspace, int B, int HW, int CH, int nmid, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -493,8 +503,9 @@ static int fcomb_train_impl(bool f16, const float* feat, const float* w1, const 
     } while (0)
 #define PUNET_TRAIN_LAUNCH(NB, NM)                \
     do {                                          \
-        if (f16) PUNET_TRAIN_LAUNCH1(NB, NM, true); \
-        else PUNET_TRAIN_LAUNCH1(NB, NM, false);  \
+        if (f16 == 2) PUNET_TRAIN_LAUNCH1(NB, NM, 2); \
+        else if (f16 == 1) PUNET_TRAIN_LAUNCH1(NB, NM, 1); \
+        else PUNET_TRAIN_LAUNCH1(NB, NM, 0);  \
     } while (0)
     if (CH == 64 && nmid == 1) PUNET_TRAIN_LAUNCH(2, 1);
     else if (CH == 64) PUNET_TRAIN_LAUNCH(2, 0);

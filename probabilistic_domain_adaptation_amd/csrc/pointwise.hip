@@ -4,6 +4,7 @@
 #include "punet_hip.h"
 
 #include <math.h>
+#include <type_traits>
 
 namespace {
 
@@ -190,14 +191,15 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float4* __res
     }
 }
 
-// the same on bf16 tensors (the "bf16s" fast mode): 8-byte loads / stores of four channels, fp32 interpolation
-typedef __bf16 pw_bf16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ld_bf16x4(const pw_bf16x4* p) {
-    const pw_bf16x4 v = *p;
-    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
-}
-__global__ __launch_bounds__(256) void upsample2x_fwd16_kernel(const pw_bf16x4* __restrict__ x, pw_bf16x4* __restrict__ y, int B, int H,
+// the same on 16-bit tensors (T16 = __bf16: the "bf16s" fast mode; _Float16: "f16s"): 8-byte loads / stores of four channels,
+// fp32 interpolation
+template <typename T16>
+__global__ __launch_bounds__(256) void upsample2x_fwd16_kernel(const void* __restrict__ xv, void* __restrict__ yv, int B, int H,
                                                                int W, int C4, int c4_shift) {
+    typedef T16 t16x4 __attribute__((ext_vector_type(4)));
+    const t16x4* x = reinterpret_cast<const t16x4*>(xv);
+    t16x4* y = reinterpret_cast<t16x4*>(yv);
+    auto ld4 = [](const t16x4* p) { const t16x4 v = *p; return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]); };
     const int OH = 2 * H, OW = 2 * W;
     const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
     const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
@@ -214,15 +216,15 @@ __global__ __launch_bounds__(256) void upsample2x_fwd16_kernel(const pw_bf16x4* 
         up_src(oy, sh, H, h1, hp, hl1);
         up_src(ox, sw, W, w1, wp, wl1);
         const float hl0 = 1.f - hl1, wl0 = 1.f - wl1;
-        const pw_bf16x4* r0 = x + ((b * H + h1) * W) * C4 + c;
-        const pw_bf16x4* r1 = x + ((b * H + h1 + hp) * W) * C4 + c;
-        const float4 v00 = ld_bf16x4(r0 + (size_t)w1 * C4), v01 = ld_bf16x4(r0 + (size_t)(w1 + wp) * C4);
-        const float4 v10 = ld_bf16x4(r1 + (size_t)w1 * C4), v11 = ld_bf16x4(r1 + (size_t)(w1 + wp) * C4);
-        pw_bf16x4 o;
-        o[0] = (__bf16)(hl0 * (wl0 * v00.x + wl1 * v01.x) + hl1 * (wl0 * v10.x + wl1 * v11.x));
-        o[1] = (__bf16)(hl0 * (wl0 * v00.y + wl1 * v01.y) + hl1 * (wl0 * v10.y + wl1 * v11.y));
-        o[2] = (__bf16)(hl0 * (wl0 * v00.z + wl1 * v01.z) + hl1 * (wl0 * v10.z + wl1 * v11.z));
-        o[3] = (__bf16)(hl0 * (wl0 * v00.w + wl1 * v01.w) + hl1 * (wl0 * v10.w + wl1 * v11.w));
+        const t16x4* r0 = x + ((b * H + h1) * W) * C4 + c;
+        const t16x4* r1 = x + ((b * H + h1 + hp) * W) * C4 + c;
+        const float4 v00 = ld4(r0 + (size_t)w1 * C4), v01 = ld4(r0 + (size_t)(w1 + wp) * C4);
+        const float4 v10 = ld4(r1 + (size_t)w1 * C4), v11 = ld4(r1 + (size_t)(w1 + wp) * C4);
+        t16x4 o;
+        o[0] = (T16)(hl0 * (wl0 * v00.x + wl1 * v01.x) + hl1 * (wl0 * v10.x + wl1 * v11.x));
+        o[1] = (T16)(hl0 * (wl0 * v00.y + wl1 * v01.y) + hl1 * (wl0 * v10.y + wl1 * v11.y));
+        o[2] = (T16)(hl0 * (wl0 * v00.z + wl1 * v01.z) + hl1 * (wl0 * v10.z + wl1 * v11.z));
+        o[3] = (T16)(hl0 * (wl0 * v00.w + wl1 * v01.w) + hl1 * (wl0 * v10.w + wl1 * v11.w));
         y[(size_t)row * OW * C4 + e] = o;
     }
 }
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float4* __res
 // K6: latent head = global average pool + 1x1 conv C -> 2L (probabilistic_unet.py:126-137)
 // ------------------------------------------------------------------------------------------------
 // partial[b][s][c] = sum over the pixels of slice s of x[b][p][c]
-template <bool IN16>  // IN16: x holds bf16 (the "bf16s" fast mode); sums are fp32 either way
+template <int IN16>  // IN16: x holds 1 = bf16 (the "bf16s" fast mode), 2 = fp16 ("f16s"); sums are fp32 either way
 __global__ __launch_bounds__(256) void chan_sum_partial_kernel(const void* __restrict__ xv_, float4* __restrict__ partial,
                                                                int P, int C4, int S) {
     const float4* x = reinterpret_cast<const float4*>(xv_);
@@ -306,8 +308,9 @@ __global__ __launch_bounds__(256) void chan_sum_partial_kernel(const void* __res
         if (c < C4 && pl < ppl)
             for (int p = p0 + pl; p < p1; p += ppl) {
                 float4 v;
-                if constexpr (IN16) {
-                    typedef __bf16 cs_bf16x4 __attribute__((ext_vector_type(4)));
+                if constexpr (IN16 != 0) {
+                    typedef typename std::conditional<IN16 == 2, _Float16, __bf16>::type cs_t16;
+                    typedef cs_t16 cs_bf16x4 __attribute__((ext_vector_type(4)));
                     const cs_bf16x4 h = reinterpret_cast<const cs_bf16x4*>(xv_)[((size_t)b * P + p) * C4 + c];
                     v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
                 } else {
@@ -596,7 +599,8 @@ __global__ void bcast_mean_bwd_kernel(const float4* __restrict__ dmean, const fl
 // ReLU gate bits (punet_gate_dwords layout) of a bf16 activation tensor: for producers that do not publish them themselves (the
 // first-layer kernel in the "bf16s" mode).  One thread per dword: pixel x = 32 t + (l & 31), bit 16 nb + 4 rg + e <-> channel
 // 64 cb + 32 nb + 8 rg + 4 (l >> 5) + e.
-__global__ void gate_bits_bf16_kernel(const __bf16* __restrict__ y, unsigned* __restrict__ bits, int B, int H, int W, int C) {
+template <typename T16>
+__global__ void gate_bits16_kernel(const T16* __restrict__ y, unsigned* __restrict__ bits, int B, int H, int W, int C) {
     const int tiles = (W + 31) >> 5, cbs = (C + 63) >> 6;
     const size_t n = (size_t)B * H * tiles * cbs * 64;
     GRID_STRIDE(i, n) {
@@ -609,7 +613,7 @@ __global__ void gate_bits_bf16_kernel(const __bf16* __restrict__ y, unsigned* __
         const int x = 32 * t + (l & 31), half = l >> 5;
         unsigned g = 0u;
         if (x < W) {
-            const __bf16* p = y + ((b * H + yy) * W + x) * C;
+            const T16* p = y + ((b * H + yy) * W + x) * C;
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -1179,19 +1183,26 @@ extern "C" int punet_chan_sum(const float* x, float* out, float* workspace, int 
                               void* stream) {
     PUNET_CHECK_ARG(x && out && workspace && C % 4 == 0 && B > 0 && P > 0, "punet_chan_sum: bad args (C=%d)", C);
     const int S = chan_slices(P, C);
-    chan_sum_partial_kernel<false><<<dim3(S, B), 256, 256 * sizeof(float4), STREAM>>>(x, (float4*)workspace, P, C / 4, S);
+    chan_sum_partial_kernel<0><<<dim3(S, B), 256, 256 * sizeof(float4), STREAM>>>(x, (float4*)workspace, P, C / 4, S);
     PUNET_LAUNCH_CHECK("chan_sum_partial");
     chan_sum_finalize_kernel<<<dim3(B, (C + 63) / 64), 256, 0, STREAM>>>(workspace, out, S, C, scale);
     PUNET_LAUNCH_CHECK("chan_sum_finalize");
     return PUNET_OK;
 }
 
-extern "C" int punet_upsample2x_fwd_bf16s(const void* x, void* y, int B, int H, int W, int C, void* stream) {
-    PUNET_CHECK_ARG(x && y && C % 4 == 0 && B > 0 && H > 0 && W > 0, "punet_upsample2x_fwd_bf16s: bad args (C=%d)", C);
-    upsample2x_fwd16_kernel<<<dim3(ceil_div(2 * W * (C / 4), 256), B * 2 * H < 65535 ? B * 2 * H : 65535), 256, 0, STREAM>>>(
-        (const pw_bf16x4*)x, (pw_bf16x4*)y, B, H, W, C / 4, pow2_shift(C / 4));
+template <typename T16>
+static int upsample16_launch(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+    PUNET_CHECK_ARG(x && y && C % 4 == 0 && B > 0 && H > 0 && W > 0, "punet_upsample2x_fwd (16-bit storage): bad args (C=%d)", C);
+    upsample2x_fwd16_kernel<T16><<<dim3(ceil_div(2 * W * (C / 4), 256), B * 2 * H < 65535 ? B * 2 * H : 65535), 256, 0, STREAM>>>(
+        x, y, B, H, W, C / 4, pow2_shift(C / 4));
     PUNET_LAUNCH_CHECK("upsample2x_fwd16");
     return PUNET_OK;
+}
+extern "C" int punet_upsample2x_fwd_bf16s(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+    return upsample16_launch<__bf16>(x, y, B, H, W, C, stream);
+}
+extern "C" int punet_upsample2x_fwd_f16s(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+    return upsample16_launch<_Float16>(x, y, B, H, W, C, stream);
 }
 
 extern "C" int punet_latent_head_fwd(const float* enc, const float* w, const float* bias, float* mean, float* muls,
@@ -1204,17 +1215,26 @@ extern "C" int punet_latent_head_fwd(const float* enc, const float* w, const flo
     return PUNET_OK;
 }
 
-extern "C" int punet_latent_head_fwd_bf16s(const void* enc, const float* w, const float* bias, float* mean, float* muls,
-                                           float* workspace, int B, int P, int C, int J, void* stream) {
-    PUNET_CHECK_ARG(enc && w && bias && mean && muls && workspace && C % 4 == 0, "punet_latent_head_fwd_bf16s: bad args");
+template <int IN16>
+static int latent_head16_launch(const void* enc, const float* w, const float* bias, float* mean, float* muls, float* workspace, int B,
+                                int P, int C, int J, void* stream) {
+    PUNET_CHECK_ARG(enc && w && bias && mean && muls && workspace && C % 4 == 0, "punet_latent_head_fwd (16-bit storage): bad args");
     const int S = chan_slices(P, C);
-    chan_sum_partial_kernel<true><<<dim3(S, B), 256, 256 * sizeof(float4), STREAM>>>(enc, (float4*)workspace, P, C / 4, S);
+    chan_sum_partial_kernel<IN16><<<dim3(S, B), 256, 256 * sizeof(float4), STREAM>>>(enc, (float4*)workspace, P, C / 4, S);
     PUNET_LAUNCH_CHECK("chan_sum_partial16");
     chan_sum_finalize_kernel<<<dim3(B, (C + 63) / 64), 256, 0, STREAM>>>(workspace, mean, S, C, 1.f / (float)P);
     PUNET_LAUNCH_CHECK("chan_sum_finalize");
     latent_head_kernel<<<B, 256, 0, STREAM>>>(mean, w, bias, muls, C, J);
     PUNET_LAUNCH_CHECK("latent_head");
     return PUNET_OK;
+}
+extern "C" int punet_latent_head_fwd_bf16s(const void* enc, const float* w, const float* bias, float* mean, float* muls,
+                                           float* workspace, int B, int P, int C, int J, void* stream) {
+    return latent_head16_launch<1>(enc, w, bias, mean, muls, workspace, B, P, C, J, stream);
+}
+extern "C" int punet_latent_head_fwd_f16s(const void* enc, const float* w, const float* bias, float* mean, float* muls,
+                                          float* workspace, int B, int P, int C, int J, void* stream) {
+    return latent_head16_launch<2>(enc, w, bias, mean, muls, workspace, B, P, C, J, stream);
 }
 
 extern "C" int punet_reparam(const float* muls, const float* eps, float* z, int N, int B, int L, void* stream) {
@@ -1312,12 +1332,19 @@ extern "C" int punet_latent_head_bwd(const float* d_muls, const float* mean, con
     return PUNET_OK;
 }
 
-extern "C" int punet_gate_bits_bf16(const void* y, void* bits, int B, int H, int W, int C, void* stream) {
-    PUNET_CHECK_ARG(y && bits && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "punet_gate_bits_bf16: bad args");
+template <typename T16>
+static int gate_bits16_launch(const void* y, void* bits, int B, int H, int W, int C, void* stream) {
+    PUNET_CHECK_ARG(y && bits && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "punet_gate_bits (16-bit storage): bad args");
     const size_t n = (size_t)B * H * ((W + 31) / 32) * ((C + 63) / 64) * 64;
-    gate_bits_bf16_kernel<<<ew_grid(n), EW_BLOCK, 0, STREAM>>>((const __bf16*)y, (unsigned*)bits, B, H, W, C);
-    PUNET_LAUNCH_CHECK("gate_bits_bf16");
+    gate_bits16_kernel<T16><<<ew_grid(n), EW_BLOCK, 0, STREAM>>>((const T16*)y, (unsigned*)bits, B, H, W, C);
+    PUNET_LAUNCH_CHECK("gate_bits16");
     return PUNET_OK;
+}
+extern "C" int punet_gate_bits_bf16(const void* y, void* bits, int B, int H, int W, int C, void* stream) {
+    return gate_bits16_launch<__bf16>(y, bits, B, H, W, C, stream);
+}
+extern "C" int punet_gate_bits_f16(const void* y, void* bits, int B, int H, int W, int C, void* stream) {
+    return gate_bits16_launch<_Float16>(y, bits, B, H, W, C, stream);
 }
 
 extern "C" int punet_latent_head_bwd_bits(const float* d_muls, const float* mean, const float* w, const void* enc_bits, float* dw,

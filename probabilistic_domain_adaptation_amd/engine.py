@@ -196,10 +196,12 @@ def _stream():
 
 
 # bf16 products per fp32 product in the split-plane kernels; handed to the library with every call (options word)
-_X6_PRODUCTS = {"x6": 6, "x3": 3, "bf16": 1, "bf16s": 1, "f16x3": 3, "f16": 1}
+_X6_PRODUCTS = {"x6": 6, "x3": 3, "bf16": 1, "bf16s": 1, "f16x3": 3, "f16": 1, "f16s": 1}
 # fp16 planes per operand of the fp16-operand modes (csrc/common.h): "f16x3" = h + l, products hh + hl + lh (22-23 significand
 # bits at x3's cost); "f16" = one plane, the analogue of the reference scripts' fp16 autocast (LIVECell/livecell_mt.py:107)
-_F16_PLANES = {"f16x3": 2, "f16": 1}
+# ("f16s" = "f16" + fp16 STORAGE of the activations, unscaled as under autocast; gradients stay fp32 and are scaled per tensor)
+_F16_PLANES = {"f16x3": 2, "f16": 1, "f16s": 1}
+_ACT16 = {"bf16s": torch.bfloat16, "f16s": torch.float16}  # activation storage type of the 16-bit-storage modes
 
 
 def _aptr(t):
@@ -262,7 +264,7 @@ class PUNetEngine:
         # bits, more than the fp16 autocast of the reference), "bf16" = one plane.  Storage stays fp32 in every mode.
         self.conv_mode = conv_mode or os.environ.get("PUNET_CONV_MODE", "x6")
         if self.conv_mode not in _X6_PRODUCTS and self.conv_mode != "f32":
-            raise ValueError("PUNET_CONV_MODE must be one of 'x6', 'f32', 'x3', 'bf16', 'bf16s', 'f16x3', 'f16'")
+            raise ValueError("PUNET_CONV_MODE must be one of 'x6', 'f32', 'x3', 'bf16', 'bf16s', 'f16x3', 'f16', 'f16s'")
         self.x6 = self.conv_mode in _X6_PRODUCTS  # the split-plane kernel family
         self.f16 = _F16_PLANES.get(self.conv_mode, 0)  # fp16 planes per operand (0: the bf16 planes of the x6 family)
         self._wamax = {}  # flat.data_ptr() -> device float [nconv]: amax slot per 3x3 weight slab (fp16-operand modes)
@@ -270,7 +272,8 @@ class PUNetEngine:
         self._amax_pool, self._amax_next = None, 0
         # "bf16s" = "bf16" + bf16 STORAGE of the activations wherever no backward follows (forward_features: inference, the
         # teacher / weak pass): half the activation traffic, no fp32 -> bf16 conversion in the conv loaders
-        self.act16 = self.conv_mode == "bf16s"
+        self.act16 = _ACT16.get(self.conv_mode)  # None: fp32 storage
+        self._sfx16 = "bf16s" if self.act16 is torch.bfloat16 else "f16s"  # suffix of the 16-bit-storage entry points
         self._infer16 = False  # set while forward_features runs in that mode
         # per-call options word of the split-plane kernels: products of this mode, MFMA shape 16 ($PUNET_X6_MFMA_SHAPE=32
         # selects the older 32x32x16 kernels, an A/B switch)
@@ -356,27 +359,31 @@ class PUNetEngine:
         B, H, W = x0.B, x0.H, x0.W
         cin = x0.C + (x1.C if x1 is not None else 0)
         assert cin == c.cin, (name, cin, c.cin)
-        if self._infer16 and c.k == 3:  # bf16 activation storage ("bf16s"): the gradients, if any follow, stay fp32
-            y = Act(torch.empty(B, H, W, c.cout, dtype=torch.bfloat16, device=self.device), B, H, W, c.cout, relu_out=relu)
+        if self._infer16 and c.k == 3:  # 16-bit activation storage ("bf16s" / "f16s"): the gradients, if any follow, stay fp32
+            y = Act(torch.empty(B, H, W, c.cout, dtype=self.act16, device=self.device), B, H, W, c.cout, relu_out=relu)
             if cin <= SMALL_CIN:
-                _lib.call("punet_conv3x3_small_fwd_bf16s", x0.ptr, cin, self._wptr(flat, c), self._bptr(flat, c), y.ptr, c.cout, B, H,
-                          W, int(relu), _stream())
+                _lib.call("punet_conv3x3_small_fwd_" + self._sfx16, x0.ptr, cin, self._wptr(flat, c), self._bptr(flat, c), y.ptr, c.cout,
+                          B, H, W, int(relu), _stream())
                 if relu and tape is not None:  # the first-layer kernel publishes no gate bits: one small pass makes them
                     y.bits = torch.empty(_lib.call("punet_gate_dwords", B, H, W, c.cout), dtype=torch.int32, device=self.device)
-                    _lib.call("punet_gate_bits_bf16", y.ptr, y.bits.data_ptr(), B, H, W, c.cout, _stream())
+                    _lib.call("punet_gate_bits_bf16" if self.act16 is torch.bfloat16 else "punet_gate_bits_f16", y.ptr,
+                              y.bits.data_ptr(), B, H, W, c.cout, _stream())
             else:
                 q = None
                 if pooled is not None and H % 2 == 0 and W % 2 == 0:
-                    q = Act(torch.empty(B, H // 2, W // 2, c.cout, dtype=torch.bfloat16, device=self.device), B, H // 2, W // 2, c.cout)
+                    q = Act(torch.empty(B, H // 2, W // 2, c.cout, dtype=self.act16, device=self.device), B, H // 2, W // 2, c.cout)
                     pooled.append(q)
                 if relu and (tape is not None or tape_bits):
                     y.bits = torch.empty(_lib.call("punet_gate_dwords", B, H, W, c.cout), dtype=torch.int32, device=self.device)
                 planes = self._x6[(flat.data_ptr(), 0)]
-                self._timed("conv3x3_fwd", 2.0 * B * H * W * cin * c.cout * 9, "punet_conv3x3_bf16s", x0.ptr, x0.C,
-                            x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0, planes.data_ptr() + 2 * 3 * c.w_off,
-                            c.w_numel, c.cout, 0, self._bptr(flat, c), y.ptr, c.cout,
-                            y.bits.data_ptr() if y.bits is not None else None, q.ptr if q is not None else None, int(relu), B, H, W,
-                            _stream())
+                args = (x0.ptr, x0.C, x1.ptr if x1 is not None else None, x1.C if x1 is not None else 0,
+                        planes.data_ptr() + 2 * 3 * c.w_off, c.w_numel, c.cout, 0, self._bptr(flat, c), y.ptr, c.cout,
+                        y.bits.data_ptr() if y.bits is not None else None, q.ptr if q is not None else None, int(relu), B, H, W)
+                if self.f16:  # fp16 storage is unscaled (as under autocast); the weights carry their slab's power-of-two scale
+                    self._timed("conv3x3_fwd", 2.0 * B * H * W * cin * c.cout * 9, "punet_conv3x3_f16s", *args,
+                                self._wamax_ptr(flat, c), _stream())
+                else:
+                    self._timed("conv3x3_fwd", 2.0 * B * H * W * cin * c.cout * 9, "punet_conv3x3_bf16s", *args, _stream())
             if tape is not None:
                 tape.append(("conv", c, x0, x1, y))
             if taps is not None:
@@ -385,10 +392,13 @@ class PUNetEngine:
         y = Act(self._empty(B, H, W, c.cout), B, H, W, c.cout, relu_out=relu)
         if cin <= SMALL_CIN:
             assert x1 is None and c.k == 3
-            _lib.call("punet_conv3x3_small_fwd", x0.ptr, cin, self._wptr(flat, c), self._bptr(flat, c), y.ptr, c.cout,
-                      B, H, W, int(relu), _stream())
-            if self.f16:
-                y.amax = self._amax_of(y.t)
+            if self.f16:  # the next layer scales its operand by this tensor's amax: published by the kernel itself
+                y.amax = self._slot()
+                _lib.call("punet_conv3x3_small_fwd_amax", x0.ptr, cin, self._wptr(flat, c), self._bptr(flat, c), y.ptr, c.cout,
+                          B, H, W, int(relu), y.amax.data_ptr(), _stream())
+            else:
+                _lib.call("punet_conv3x3_small_fwd", x0.ptr, cin, self._wptr(flat, c), self._bptr(flat, c), y.ptr, c.cout,
+                          B, H, W, int(relu), _stream())
         elif self.f16 and c.k == 3:  # fp16 planes scaled by powers of two from the operands' amax slots; publishes y's amax
             planes = self._x6[(flat.data_ptr(), 0)]
             if relu and (tape is not None or tape_bits):
@@ -450,9 +460,10 @@ class PUNetEngine:
         return y
 
     def upsample(self, x: Act, tape=None) -> Act:
-        if x.t.dtype == torch.bfloat16:
-            y = Act(torch.empty(x.B, 2 * x.H, 2 * x.W, x.C, dtype=torch.bfloat16, device=self.device), x.B, 2 * x.H, 2 * x.W, x.C)
-            _lib.call("punet_upsample2x_fwd_bf16s", x.ptr, y.ptr, x.B, x.H, x.W, x.C, _stream())
+        if x.t.dtype != torch.float32:
+            y = Act(torch.empty(x.B, 2 * x.H, 2 * x.W, x.C, dtype=x.t.dtype, device=self.device), x.B, 2 * x.H, 2 * x.W, x.C)
+            _lib.call("punet_upsample2x_fwd_bf16s" if x.t.dtype == torch.bfloat16 else "punet_upsample2x_fwd_f16s", x.ptr, y.ptr, x.B,
+                      x.H, x.W, x.C, _stream())
             if tape is not None:
                 tape.append(("up", x, y))
             return y
@@ -508,7 +519,8 @@ class PUNetEngine:
         mean = self._empty(enc.B, enc.C)
         muls = self._empty(enc.B, c.cout)
         ws = self.ws.get("chan", _lib.call("punet_chan_sum_workspace_floats", enc.B, P, enc.C))
-        _lib.call("punet_latent_head_fwd_bf16s" if enc.t.dtype == torch.bfloat16 else "punet_latent_head_fwd", enc.ptr,
+        _lib.call({torch.bfloat16: "punet_latent_head_fwd_bf16s", torch.float16: "punet_latent_head_fwd_f16s",
+                   torch.float32: "punet_latent_head_fwd"}[enc.t.dtype], enc.ptr,
                   self._wptr(flat, c), self._bptr(flat, c), mean.data_ptr(), muls.data_ptr(), ws.data_ptr(), enc.B, P, enc.C, c.cout,
                   _stream())
         return muls, mean, enc
@@ -519,7 +531,7 @@ class PUNetEngine:
         B, H, W, C = x_nhwc.shape
         self.prepare_forward_weights(flat)
         xin = Act(x_nhwc, B, H, W, C, needs_grad=False)
-        self._infer16 = self.act16
+        self._infer16 = self.act16 is not None
         try:
             muls_p, _, _ = self.latent(flat, "prior", xin, None, taps)
             feat = self.unet(flat, xin, None, taps)
@@ -587,6 +599,7 @@ class PUNetEngine:
         HW = feat.H * feat.W
         # split-plane arithmetic on the BF16 matrix cores in every x6-family mode (always six products: parity), fp32 MFMA in "f32"
         fn = "punet_fcomb_sample_x6_bf16s" if feat.t.dtype == torch.bfloat16 else \
+            "punet_fcomb_sample_x6_f16s" if feat.t.dtype == torch.float16 else \
             ("punet_fcomb_sample_x6" if self.x6 and self.sampler_x6 else "punet_fcomb_sample")
         K = c3.cout
         if CH not in (32, 64):  # outside the fused sampler's domain: Fcomb layer by layer per sample, then the consensus kernel K8
@@ -689,7 +702,7 @@ class PUNetEngine:
         tq = [] if record else None
         tp = [] if record else None
         tu = [] if record else None
-        self._infer16 = self.act16 and record  # "bf16s": the student pass stores its activations as bf16 too (gradients fp32)
+        self._infer16 = self.act16 is not None and record  # the student pass stores its activations in 16 bits too (gradients fp32)
         try:
             muls_q, mean_q, enc_q = self.latent(flat, "posterior", xq, tq, taps)
             muls_p, mean_p, enc_p = self.latent(flat, "prior", xin, tp, taps)
@@ -735,7 +748,8 @@ class PUNetEngine:
             ws = self._empty(_lib.call("punet_fcomb_train_workspace_floats", B, H * W, CH, nmid))
             logits, dfeat, rec = self._empty(B, 1, H, W), self._empty(B, H, W, CH), self._empty(1)
             self._timed("fcomb_train", 2.0 * 3 * B * H * W * CH * (CH * (1 + nmid) + 1),
-                        "punet_fcomb_train_fwd_bwd_bf16s" if feat.t.dtype == torch.bfloat16 else "punet_fcomb_train_fwd_bwd", feat.ptr,
+                        {torch.bfloat16: "punet_fcomb_train_fwd_bwd_bf16s", torch.float16: "punet_fcomb_train_fwd_bwd_f16s",
+                         torch.float32: "punet_fcomb_train_fwd_bwd"}[feat.t.dtype], feat.ptr,
                         self._wptr(flat, c1), zb.data_ptr(), self._wptr(flat, cm_) if nmid else None,
                         self._bptr(flat, cm_) if nmid else None, self._wptr(flat, c3), self._bptr(flat, c3), y_tgt.data_ptr(),
                         consm.data_ptr() if consm is not None else None, float(gscale), logits.data_ptr(), dfeat.data_ptr(),
@@ -744,7 +758,7 @@ class PUNetEngine:
                       loss_kind=loss_kind, kl_sampled=not analytic_kl, z_is_mean=bool(posterior_mean), recorded=record,
                       fused_fcomb=ws, dfeat=dfeat)
             return st
-        if feat.t.dtype == torch.bfloat16:  # "bf16s" outside the fused kernel's domain: the per-op kernels read fp32
+        if feat.t.dtype != torch.float32:  # 16-bit storage outside the fused kernel's domain: the per-op kernels read fp32
             f32 = Act(feat.t.float(), B, H, W, CH, relu_out=True)
             f32.bits = feat.bits
             st["feat_f32"] = f32
@@ -816,6 +830,11 @@ class PUNetEngine:
             self._timed("conv3x3_wgrad", 2.0 * B * H * W * x.C * c.cout * 9, "punet_conv_wgrad_f16", x.ptr, x.C, dz.data_ptr(),
                         c.cout, dw, c.cin, ci_off, db if with_bias else None, ws.data_ptr(), ns, B, H, W, int(accumulate), 1.0,
                         self.f16, 0, _aptr(x.amax), _aptr(getattr(dz, "punet_amax", None)), _stream())
+            return
+        if x6 and x.t.dtype == torch.float16:  # "f16s": the stored operand is unscaled, the gradient scaled by its amax
+            self._timed("conv3x3_wgrad", 2.0 * B * H * W * x.C * c.cout * 9, "punet_conv_wgrad_f16", x.ptr, x.C, dz.data_ptr(),
+                        c.cout, dw, c.cin, ci_off, db if with_bias else None, ws.data_ptr(), ns, B, H, W, int(accumulate), 1.0,
+                        1, 1, None, _aptr(getattr(dz, "punet_amax", None)), _stream())
             return
         if x6 and x.t.dtype == torch.bfloat16:
             self._timed("conv3x3_wgrad", 2.0 * B * H * W * x.C * c.cout * 9, "punet_conv_wgrad_bf16s", x.ptr, x.C, dz.data_ptr(),
@@ -1098,7 +1117,7 @@ class PUNetEngine:
             gm = {}
             denc, _ = self._grad_into(gm, enc)
             dmean = self._empty(B, enc.C)
-            if enc.t.dtype == torch.bfloat16:
+            if enc.t.dtype != torch.float32:
                 _lib.call("punet_latent_head_bwd_bits", d.data_ptr(), mean.data_ptr(), self._wptr(flat, c), enc.bits.data_ptr(),
                           gflat.data_ptr() + 4 * c.w_off, gflat.data_ptr() + 4 * c.b_off, dmean.data_ptr(), denc.data_ptr(), B, enc.H,
                           enc.W, enc.C, c.cout, acc, _stream())

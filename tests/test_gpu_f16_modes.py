@@ -261,3 +261,60 @@ def test_mixed_precision_flag_selects_the_documented_mode(monkeypatch):
     assert run(mixed_precision=True).model.engine.conv_mode == "f16"
     monkeypatch.setenv("PUNET_MIXED_PRECISION_MODE", "off")
     assert run(mixed_precision=True).model.engine.conv_mode == "x6"
+
+
+def test_f16_storage_mode_runs_on_fp16_tensors_and_stays_close_to_f16_arithmetic():
+    """"f16s": every activation of the forward passes IS an fp16 tensor (unscaled, as under the reference's autocast), the
+    logits stay within the one-plane arithmetic's own error of the fp32-storage "f16" mode, the student pass's gradients (fp32
+    in memory, scaled per tensor in the loaders) within a few per cent of "f16"'s - fused Fcomb kernel and per-op path (Dice)."""
+    import copy
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    dev = torch.device("cuda:0")
+    nf = [64, 64, 96, 128]
+    x, x1, x2, y = [t.to(dev) for t in O.synth_batch(2, 1, 64, 96, 0)]
+    eps = torch.randn(4, 2, 6, generator=torch.Generator().manual_seed(5)).to(dev)
+    outs = {}
+    for mode in ("x6", "f16", "f16s"):
+        m = ProbabilisticUnet(1, 1, nf, 6, 3, 1.0, consensus_masking=True, device=dev, seed=1, conv_mode=mode)
+        taps = {}
+        with torch.no_grad():
+            st = m.engine.forward_features(m.flat_params, m.engine.to_nhwc(x1), taps)
+            z = m.engine.reparam(st["prior_muls"], eps)
+            ym, cz, lg = m.engine.sample(m.flat_params, st["features"], z, 0.9, 0.1, False, want_logits=True)
+        torch.cuda.synchronize()
+        dt = {v.t.dtype for k, v in taps.items()}
+        assert dt == ({torch.float16} if mode == "f16s" else {torch.float32}), (mode, dt)
+        outs[mode] = lg.float().cpu()
+    e_f16 = (outs["f16"] - outs["x6"]).abs().max().item()
+    e_s = (outs["f16s"] - outs["x6"]).abs().max().item()
+    print(f"\nlogits max abs err vs x6: f16 {e_f16:.3e}, f16s {e_s:.3e}")
+    assert 1e-6 < e_s < 3.0 * e_f16 + 1e-3 and not torch.equal(outs["f16s"], outs["f16"])
+    grads = {}
+    for mode in ("f16", "f16s"):
+        for loss_kind in ("bce", "dice"):
+            m = ProbabilisticUnet(1, 1, nf, 6, 3, 1.0, consensus_masking=True, device=dev, seed=1, conv_mode=mode)
+            eng = m.engine
+            consm = (torch.rand(2, 1, 64, 96, generator=torch.Generator().manual_seed(3)) > 0.3).float().to(dev)
+            st = eng.elbo_forward(m.flat_params, eng.to_nhwc(x2), y, consm, eps[0], loss_kind, 1.0, 1.0, True)
+            if mode == "f16s":
+                assert st["feat"].t.dtype == torch.float16 and st["enc_q"].t.dtype == torch.float16
+                assert (st.get("fused_fcomb") is not None) == (loss_kind == "bce")
+            g = torch.zeros_like(m.flat_params)
+            eng.elbo_backward(m.flat_params, g, st, False)
+            torch.cuda.synchronize()
+            grads[(mode, loss_kind)] = (g.clone(), st["rec"].item())
+    for loss_kind in ("bce", "dice"):
+        (ga, ra), (gb, rb) = grads[("f16", loss_kind)], grads[("f16s", loss_kind)]
+        assert torch.isfinite(gb).all() and abs(ra - rb) <= 5e-3 * abs(ra) + 1e-3, (loss_kind, ra, rb)
+        rel_ = (ga - gb).norm().item() / ga.norm().item()
+        print(f"{loss_kind}: relative gradient difference f16s vs f16 {rel_:.3e}")
+        assert 1e-7 < rel_ < 0.02, (loss_kind, rel_)
+    m = ProbabilisticUnet(1, 1, nf, 6, 3, 1.0, consensus_masking=True, device=dev, seed=1, conv_mode="f16s")
+    t = copy.deepcopy(m)
+    assert t.engine.conv_mode == "f16s"
+    opt = FusedAdam(m, lr=1e-4)
+    loss, ys, zs, _ = FU.fused_self_training_step(m, t, opt, x1, x2, 4, True, eps_pl=eps, eps_s=eps[:1])
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss)) and ys.dtype == torch.float32 and 0.0 <= float(ys.min()) and float(ys.max()) <= 1.0
