@@ -446,6 +446,8 @@ def main():
                                "f32": ("pmc_hbm_traffic.json", "conv_mfma_kernel<3, false>")}[eng.conv_mode]
                     rdir = next(r for r in ("r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", r, fn)))
                     pm = json.load(open(os.path.join(ROOT, "profiles", rdir, fn)))
+                    if key not in pm["kernels"]:  # (round 3 added a template argument to the kernels' names)
+                        key = key.replace("<3, false>", "<3, false, false>")
                     traffic = round(pm["kernels"][key]["hbm_bytes_per_launch"])
                     import hashlib
                     hh = hashlib.sha256()

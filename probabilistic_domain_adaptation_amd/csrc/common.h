@@ -119,13 +119,23 @@ __device__ __forceinline__ float punet_f16_scale_of(float amax) {
 }
 __device__ __forceinline__ float punet_f16_scale_from(const float* slot) { return slot ? punet_f16_scale_of(*slot) : 1.f; }
 
+// One lane's contribution to an amax slot.  Thousands of workgroups publish into ONE address and contended atomics queue at
+// the memory side (~12 ns each: 8,192 blocks of the first-layer conv cost 30 us of a 78 us kernel): look first (an L2 read that
+// bypasses the L1) and skip the atomic when the slot already holds at least this value - after the first few publications almost
+// every one does.  A stale look only costs a redundant atomic; the maximum itself is still decided by atomicMax (order-independent).
+__device__ __forceinline__ void punet_amax_atomic(float* slot, float m) {
+    const unsigned mb = __builtin_bit_cast(unsigned, m);
+    if (mb > __hip_atomic_load(reinterpret_cast<unsigned*>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(reinterpret_cast<unsigned*>(slot), mb);
+}
+
 // amax slot update: |v| as unsigned bits (monotone for non-negative floats); NaN-free inputs assumed (a NaN would publish a
 // huge pattern -> scale 2^-113..: the consumer's values underflow to zero, the NaN itself still propagates through the MFMAs)
 __device__ __forceinline__ void punet_amax_publish(float* slot, float wave_local_max) {
     float m = wave_local_max;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, m));
+    if ((threadIdx.x & 63) == 0) punet_amax_atomic(slot, m);
 }
 
 // the same with ONE atomic per 256-thread workgroup: `lds` = 4 floats of LDS nobody else touches any more (the caller has passed a
@@ -136,8 +146,7 @@ __device__ __forceinline__ void punet_amax_publish_block256(float* slot, float t
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0)
-        atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3]))));
+    if (threadIdx.x == 0) punet_amax_atomic(slot, fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3])));
 }
 
 // scaled fp32 -> fp16 planes h (+ l) of a PAIR of values (v_pk_mul_f32, v_cvt_pk_f16_f32, one v_pk_fma_f32 for the residual)

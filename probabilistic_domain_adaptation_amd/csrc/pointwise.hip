@@ -1092,8 +1092,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float4* __restrict__ x,
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0)
-        atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]))));
+    if (threadIdx.x == 0) punet_amax_atomic(slot, fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])));
 }
 __global__ void amax_bound_kernel(const float* a, float ca, const float* b, float cb, float* out) {
     out[0] = (a ? ca * a[0] : 0.f) + (b ? cb * b[0] : 0.f);

@@ -42,12 +42,12 @@ for r in rows:
         if n_adam == 25:
             break
     d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    if "conv3x3_x6b_kernel<3, false>" in k:
+    if "conv3x3_x6b_kernel<3, false, false>" in k or "conv3x3_x6b_kernel<3, false>" in k:
         tot += d
         n += 1
     key = short(k)
     per[key] = per.get(key, 0) + d
-json.dump({"kernel": "conv3x3_x6b_kernel<3, false>",
+json.dump({"kernel": "conv3x3_x6b_kernel<3, false, false> (NP = 3 planes, forward, bf16 planes)",
            "population": "the default command's dispatches up to the 25th Adam step (= the headline workload: 1 sizing + 3 warm-up + "
                          "10 graph-replayed + 1 + 10 eagerly launched steps), from the default command's kernel_trace.csv",
            "launches": n, "avg_us": tot / n / 1e3,
@@ -66,4 +66,14 @@ if os.path.exists(stamp):
     env.update(PUNET_GIT_HEAD=head, PUNET_SOURCES_SHA16=sha)
 subprocess.check_call([sys.executable, os.path.join(here, "pmc_traffic.py"), one("pmc_fetch/*/*_counter_collection.csv"),
                        one("pmc_write/*/*_counter_collection.csv"), os.path.join(dst, "pmc_hbm_traffic_x6.json")], env=env)
+# the f16x3 fast mode: kernel stats + matrix-pipe utilisation of the same step
+for pat, name in (("stats_f16x3/*/*_kernel_stats.csv", "f16x3_kernel_stats.csv"),):
+    f = glob.glob(os.path.join(src, pat))
+    if f:
+        shutil.copy(f[0], os.path.join(dst, name))
+if os.path.exists(os.path.join(src, "f16x3_bench_under_rocprof.json")):
+    shutil.copy(os.path.join(src, "f16x3_bench_under_rocprof.json"), os.path.join(dst, "f16x3_bench_under_rocprof.json"))
+f = glob.glob(os.path.join(src, "pmc_mfma_f16x3/*/*_counter_collection.csv"))
+if f:
+    subprocess.check_call([sys.executable, os.path.join(here, "pmc_mfma.py"), f[0], os.path.join(dst, "pmc_mfma_util_f16x3.json")])
 print(open(os.path.join(dst, "default_command_headline_part_roofline_kernel.json")).read())
