@@ -240,6 +240,9 @@ __device__ __forceinline__ float up_weight(int o, int i, float scale, int in_siz
     return w;
 }
 
+#ifndef PUNET_UPBWD_BATCH
+#define PUNET_UPBWD_BATCH 1  // 0: round 2's form (per-tap divergent loads), for same-box A/B (tools/ab_variants.sh)
+#endif
 // dx[b][iy][ix] = (x > 0) * sum_{oy, ox} wy(oy, iy) * wx(ox, ix) * dy[b][oy][ox]   (gather form: deterministic)
 // grid = (ceil(W * C4 / 256), B * H); the (up to 7) row weights are block-uniform, the column weights are computed once
 // per thread instead of once per (oy, ox) pair; summation order (oy outer, ox inner, zero weights skipped) as before
@@ -265,9 +268,24 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float4* __res
         for (int k = 0; k < 7; ++k) wx[k] = ox0 + k <= ox1 ? up_weight(ox0 + k, ix, sw, W) : 0.f;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int oy = oy0; oy <= oy1; ++oy) {
-            const float wy = up_weight(oy, iy, sh, H);
+            const float wy = up_weight(oy, iy, sh, H);  // block-uniform: the skip below is a scalar branch
             if (wy == 0.f) continue;
             const float4* drow = dy + ((b * OH + oy) * OW + ox0) * C4 + c;
+#if PUNET_UPBWD_BATCH
+            // all seven column taps of the row are loaded together (clamped to the row's last valid column; taps of weight zero
+            // are selected away, not multiplied by zero) and only then accumulated, in the same order as before: with the loads
+            // inside per-tap divergent branches every tap was its own load -> wait -> fma round trip (28 per thread)
+            float4 g[7];
+    #pragma unroll
+            for (int k = 0; k < 7; ++k) g[k] = drow[(size_t)min(k, ox1 - ox0) * C4];
+    #pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const bool on = wx[k] != 0.f;
+                const float wgt = wy * wx[k];
+                s.x = on ? s.x + wgt * g[k].x : s.x; s.y = on ? s.y + wgt * g[k].y : s.y;
+                s.z = on ? s.z + wgt * g[k].z : s.z; s.w = on ? s.w + wgt * g[k].w : s.w;
+            }
+#else
     #pragma unroll
             for (int k = 0; k < 7; ++k) {
                 if (wx[k] == 0.f) continue;
@@ -275,6 +293,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float4* __res
                 const float wgt = wy * wx[k];
                 s.x += wgt * g.x; s.y += wgt * g.y; s.z += wgt * g.z; s.w += wgt * g.w;
             }
+#endif
         }
         if (xbits) {
             const unsigned g4 = punet_gate_nibble(xbits, b, H, W, 4 * C4, iy, ix, 4 * c);
