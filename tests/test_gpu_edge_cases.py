@@ -86,6 +86,22 @@ def test_smallest_and_ragged_shapes_match_oracle(model, B, H, W, n):
 ], ids=["nf8", "ctor_defaults", "depth3_latent2", "depth5_fcomb2_rgb", "six_channels", "first16", "first128_fcomb4",
         "first128_rgb", "first256"])
 def test_constructor_space_against_oracle(nf, H, W, latent, nfc, C):
+    _constructor_case(nf, H, W, latent, nfc, C, None)
+
+
+@pytest.mark.parametrize("nf,H,W,latent,nfc,C", [
+    ([32, 40, 72, 104], 40, 56, 6, 3, 1),      # not multiples of 32: the fp16 instantiation of the 32x32x16 kernels
+    ([32, 32, 64, 64, 96], 48, 80, 6, 2, 3),   # five levels, RGB
+    ([16, 32, 48, 64], 32, 40, 6, 3, 1),       # Fcomb layer by layer; run with the UNFUSED pooling kernel (inherited amax slot)
+], ids=["nf8", "depth5_fcomb2_rgb", "first16_unfused_pool"])
+def test_constructor_space_in_f16x3(nf, H, W, latent, nfc, C):
+    """The same whole-training-path check in the f16x3 arithmetic (what mixed_precision=True selects), same tolerances as the
+    parity arithmetic: amax slots through fused and unfused pooling, up-sampling, concat convolutions with two sources, the
+    accumulate path of skip connections, first-layer publications, other depths."""
+    _constructor_case(nf, H, W, latent, nfc, C, "f16x3", fuse_pool=nf[0] != 16)
+
+
+def _constructor_case(nf, H, W, latent, nfc, C, conv_mode, fuse_pool=True):
     """The constructor's argument space beyond the scripts' one setting - widths that are multiples of 8 but not of 32 (they
     go through the 32x32x16 kernels; the 16x16x32 kernel needs a multiple of 32), the reference's default arguments, other
     depths, latent sizes, Fcomb lengths and input channels: whole training path (logits, loss scalars, all gradients)
@@ -101,7 +117,8 @@ def test_constructor_space_against_oracle(nf, H, W, latent, nfc, C):
     cfg = O.PUNetConfig(C, 1, nf, latent, nfc, 1.0, consensus_masking=True, rl_swap=False)
     Pnp = O.synth_params(cfg.spec(), 6)
     lay = ParamLayout(C, 1, nf, latent, nfc)
-    eng = PUNetEngine(lay, dev)
+    eng = PUNetEngine(lay, dev, conv_mode=conv_mode)
+    eng.fuse_pool = eng.fuse_pool and fuse_pool
     flat = torch.zeros(lay.numel, device=dev)
     for k, v in lay.views(flat).items():
         v.copy_(torch.from_numpy(Pnp[k]))
