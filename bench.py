@@ -252,6 +252,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="(kept for compatibility; the segmented replay is now the default under torch.distributed too: it is used "
                          "when a one-step self-check shows it bit-identical to the eager step on EVERY rank, else eager with a note)")
+    ap.add_argument("--runtime", default=None, choices=["native", "python"],
+                    help="who walks the layer graph of a step: the step-level native runtime inside libpunet_hip.so (default where it "
+                         "applies: four library calls per step) or the Python engine (~500 per-op calls); same kernels, same bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -262,6 +265,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI; the default) or gloo (rehearsal on one GPU)")
     a = ap.parse_args()
 
+    if a.runtime:
+        os.environ["PUNET_RUNTIME"] = a.runtime
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -389,6 +394,9 @@ def main():
                        "launch": "hipGraph replay of the captured fused step (one graph launch per step"
                                  + (f"; {len(run.graphed.segments)} segments cut at the gradient all-reduces)" if world > 1 else ")")
                                  if use_graph else (graph_note or "eager: ~500 kernel launches per step from Python"),
+                       "graph_walk": ("native runtime inside libpunet_hip.so (csrc/runtime.hip): pseudo-labels, ELBO forward/backward, "
+                                      "regulariser, Adam+EMA = 4-5 library calls per step" if FU.native_ok(run.model)
+                                      else "Python engine (engine.py): one library call per kernel"),
                        "algorithmic_gflop_per_patch": gf,
                        "model_tflops_per_gpu": round(gf * patches / dt / world / 1e3, 2),
                        "host_enqueue_ms_per_step": round(1e3 * t_enq / a.steps, 2),

@@ -366,6 +366,47 @@ int punet_standardize_stats(const float* x, float* stats, double* workspace, int
 int punet_augment_view(const float* x, const float* stats, const float* noise, const float* params, int max_ksize,
                        float contrast_mean, float eps, float* tmp, float* out, int B, int C, int H, int W, void* stream);
 
+/* ==== Step-level runtime (csrc/runtime.hip): the graph walk as native host code =========================================
+ * The entry points above replace single ATen ops; these replace the METHODS the reference's trainers call - a host in any
+ * language drives a self-training step without knowing the layer graph:
+ *     punet_rt_pseudo_labels   = teacher.forward(x1, None, False) + N x sigmoid(teacher.sample()) + consensus
+ *                                (mean_teacher_trainer.py:72-88, fixmatch_trainer.py:37-54, punet_predictions.py:29-33)
+ *     punet_rt_elbo_fwd_bwd    = model.forward(x2, y, True); model.elbo(y, z); loss.backward()
+ *                                (probabilistic_unet.py:285-293, 341-371; mean_teacher_trainer.py:113-119)
+ *     punet_rt_l2_reg_grad     = the three l2_regularisation terms and their gradient (utils.py:32-40, mean_teacher_trainer.py:115-117)
+ *     punet_adam_hyper + punet_adam_ema_dev (above) = optimizer.step() + _momentum_update()
+ * Covered: num_classes = 1, num_filters[0] in {32, 64}, no_convs_fcomb in {2, 3}, filters multiples of 8, input_channels <= 6,
+ * the BCE criterion, the six-product parity arithmetic - every configuration the reference's scripts build with rl_swap=False.
+ * Parameters: ONE flat fp32 buffer in the reference's state-dict order, conv weights [ky][kx][cin][cout] (punet_rt_param_entry
+ * lists name / offset / logical shape of every tensor).  The runtime owns NOTHING on the device: every call carves its
+ * activations, gate bits, gradients, weight planes and split-K slabs out of a caller-provided ARENA (punet_rt_arena_bytes) and
+ * reads two small index tables from a caller-provided TABLES buffer (punet_rt_tables_bytes / punet_rt_init_tables, once).  No
+ * allocation, no synchronisation, no host read inside a call: each is hipGraph-capturable.  x is NHWC fp32 ([B][H][W][C]; for
+ * C = 1 the same bytes as NCHW); target / consm / y / z / logits are [B][1][H][W].  Not thread-safe per handle. */
+typedef struct PunetRt PunetRt;
+typedef struct {
+    int input_channels, num_classes, levels, latent_dim, no_convs_fcomb;
+    int num_filters[8];
+} PunetRtConfig;
+int punet_rt_create(const PunetRtConfig* cfg, PunetRt** out);
+void punet_rt_destroy(PunetRt* rt);
+long punet_rt_param_floats(const PunetRt* rt);
+long punet_rt_unet_floats(const PunetRt* rt); /* [0, this) of the flat buffers = the U-Net's tensors (final first in the backward) */
+int punet_rt_num_entries(const PunetRt* rt);
+int punet_rt_param_entry(const PunetRt* rt, int i, char* name, int cap, long* off, long* numel, int* shape4);
+size_t punet_rt_tables_bytes(const PunetRt* rt);
+int punet_rt_init_tables(PunetRt* rt, void* device_tables, void* stream);
+size_t punet_rt_arena_bytes(PunetRt* rt, int B, int H, int W, int N, int training); /* exact: a dry walk of the call's graph */
+size_t punet_rt_last_arena_used(const PunetRt* rt);
+int punet_rt_pseudo_labels(PunetRt* rt, const float* flat, const float* x, int B, int H, int W, const float* eps, int N, float upper,
+                           float lower, int masking, float* y, float* z, float* logits, void* arena, size_t arena_bytes, void* stream);
+int punet_rt_elbo_fwd_bwd(PunetRt* rt, const float* flat, float* gflat, const float* x, const float* target, const float* consm,
+                          const float* eps, int B, int H, int W, float beta, float gscale, int accumulate, float* rec_out,
+                          float* kl_out, float* logits_out, void (*after_unet)(void*), void* ctx, void* arena, size_t arena_bytes,
+                          void* stream);
+int punet_rt_l2_reg_grad(PunetRt* rt, const float* flat, float* gflat, float coef, float* reg_out, void* arena, size_t arena_bytes,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,7 +109,34 @@ _SIGS = {
     "punet_augment_view": (_i, [_p, _p, _p, _p, _i, _f, _f, _p, _p, _i, _i, _i, _i, _p]),
 }
 
-_NO_WRAP = {"punet_last_error", "punet_build_info", "punet_device_ok", "punet_compute_units", "punet_wgrad_workspace_floats", "punet_gate_dwords",
+
+
+class PunetRtConfig(C.Structure):
+    """include/punet_hip.h: PunetRtConfig"""
+    _fields_ = [("input_channels", _i), ("num_classes", _i), ("levels", _i), ("latent_dim", _i), ("no_convs_fcomb", _i),
+                ("num_filters", _i * 8)]
+
+
+AFTER_UNET_CB = C.CFUNCTYPE(None, _p)  # void (*after_unet)(void* ctx)
+
+_SIGS.update({
+    "punet_rt_create": (_i, [C.POINTER(PunetRtConfig), C.POINTER(_p)]),
+    "punet_rt_destroy": (None, [_p]),
+    "punet_rt_param_floats": (_l, [_p]),
+    "punet_rt_unet_floats": (_l, [_p]),
+    "punet_rt_num_entries": (_i, [_p]),
+    "punet_rt_param_entry": (_i, [_p, _i, C.c_char_p, _i, C.POINTER(_l), C.POINTER(_l), C.POINTER(_i * 4)]),
+    "punet_rt_tables_bytes": (_sz, [_p]),
+    "punet_rt_init_tables": (_i, [_p, _p, _p]),
+    "punet_rt_arena_bytes": (_sz, [_p, _i, _i, _i, _i, _i]),
+    "punet_rt_last_arena_used": (_sz, [_p]),
+    "punet_rt_pseudo_labels": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _f, _f, _i, _p, _p, _p, _p, _sz, _p]),
+    "punet_rt_elbo_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _p, _p, _p, AFTER_UNET_CB, _p, _p, _sz, _p]),
+    "punet_rt_l2_reg_grad": (_i, [_p, _p, _p, _f, _p, _p, _sz, _p]),
+})
+
+_NO_WRAP = {"punet_rt_destroy", "punet_rt_param_floats", "punet_rt_unet_floats", "punet_rt_num_entries", "punet_rt_tables_bytes",
+            "punet_rt_arena_bytes", "punet_rt_last_arena_used", "punet_last_error", "punet_build_info", "punet_device_ok", "punet_compute_units", "punet_wgrad_workspace_floats", "punet_gate_dwords",
             "punet_wgrad_slices", "punet_wgrad_x6_slices", "punet_small_wgrad_workspace_floats", "punet_chan_sum_workspace_floats",
             "punet_dot_bwd_workspace_floats", "punet_loss_workspace_floats", "punet_fcomb_train_supported",
             "punet_fcomb_train_workspace_floats", "punet_standardize_workspace_doubles"}

@@ -1,0 +1,651 @@
+// Step-level runtime of libpunet_hip.so: the graph walk of the Probabilistic U-Net - forward(patch, segm, training)
+// (probabilistic_unet.py:285-293), sample / consensus (mean_teacher_trainer.py:72-88), elbo (probabilistic_unet.py:341-371) and the
+// whole backward that autograd performs in the reference - as NATIVE host code behind the C ABI (punet_create,
+// punet_forward_features, punet_elbo_fwd_bwd, ...).  A host in any language drives a training step with four calls and no
+// knowledge of the layer graph; the Python engine (engine.py) remains for the parts of the constructor space this runtime does
+// not cover and enqueues exactly the same kernels in the same order, so the two agree bit for bit (tests/test_gpu_runtime.py).
+//
+// Covered: num_classes = 1, num_filters[0] in {32, 64} (the fused Fcomb kernels), no_convs_fcomb in {2, 3}, every other filter
+// count a multiple of 8, input_channels + 1 <= 7, the BCE criterion, the six-product parity arithmetic ("x6") - i.e. every
+// configuration the reference's scripts build with rl_swap=False, and the bench workload.
+//
+// Memory: the runtime owns nothing on the device.  The caller hands every call an ARENA (device bytes, punet_rt_arena_bytes) that
+// is carved up by a bump allocator - activations, gate bits, gradients, weight planes, split-K slabs - and a small TABLES buffer
+// (punet_rt_tables_bytes, filled once by punet_rt_init_tables).  Nothing is allocated, freed or synchronised inside a call, so a
+// call is hipGraph-capturable as it stands.
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "punet_hip.h"
+
+namespace {
+
+constexpr int SMALL_CIN = 7;
+constexpr int X6_OPTS = PUNET_X6_OPTS(6, 16);
+
+struct Conv {
+    std::string name;
+    int cin, cout, k;
+    long w_off, b_off;
+    long w_numel() const { return (long)k * k * cin * cout; }
+};
+
+struct Entry {
+    std::string name;
+    long off, numel;
+    int shape[4];
+    int ndim;
+};
+
+struct Act {
+    float* t = nullptr;
+    int B = 0, H = 0, W = 0, C = 0;
+    bool relu_out = false, needs_grad = true;
+    unsigned* bits = nullptr;
+    float* grad = nullptr;  // gradient buffer once one exists (the "gm" map of engine.py)
+    size_t numel() const { return (size_t)B * H * W * C; }
+};
+
+struct Op {
+    int kind;  // 0 conv, 1 pool, 2 up
+    int conv;
+    Act *x0, *x1, *y;
+};
+
+struct Arena {
+    char* base;
+    size_t cap, used = 0;
+    void* take(size_t bytes) {  // (a real pass runs only after a dry pass has shown that everything fits: no overflow here)
+        const size_t a = (used + 255) & ~(size_t)255;
+        used = a + bytes;
+        return base + a;
+    }
+    float* floats(size_t n) { return (float*)take(n * sizeof(float)); }
+};
+
+}  // namespace
+
+struct PunetRt {
+    PunetRtConfig cfg;
+    std::vector<Conv> convs;
+    std::vector<Entry> entries;
+    std::vector<std::vector<int>> unet_down, unet_up, enc_prior, enc_post;
+    int head_prior = -1, head_post = -1, fc1 = -1, fcmid = -1, fc3 = -1;
+    long numel = 0, unet_numel = 0;
+    // host copies of the device tables; device pointers once punet_rt_init_tables has run
+    std::vector<long> x6_table;  // [nconv + 1][4]
+    int x6_nconv = 0;
+    long x6_units = 0;
+    std::vector<long> l2_table;  // [nchunks][3]
+    int l2_nchunks = 0, l2_ntensors = 0;
+    long* d_x6 = nullptr;
+    long* d_l2 = nullptr;
+    // per-call state
+    size_t last_arena_used = 0;
+    std::vector<Act*> acts;
+    Act* new_act(float* t, int B, int H, int W, int C, bool relu, bool needs_grad = true) {
+        Act* a = new Act();
+        a->t = t; a->B = B; a->H = H; a->W = W; a->C = C; a->relu_out = relu; a->needs_grad = needs_grad;
+        acts.push_back(a);
+        return a;
+    }
+    void clear_acts() {
+        for (Act* a : acts) delete a;
+        acts.clear();
+    }
+};
+
+namespace {
+
+int add_conv(PunetRt* rt, const std::string& name, int cin, int cout, int k) {
+    Conv c;
+    c.name = name; c.cin = cin; c.cout = cout; c.k = k; c.w_off = c.b_off = -1;
+    rt->convs.push_back(c);
+    return (int)rt->convs.size() - 1;
+}
+
+// the reference's nn.Sequential indices of the Encoder's convs (probabilistic_unet.py:44-63): a pool in front of blocks 1.., a
+// ReLU behind every conv
+std::vector<std::vector<int>> encoder_indices(int n_blocks) {
+    std::vector<std::vector<int>> out;
+    int idx = 0;
+    for (int i = 0; i < n_blocks; ++i) {
+        if (i) ++idx;
+        std::vector<int> blk;
+        for (int k = 0; k < 3; ++k) { blk.push_back(idx); idx += 2; }
+        out.push_back(blk);
+    }
+    return out;
+}
+
+#define RT_CALL(expr)                  \
+    do {                               \
+        const int rc_ = (expr);        \
+        if (rc_ != PUNET_OK) return rc_; \
+    } while (0)
+// a kernel launch through the per-op ABI: skipped in a DRY pass (which only walks the graph and sizes the arena)
+#define RT_LAUNCH(expr)                \
+    do {                               \
+        if (!dry) RT_CALL(expr);       \
+    } while (0)
+
+struct Pass {  // one forward / backward walk
+    PunetRt* rt;
+    const float* flat;
+    float* gflat;
+    Arena* ar;
+    void* stream;
+    const __bf16* planes0 = nullptr;  // forward-orientation weight planes of `flat`
+    const __bf16* planes1 = nullptr;  // input-gradient orientation
+    float* ws_wgrad = nullptr;
+    float* ws_chan = nullptr;
+    bool fuse_pool = true;
+    bool dry = false;
+
+    const float* w(const Conv& c) const { return flat + c.w_off; }
+    const float* b(const Conv& c) const { return flat + c.b_off; }
+
+    int split(int mode, const __bf16** out) {
+        __bf16* p = (__bf16*)ar->take((size_t)3 * rt->numel * 2);
+        RT_LAUNCH(punet_split_weights_x6_batch(flat, p, rt->d_x6, rt->x6_nconv, rt->x6_units, mode, stream));
+        *out = p;
+        return PUNET_OK;
+    }
+
+    // Conv2d + ReLU; tape != nullptr records the op and publishes the gate bits; pooled != nullptr asks for the fused 2x2 average
+    int conv(int ci, Act* x0, Act* x1, bool relu, std::vector<Op>* tape, Act** pooled, Act** out) {
+        const Conv& c = rt->convs[ci];
+        const int B = x0->B, H = x0->H, W = x0->W;
+        const int cin = x0->C + (x1 ? x1->C : 0);
+        if (cin != c.cin) {
+            punet_set_error("punet_rt: %s expects %d input channels, got %d", c.name.c_str(), c.cin, cin);
+            return PUNET_ERR_ARG;
+        }
+        Act* y = rt->new_act(ar->floats((size_t)B * H * W * c.cout), B, H, W, c.cout, relu);
+        if (cin <= SMALL_CIN) {
+            RT_LAUNCH(punet_conv3x3_small_fwd(x0->t, cin, w(c), b(c), y->t, c.cout, B, H, W, relu ? 1 : 0, stream));
+        } else {
+            if (relu && tape) y->bits = (unsigned*)ar->take(punet_gate_dwords(B, H, W, c.cout) * 4);
+            const void* wp = planes0 + 3 * c.w_off;
+            if (pooled && H % 2 == 0 && W % 2 == 0) {
+                Act* q = rt->new_act(ar->floats((size_t)B * (H / 2) * (W / 2) * c.cout), B, H / 2, W / 2, c.cout, false);
+                *pooled = q;
+                RT_LAUNCH(punet_conv3x3_x6_pooled(x0->t, x0->C, x1 ? x1->t : nullptr, x1 ? x1->C : 0, wp, c.w_numel(), c.cout, 0, b(c), 0,
+                                                y->t, c.cout, y->bits, q->t, relu ? 1 : 0, B, H, W, X6_OPTS, stream));
+            } else {
+                RT_LAUNCH(punet_conv3x3_x6_gated(x0->t, x0->C, x1 ? x1->t : nullptr, x1 ? x1->C : 0, wp, c.w_numel(), c.cout, 0, b(c), 0,
+                                               y->t, c.cout, nullptr, nullptr, y->bits, 0, relu ? 1 : 0, B, H, W, X6_OPTS, stream));
+            }
+        }
+        if (tape) tape->push_back(Op{0, ci, x0, x1, y});
+        *out = y;
+        return PUNET_OK;
+    }
+
+    int pool(Act* x, std::vector<Op>* tape, Act** out) {
+        const int OH = (x->H + 1) / 2, OW = (x->W + 1) / 2;
+        Act* y = rt->new_act(ar->floats((size_t)x->B * OH * OW * x->C), x->B, OH, OW, x->C, false);
+        RT_LAUNCH(punet_pool2x2_fwd(x->t, y->t, x->B, x->H, x->W, x->C, stream));
+        if (tape) tape->push_back(Op{1, -1, x, nullptr, y});
+        *out = y;
+        return PUNET_OK;
+    }
+
+    // the contracting stack shared by Unet (unet.py:50-55) and Encoder (probabilistic_unet.py:67-69)
+    int encoder_stack(const std::vector<std::vector<int>>& blocks, Act* x, std::vector<Op>* tape, std::vector<Act*>* outs, Act** last) {
+        Act* pooled = nullptr;
+        for (size_t i = 0; i < blocks.size(); ++i) {
+            if (i) {
+                if (pooled) {
+                    if (tape) tape->push_back(Op{1, -1, x, nullptr, pooled});
+                    x = pooled;
+                    pooled = nullptr;
+                } else {
+                    RT_CALL(pool(x, tape, &x));
+                }
+            }
+            for (size_t k = 0; k < blocks[i].size(); ++k) {
+                const bool want_pool = k + 1 == blocks[i].size() && i + 1 < blocks.size() && fuse_pool;
+                RT_CALL(conv(blocks[i][k], x, nullptr, true, tape, want_pool ? &pooled : nullptr, &x));
+            }
+            if (outs) outs->push_back(x);
+        }
+        *last = x;
+        return PUNET_OK;
+    }
+
+    int unet(Act* x, std::vector<Op>* tape, Act** feat) {
+        const int div = 1 << (rt->cfg.levels - 1);
+        if (x->H % div || x->W % div) {
+            punet_set_error("punet_rt: H and W must be divisible by %d (got %dx%d)", div, x->H, x->W);
+            return PUNET_ERR_ARG;
+        }
+        std::vector<Act*> outs;
+        RT_CALL(encoder_stack(rt->unet_down, x, tape, &outs, &x));
+        for (size_t j = 0; j < rt->unet_up.size(); ++j) {
+            Act* up = rt->new_act(ar->floats((size_t)x->B * 4 * x->H * x->W * x->C), x->B, 2 * x->H, 2 * x->W, x->C, false);
+            RT_LAUNCH(punet_upsample2x_fwd(x->t, up->t, x->B, x->H, x->W, x->C, stream));
+            if (tape) tape->push_back(Op{2, -1, x, nullptr, up});
+            Act* bridge = outs[outs.size() - 2 - j];
+            RT_CALL(conv(rt->unet_up[j][0], up, bridge, true, tape, nullptr, &x));  // concat order [up, bridge] (unet_blocks.py:56)
+            RT_CALL(conv(rt->unet_up[j][1], x, nullptr, true, tape, nullptr, &x));
+            RT_CALL(conv(rt->unet_up[j][2], x, nullptr, true, tape, nullptr, &x));
+        }
+        *feat = x;
+        return PUNET_OK;
+    }
+
+    // AxisAlignedConvGaussian.forward (probabilistic_unet.py:113-142): encoder, mean over H and W, 1x1 conv -> (mu, log sigma)
+    int latent(const std::vector<std::vector<int>>& blocks, int head, Act* x, std::vector<Op>* tape, float** muls, float** mean, Act** enc) {
+        RT_CALL(encoder_stack(blocks, x, tape, nullptr, enc));
+        const Conv& c = rt->convs[head];
+        const int P = (*enc)->H * (*enc)->W;
+        *mean = ar->floats((size_t)(*enc)->B * (*enc)->C);
+        *muls = ar->floats((size_t)(*enc)->B * c.cout);
+        RT_LAUNCH(punet_latent_head_fwd((*enc)->t, w(c), b(c), *mean, *muls, ws_chan, (*enc)->B, P, (*enc)->C, c.cout, stream));
+        return PUNET_OK;
+    }
+
+    float* grad_into(Act* a, int* acc) {
+        if (!a->grad) {
+            a->grad = ar->floats(a->numel());
+            *acc = 0;
+        } else {
+            *acc = 1;
+        }
+        return a->grad;
+    }
+
+    int wgrad(const Conv& c, Act* x, int ci_off, const float* dz, bool with_bias, int accumulate) {
+        float* dw = gflat + c.w_off;
+        float* db = gflat + c.b_off;
+        if (dry) return PUNET_OK;
+        if (c.cin <= SMALL_CIN)
+            return punet_conv3x3_small_wgrad(x->t, c.cin, dz, c.cout, dw, db, ws_wgrad, x->B, x->H, x->W, accumulate, 1.f, stream);
+        const int ns = punet_wgrad_x6_slices(x->C, c.cout, x->B, x->H, x->W);
+        return punet_conv_wgrad_x6(x->t, x->C, dz, c.cout, dw, c.cin, ci_off, with_bias ? db : nullptr, ws_wgrad, ns, x->B, x->H, x->W,
+                                   accumulate, 1.f, X6_OPTS, stream);
+    }
+
+    int backward_tape(std::vector<Op>& tape, int accumulate) {
+        for (size_t i = tape.size(); i-- > 0;) {
+            Op& op = tape[i];
+            if (op.kind == 0) {
+                const Conv& c = rt->convs[op.conv];
+                const float* dz = op.y->grad;
+                if (!dz && !dry) {
+                    punet_set_error("punet_rt: no gradient reached %s", c.name.c_str());
+                    return PUNET_ERR_ARG;
+                }
+                RT_CALL(wgrad(c, op.x0, 0, dz, true, accumulate));
+                if (op.x1) RT_CALL(wgrad(c, op.x1, op.x0->C, dz, false, accumulate));
+                int off = 0;
+                for (Act* src : {op.x0, op.x1}) {
+                    if (!src) continue;
+                    if (src->needs_grad) {
+                        int acc = 0;
+                        float* g = grad_into(src, &acc);
+                        const float* mask = src->relu_out ? src->t : nullptr;
+                        const bool use_bits = src->bits && mask;
+                        RT_LAUNCH(punet_conv3x3_x6_gated(dz, c.cout, nullptr, 0, planes1 + 3 * c.w_off, c.w_numel(), c.cin, off, nullptr, 0, g,
+                                                       src->C, use_bits ? nullptr : mask, use_bits ? src->bits : nullptr, nullptr, acc, 0,
+                                                       src->B, src->H, src->W, X6_OPTS, stream));
+                    }
+                    off += src->C;
+                }
+            } else if (op.kind == 1) {
+                int acc = 0;
+                float* g = grad_into(op.x0, &acc);
+                const void* bits = (op.x0->relu_out && op.x0->bits) ? op.x0->bits : nullptr;
+                RT_LAUNCH(punet_pool2x2_bwd_gated(op.y->grad, (op.x0->relu_out && !bits) ? op.x0->t : nullptr, bits, g, op.x0->B, op.x0->H,
+                                                op.x0->W, op.x0->C, acc, stream));
+            } else {
+                int acc = 0;
+                float* g = grad_into(op.x0, &acc);
+                const void* bits = (op.x0->relu_out && op.x0->bits) ? op.x0->bits : nullptr;
+                RT_LAUNCH(punet_upsample2x_bwd_gated(op.y->grad, (op.x0->relu_out && !bits) ? op.x0->t : nullptr, bits, g, op.x0->B, op.x0->H,
+                                                   op.x0->W, op.x0->C, stream));
+            }
+        }
+        return PUNET_OK;
+    }
+};
+
+size_t max_wgrad_ws_floats(const PunetRt* rt, int B, int H, int W) {
+    // the largest split-K slab workspace any weight gradient of one pass needs: every 3x3 layer at the level it runs at, a concat
+    // convolution once per source (its sources are reduced one at a time)
+    size_t m = 0;
+    auto one = [&](const Conv& c, int cs, int lv) {
+        const int h = H >> lv, w = W >> lv;
+        size_t v;
+        if (c.cin <= SMALL_CIN) {
+            v = punet_small_wgrad_workspace_floats(c.cin, c.cout);
+        } else {
+            const int ns = punet_wgrad_x6_slices(cs, c.cout, B, h, w);
+            v = punet_wgrad_workspace_floats(cs, c.cout, 3, ns);
+        }
+        m = v > m ? v : m;
+    };
+    const int n = rt->cfg.levels;
+    for (const auto* blocks : {&rt->unet_down, &rt->enc_prior, &rt->enc_post})
+        for (int i = 0; i < n; ++i)
+            for (int ci : (*blocks)[i]) one(rt->convs[ci], rt->convs[ci].cin, i);
+    for (int j = 0; j < (int)rt->unet_up.size(); ++j) {
+        const int lv = n - 2 - j;
+        const Conv& c0 = rt->convs[rt->unet_up[j][0]];
+        const int bridge = rt->cfg.num_filters[lv];
+        one(c0, c0.cin - bridge, lv);  // the up-sampled source
+        one(c0, bridge, lv);           // the bridge
+        one(rt->convs[rt->unet_up[j][1]], rt->convs[rt->unet_up[j][1]].cin, lv);
+        one(rt->convs[rt->unet_up[j][2]], rt->convs[rt->unet_up[j][2]].cin, lv);
+    }
+    return m;
+}
+
+}  // namespace
+
+extern "C" int punet_rt_create(const PunetRtConfig* cfg, PunetRt** out) {
+    PUNET_CHECK_ARG(cfg && out, "punet_rt_create: null pointer");
+    const int n = cfg->levels;
+    PUNET_CHECK_ARG(n >= 2 && n <= 8, "punet_rt_create: levels must be 2..8 (got %d)", n);
+    PUNET_CHECK_ARG(cfg->num_classes == 1, "punet_rt_create: the native runtime covers num_classes = 1 (got %d); use the per-op ABI", cfg->num_classes);
+    PUNET_CHECK_ARG(cfg->input_channels >= 1 && cfg->input_channels + 1 <= SMALL_CIN, "punet_rt_create: input_channels + 1 must be <= %d", SMALL_CIN);
+    PUNET_CHECK_ARG(cfg->num_filters[0] == 32 || cfg->num_filters[0] == 64, "punet_rt_create: num_filters[0] must be 32 or 64 (the fused Fcomb kernels)");
+    PUNET_CHECK_ARG(cfg->no_convs_fcomb == 2 || cfg->no_convs_fcomb == 3, "punet_rt_create: no_convs_fcomb must be 2 or 3");
+    PUNET_CHECK_ARG(cfg->latent_dim >= 1 && cfg->latent_dim <= 64, "punet_rt_create: latent_dim out of range");
+    for (int i = 0; i < n; ++i) PUNET_CHECK_ARG(cfg->num_filters[i] >= 8 && cfg->num_filters[i] % 8 == 0, "punet_rt_create: num_filters must be multiples of 8");
+    PunetRt* rt = new PunetRt();
+    rt->cfg = *cfg;
+    const int* nf = cfg->num_filters;
+    char nm[128];
+    for (int i = 0; i < n; ++i) {
+        const int ci = i == 0 ? cfg->input_channels : nf[i - 1], off = i == 0 ? 0 : 1;
+        std::vector<int> blk;
+        for (int k = 0; k < 3; ++k) {
+            snprintf(nm, sizeof nm, "unet.contracting_path.%d.layers.%d", i, off + 2 * k);
+            blk.push_back(add_conv(rt, nm, k == 0 ? ci : nf[i], nf[i], 3));
+        }
+        rt->unet_down.push_back(blk);
+    }
+    int outc = nf[n - 1];
+    for (int j = 0, i = n - 2; i >= 0; --i, ++j) {
+        const int ci = outc + nf[i];
+        outc = nf[i];
+        std::vector<int> blk;
+        for (int k = 0; k < 3; ++k) {
+            snprintf(nm, sizeof nm, "unet.upsampling_path.%d.conv_block.layers.%d", j, 2 * k);
+            blk.push_back(add_conv(rt, nm, k == 0 ? ci : outc, outc, 3));
+        }
+        rt->unet_up.push_back(blk);
+    }
+    const auto idx = encoder_indices(n);
+    for (int which = 0; which < 2; ++which) {
+        const char* net = which == 0 ? "prior" : "posterior";
+        const int extra = which == 0 ? 0 : cfg->num_classes;
+        std::vector<std::vector<int>> blocks;
+        for (int i = 0; i < n; ++i) {
+            const int ci = i == 0 ? cfg->input_channels + extra : nf[i - 1];
+            std::vector<int> blk;
+            for (int k = 0; k < 3; ++k) {
+                snprintf(nm, sizeof nm, "%s.encoder.layers.%d", net, idx[i][k]);
+                blk.push_back(add_conv(rt, nm, k == 0 ? ci : nf[i], nf[i], 3));
+            }
+            blocks.push_back(blk);
+        }
+        snprintf(nm, sizeof nm, "%s.conv_layer", net);
+        const int head = add_conv(rt, nm, nf[n - 1], 2 * cfg->latent_dim, 1);
+        if (which == 0) { rt->enc_prior = blocks; rt->head_prior = head; } else { rt->enc_post = blocks; rt->head_post = head; }
+    }
+    rt->fc1 = add_conv(rt, "fcomb.layers.0", nf[0] + cfg->latent_dim, nf[0], 1);
+    if (cfg->no_convs_fcomb == 3) rt->fcmid = add_conv(rt, "fcomb.layers.2", nf[0], nf[0], 1);
+    rt->fc3 = add_conv(rt, "fcomb.last_layer", nf[0], cfg->num_classes, 1);
+    long off = 0;
+    for (Conv& c : rt->convs) {
+        c.w_off = off;
+        Entry ew; ew.name = c.name + ".weight"; ew.off = off; ew.numel = c.w_numel(); ew.ndim = 4;
+        ew.shape[0] = c.cout; ew.shape[1] = c.cin; ew.shape[2] = c.k; ew.shape[3] = c.k;
+        rt->entries.push_back(ew);
+        off += c.w_numel();
+        c.b_off = off;
+        Entry eb; eb.name = c.name + ".bias"; eb.off = off; eb.numel = c.cout; eb.ndim = 1;
+        eb.shape[0] = c.cout; eb.shape[1] = eb.shape[2] = eb.shape[3] = 0;
+        rt->entries.push_back(eb);
+        off += c.cout;
+        off = (off + 3) / 4 * 4;  // every tensor 16-byte aligned
+    }
+    rt->numel = off;
+    rt->unet_numel = off;
+    for (const Entry& e : rt->entries)
+        if (e.name.compare(0, 5, "unet.") != 0) { rt->unet_numel = e.off; break; }
+    long units = 0;
+    for (const Conv& c : rt->convs)
+        if (c.k == 3 && c.cin > SMALL_CIN) {
+            rt->x6_table.insert(rt->x6_table.end(), {c.w_off, (long)c.cin, (long)c.cout, units});
+            units += c.w_numel() / 8;
+            ++rt->x6_nconv;
+        }
+    rt->x6_table.insert(rt->x6_table.end(), {0, 0, 0, units});
+    rt->x6_units = units;
+    int t = 0;
+    for (const Entry& e : rt->entries) {  // posterior, prior, fcomb.layers (mean_teacher_trainer.py:115-116), chunks of 16384
+        if (e.name.compare(0, 10, "posterior.") == 0 || e.name.compare(0, 6, "prior.") == 0 || e.name.compare(0, 13, "fcomb.layers.") == 0) {
+            for (long s = 0; s < e.numel; s += 16384) {
+                rt->l2_table.insert(rt->l2_table.end(), {e.off + s, e.numel - s < 16384 ? e.numel - s : 16384, (long)t});
+                ++rt->l2_nchunks;
+            }
+            ++t;
+        }
+    }
+    rt->l2_ntensors = t;
+    *out = rt;
+    return PUNET_OK;
+}
+
+extern "C" void punet_rt_destroy(PunetRt* rt) {
+    if (!rt) return;
+    rt->clear_acts();
+    delete rt;
+}
+
+extern "C" long punet_rt_param_floats(const PunetRt* rt) { return rt ? rt->numel : 0; }
+extern "C" long punet_rt_unet_floats(const PunetRt* rt) { return rt ? rt->unet_numel : 0; }
+extern "C" int punet_rt_num_entries(const PunetRt* rt) { return rt ? (int)rt->entries.size() : 0; }
+
+extern "C" int punet_rt_param_entry(const PunetRt* rt, int i, char* name, int cap, long* off, long* numel, int* shape4) {
+    PUNET_CHECK_ARG(rt && i >= 0 && i < (int)rt->entries.size() && name && cap > 0 && off && numel && shape4, "punet_rt_param_entry: bad args");
+    const Entry& e = rt->entries[i];
+    snprintf(name, (size_t)cap, "%s", e.name.c_str());
+    *off = e.off;
+    *numel = e.numel;
+    for (int k = 0; k < 4; ++k) shape4[k] = e.shape[k];
+    return PUNET_OK;
+}
+
+extern "C" size_t punet_rt_tables_bytes(const PunetRt* rt) {
+    return rt ? (rt->x6_table.size() + rt->l2_table.size()) * sizeof(long) + 256 : 0;
+}
+
+extern "C" int punet_rt_init_tables(PunetRt* rt, void* device_tables, void* stream) {
+    PUNET_CHECK_ARG(rt && device_tables, "punet_rt_init_tables: null pointer");
+    long* d = (long*)device_tables;
+    rt->d_x6 = d;
+    rt->d_l2 = d + ((rt->x6_table.size() + 31) / 32) * 32;
+    if (hipMemcpyAsync(rt->d_x6, rt->x6_table.data(), rt->x6_table.size() * sizeof(long), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
+        hipMemcpyAsync(rt->d_l2, rt->l2_table.data(), rt->l2_table.size() * sizeof(long), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+        punet_set_error("punet_rt_init_tables: copy failed");
+        return PUNET_ERR_HIP;
+    }
+    return PUNET_OK;
+}
+
+// forward(patch, None, training=False) (probabilistic_unet.py:292-293) + N x sigmoid(sample()) + thresholds + stack / sum
+// (mean_teacher_trainer.py:72-88, fixmatch_trainer.py:37-54, punet_predictions.py:29-33): y = mean sigmoid, z = consensus
+// (masking != 0: its == 1 indicator), logits[N][B][H][W] optional.  x: [B][H][W][C] fp32 (NHWC), eps: [N][B][latent].
+static int pseudo_labels_body(PunetRt* rt, const float* flat, const float* x, int B, int H, int W, const float* eps, int N, float upper,
+                              float lower, int masking, float* y, float* z, float* logits, Arena& ar, bool dry, void* stream) {
+    rt->clear_acts();
+    Pass p{rt, flat, nullptr, &ar, stream};
+    p.dry = dry;
+    const int n = rt->cfg.levels, CH = rt->cfg.num_filters[0], L = rt->cfg.latent_dim, nmid = rt->cfg.no_convs_fcomb - 2;
+    p.ws_chan = ar.floats(punet_chan_sum_workspace_floats(B, H * W, rt->cfg.num_filters[n - 1]));
+    Act* xin = rt->new_act(const_cast<float*>(x), B, H, W, rt->cfg.input_channels, false, false);
+    float* zs = ar.floats((size_t)N * B * L);
+    float* zb = ar.floats((size_t)N * B * CH);
+    RT_CALL(p.split(0, &p.planes0));
+    float *muls = nullptr, *mean = nullptr;
+    Act *enc = nullptr, *feat = nullptr;
+    RT_CALL(p.latent(rt->enc_prior, rt->head_prior, xin, nullptr, &muls, &mean, &enc));
+    RT_CALL(p.unet(xin, nullptr, &feat));
+    if (dry) return PUNET_OK;
+    const Conv &c1 = rt->convs[rt->fc1], &c3 = rt->convs[rt->fc3];
+    RT_CALL(punet_reparam(muls, eps, zs, N, B, L, stream));
+    RT_CALL(punet_fcomb_zbias(zs, p.w(c1), p.b(c1), zb, N * B, L, CH, stream));
+    const float* wmid = nmid ? p.w(rt->convs[rt->fcmid]) : nullptr;
+    const float* bmid = nmid ? p.b(rt->convs[rt->fcmid]) : nullptr;
+    return punet_fcomb_sample_x6(feat->t, p.w(c1), zb, wmid, 0, bmid, 0, p.w(c3), p.b(c3), y, z, logits, N, B, H * W, CH, nmid, upper, lower,
+                                 masking, stream);
+}
+
+static char* const DRY_BASE = (char*)(uintptr_t)4096;  // a dry pass never dereferences what it carves
+
+extern "C" int punet_rt_pseudo_labels(PunetRt* rt, const float* flat, const float* x, int B, int H, int W, const float* eps, int N, float upper,
+                                      float lower, int masking, float* y, float* z, float* logits, void* arena, size_t arena_bytes,
+                                      void* stream) {
+    PUNET_CHECK_ARG(rt && flat && x && eps && arena && (y || logits) && (!y == !z), "punet_rt_pseudo_labels: null pointer");
+    PUNET_CHECK_ARG(rt->d_x6, "punet_rt_pseudo_labels: punet_rt_init_tables has not run");
+    PUNET_CHECK_ARG(B > 0 && N > 0 && (H * W) % 32 == 0, "punet_rt_pseudo_labels: bad shape (H * W must be a multiple of 32)");
+    Arena dry{DRY_BASE, (size_t)-1};  // first walk: sizes only, nothing is launched
+    RT_CALL(pseudo_labels_body(rt, flat, x, B, H, W, eps, N, upper, lower, masking, y, z, logits, dry, true, stream));
+    PUNET_CHECK_ARG(dry.used <= arena_bytes, "punet_rt_pseudo_labels: the arena holds %zu bytes, this call needs %zu (punet_rt_arena_bytes)",
+                    arena_bytes, dry.used);
+    Arena ar{(char*)arena, arena_bytes};
+    const int rc = pseudo_labels_body(rt, flat, x, B, H, W, eps, N, upper, lower, masking, y, z, logits, ar, false, stream);
+    rt->last_arena_used = ar.used;
+    return rc;
+}
+
+// forward(patch, segm, training=True); elbo(segm, consm) with the BCE criterion (probabilistic_unet.py:285-293, 341-371) and the
+// gradient of gscale * (reconstruction_loss + beta * kl) w.r.t. every parameter into gflat (written, or accumulated when
+// accumulate != 0).  target = segm (the posterior's input AND the criterion's target, as in every reference trainer), consm nullable,
+// eps: [B][latent].  rec_out / kl_out: device scalars.  after_unet(ctx) (nullable) is called on the host once the U-Net's slice
+// [0, punet_rt_unet_floats) of gflat is final and enqueued - a data-parallel caller starts that slice's all-reduce there.
+static int elbo_body(PunetRt* rt, const float* flat, float* gflat, const float* x, const float* target, const float* consm, const float* eps,
+                     int B, int H, int W, float beta, float gscale, int accumulate, float* rec_out, float* kl_out, float* logits_out,
+                     void (*after_unet)(void*), void* ctx, Arena& ar, bool dry, void* stream) {
+    const int n = rt->cfg.levels, CH = rt->cfg.num_filters[0], L = rt->cfg.latent_dim, nmid = rt->cfg.no_convs_fcomb - 2;
+    const int C = rt->cfg.input_channels;
+    rt->clear_acts();
+    Pass p{rt, flat, gflat, &ar, stream};
+    p.dry = dry;
+    p.ws_chan = ar.floats(punet_chan_sum_workspace_floats(B, H * W, rt->cfg.num_filters[n - 1] > CH ? rt->cfg.num_filters[n - 1] : CH));
+    p.ws_wgrad = ar.floats(max_wgrad_ws_floats(rt, B, H, W));
+    // ---- forward: posterior on [patch, segm], prior, U-Net (tapes recorded)
+    RT_CALL(p.split(0, &p.planes0));
+    Act* xin = rt->new_act(const_cast<float*>(x), B, H, W, C, false, false);
+    Act* xq = rt->new_act(ar.floats((size_t)B * H * W * (C + 1)), B, H, W, C + 1, false, false);
+    if (!dry) RT_CALL(punet_concat_nhwc(x, C, target, 1, xq->t, (long)B * H * W, stream));
+    std::vector<Op> tq, tp, tu;
+    float *muls_q, *mean_q, *muls_p, *mean_p;
+    Act *enc_q, *enc_p, *feat;
+    RT_CALL(p.latent(rt->enc_post, rt->head_post, xq, &tq, &muls_q, &mean_q, &enc_q));
+    RT_CALL(p.latent(rt->enc_prior, rt->head_prior, xin, &tp, &muls_p, &mean_p, &enc_p));
+    RT_CALL(p.unet(xin, &tu, &feat));
+    // ---- elbo head: z = posterior.rsample(), KL, Fcomb + BCE + Fcomb backward in one kernel
+    const Conv &c1 = rt->convs[rt->fc1], &c3 = rt->convs[rt->fc3];
+    const Conv* cm = nmid ? &rt->convs[rt->fcmid] : nullptr;
+    float* zq = ar.floats((size_t)B * L);
+    float* kl_rows = ar.floats(B);
+    float* zb = ar.floats((size_t)B * CH);
+    float* ws_f = ar.floats(punet_fcomb_train_workspace_floats(B, H * W, CH, nmid));
+    float* logits = logits_out ? logits_out : ar.floats((size_t)B * H * W);
+    float* dfeat = ar.floats((size_t)B * H * W * CH);
+    float* S = ar.floats((size_t)B * CH);
+    float* dz = ar.floats((size_t)B * L);
+    float* dq = ar.floats((size_t)B * 2 * L);
+    float* dp = ar.floats((size_t)B * 2 * L);
+    float* dmean = ar.floats((size_t)B * rt->cfg.num_filters[n - 1]);
+    if (!dry) {
+        RT_CALL(punet_reparam(muls_q, eps, zq, 1, B, L, stream));
+        RT_CALL(punet_latent_kl_rows(muls_q, muls_p, nullptr, kl_rows, kl_out, B, L, stream));
+        RT_CALL(punet_fcomb_zbias(zq, p.w(c1), p.b(c1), zb, B, L, CH, stream));
+        RT_CALL(punet_fcomb_train_fwd_bwd(feat->t, p.w(c1), zb, cm ? p.w(*cm) : nullptr, cm ? p.b(*cm) : nullptr, p.w(c3), p.b(c3), target,
+                                          consm, gscale, logits, dfeat, rec_out, ws_f, B, H * W, CH, nmid, stream));
+    }
+    // ---- backward
+    RT_CALL(p.split(1, &p.planes1));
+    if (!dry) {
+        RT_CALL(punet_fcomb_train_reduce(ws_f, gflat + c1.w_off, c1.cin, gflat + c1.b_off, cm ? gflat + cm->w_off : nullptr,
+                                         cm ? gflat + cm->b_off : nullptr, gflat + c3.w_off, gflat + c3.b_off, S, p.ws_chan, B, H * W, CH,
+                                         nmid, accumulate, stream));
+        RT_CALL(punet_fcomb_z_bwd(S, zq, p.w(c1), gflat + c1.w_off, dz, B, L, CH, accumulate, stream));
+    }
+    feat->grad = dfeat;
+    RT_CALL(p.backward_tape(tu, accumulate));
+    if (after_unet && !dry) after_unet(ctx);
+    if (!dry)
+        RT_CALL(punet_latent_kl_bwd_ex(muls_q, muls_p, eps, dz, gscale * beta / (float)B, 0, 0, dq, dp, B, L, stream));
+    for (int which = 0; which < 2; ++which) {  // posterior first, then prior (the order of engine.py)
+        const Conv& ch = rt->convs[which == 0 ? rt->head_post : rt->head_prior];
+        Act* enc = which == 0 ? enc_q : enc_p;
+        int acc = 0;
+        float* denc = p.grad_into(enc, &acc);
+        if (!dry)
+            RT_CALL(punet_latent_head_bwd(which == 0 ? dq : dp, which == 0 ? mean_q : mean_p, p.w(ch), enc->t, gflat + ch.w_off,
+                                          gflat + ch.b_off, dmean, denc, B, enc->H * enc->W, enc->C, ch.cout, accumulate, stream));
+        RT_CALL(p.backward_tape(which == 0 ? tq : tp, accumulate));
+    }
+    return PUNET_OK;
+}
+
+extern "C" int punet_rt_elbo_fwd_bwd(PunetRt* rt, const float* flat, float* gflat, const float* x, const float* target, const float* consm,
+                                     const float* eps, int B, int H, int W, float beta, float gscale, int accumulate, float* rec_out,
+                                     float* kl_out, float* logits_out, void (*after_unet)(void*), void* ctx, void* arena, size_t arena_bytes,
+                                     void* stream) {
+    PUNET_CHECK_ARG(rt && flat && gflat && x && target && eps && rec_out && kl_out && arena, "punet_rt_elbo_fwd_bwd: null pointer");
+    PUNET_CHECK_ARG(rt->d_x6, "punet_rt_elbo_fwd_bwd: punet_rt_init_tables has not run");
+    PUNET_CHECK_ARG(B > 0 && punet_fcomb_train_supported(rt->cfg.num_filters[0], rt->cfg.no_convs_fcomb - 2, H * W),
+                    "punet_rt_elbo_fwd_bwd: H * W must be a multiple of 32");
+    Arena dry{DRY_BASE, (size_t)-1};  // first walk: sizes only, nothing is launched, the callback is not called
+    RT_CALL(elbo_body(rt, flat, gflat, x, target, consm, eps, B, H, W, beta, gscale, accumulate, rec_out, kl_out, logits_out, after_unet, ctx,
+                      dry, true, stream));
+    PUNET_CHECK_ARG(dry.used <= arena_bytes, "punet_rt_elbo_fwd_bwd: the arena holds %zu bytes, this call needs %zu (punet_rt_arena_bytes)",
+                    arena_bytes, dry.used);
+    Arena ar{(char*)arena, arena_bytes};
+    const int rc = elbo_body(rt, flat, gflat, x, target, consm, eps, B, H, W, beta, gscale, accumulate, rec_out, kl_out, logits_out, after_unet,
+                             ctx, ar, false, stream);
+    rt->last_arena_used = ar.used;
+    return rc;
+}
+
+// EXACT bytes the corresponding call carves out of its arena (a dry walk of the same graph): training != 0: punet_rt_elbo_fwd_bwd,
+// else punet_rt_pseudo_labels with N samples
+extern "C" size_t punet_rt_arena_bytes(PunetRt* rt, int B, int H, int W, int N, int training) {
+    if (!rt || B <= 0 || H <= 0 || W <= 0) return 0;
+    Arena dry{DRY_BASE, (size_t)-1};
+    const float* f = (const float*)DRY_BASE;
+    float* g = (float*)DRY_BASE;
+    const int rc = training ? elbo_body(rt, f, g, f, f, nullptr, f, B, H, W, 1.f, 1.f, 0, g, g, nullptr, nullptr, nullptr, dry, true, nullptr)
+                            : pseudo_labels_body(rt, f, f, B, H, W, f, N > 0 ? N : 1, 0.9f, 0.1f, 0, g, g, nullptr, dry, true, nullptr);
+    return rc == PUNET_OK ? dry.used + 256 : 0;
+}
+
+// bytes the last punet_rt_pseudo_labels / punet_rt_elbo_fwd_bwd call carved out of its arena (diagnostic: compare with the bound)
+extern "C" size_t punet_rt_last_arena_used(const PunetRt* rt) { return rt ? rt->last_arena_used : 0; }
+
+// reg_out[0] = l2_regularisation(posterior) + (prior) + (fcomb.layers) (utils.py:32-40: un-squared 2-norms, biases included) and
+// gflat += coef * d reg / d theta (mean_teacher_trainer.py:115-117)
+extern "C" int punet_rt_l2_reg_grad(PunetRt* rt, const float* flat, float* gflat, float coef, float* reg_out, void* arena, size_t arena_bytes,
+                                    void* stream) {
+    PUNET_CHECK_ARG(rt && flat && reg_out && arena && rt->d_l2, "punet_rt_l2_reg_grad: null pointer / tables not initialised");
+    Arena ar{(char*)arena, arena_bytes};
+    float* partial = ar.floats(rt->l2_nchunks);
+    float* norms = ar.floats(rt->l2_ntensors);
+    PUNET_CHECK_ARG(ar.used <= arena_bytes, "punet_rt_l2_reg_grad: arena too small (%zu bytes needed)", ar.used);
+    RT_CALL(punet_l2_reg(flat, (const int64_t*)rt->d_l2, rt->l2_nchunks, rt->l2_ntensors, partial, norms, reg_out, stream));
+    if (gflat) RT_CALL(punet_l2_reg_add_grad(flat, gflat, (const int64_t*)rt->d_l2, rt->l2_nchunks, norms, coef, stream));
+    return PUNET_OK;
+}

@@ -141,6 +141,18 @@ class ProbabilisticUnet(nn.Module):
                     nn.init.trunc_normal_(b, std=0.001, a=-0.002, b=0.002, generator=g)
                     v.copy_(b)
 
+    def native_runtime(self):
+        """The step-level native runtime of this model's configuration (runtime.NativeRuntime: the graph walk as host code
+        inside libpunet_hip.so), created on first use; raises ValueError outside its domain (num_classes 1, num_filters[0] in
+        {32, 64}, no_convs_fcomb 2 or 3) and for arithmetics other than the parity default."""
+        rt = getattr(self, "_native_rt", None)
+        if rt is None:
+            from ..runtime import NativeRuntime
+            if self.engine.conv_mode != "x6":
+                raise ValueError("the native runtime computes in the parity arithmetic (conv_mode 'x6')")
+            rt = self._native_rt = NativeRuntime(self.layout, self.device)
+        return rt
+
     def set_conv_mode(self, conv_mode: str):
         """Switch the 3x3 conv arithmetic of this model (engine.PUNetEngine: "x6" parity default, "f32", or a fast mode -
         "f16x3", "f16", "x3", "bf16", "bf16s").  The engine holds no weights, so a new one is built; cached forward state is

@@ -222,6 +222,43 @@ def allreduce_grads(gflat: torch.Tensor, started: Optional[dict] = None) -> floa
     return 1.0 / w
 
 
+def native_ok(*models) -> bool:
+    """May the fused steps hand the graph walk to the step-level native runtime (csrc/runtime.hip)?  Yes for the configuration
+    class it covers (runtime.supported), the parity arithmetic, the BCE criterion and the default kernel selection; $PUNET_RUNTIME
+    = python keeps the Python engine (the two enqueue the same kernels in the same order and give the same bits)."""
+    import os
+    from ..runtime import supported
+    if os.environ.get("PUNET_RUNTIME", "native") == "python":
+        return False
+    for m in models:
+        e = m.engine
+        if not (supported(m.layout) and e.conv_mode == "x6" and not m.rl_swap and e.fuse_fcomb and e.fuse_pool and e.sampler_x6
+                and e.prof is None and e.x6_opts == 6 | (16 << 8)):
+            return False
+    return True
+
+
+def _dp_hook(gflat, n, started):
+    """after_unet callback of a data-parallel gradient pass: start the all-reduce of the U-Net slice gflat[:n] asynchronously
+    (eagerly between graph segments while a step is being captured)."""
+    if _world() == 1:
+        return None
+
+    def launch():
+        t0 = time.perf_counter() if COMM_HOST_S is not None else 0.0
+        started["work"] = dist.all_reduce(gflat[:n], op=dist.ReduceOp.SUM, async_op=True)
+        if COMM_HOST_S is not None:
+            COMM_HOST_S[0] += time.perf_counter() - t0
+
+    def hook():
+        started["numel"] = n
+        if _CAPTURE is not None:
+            _CAPTURE.cut(launch)
+        else:
+            launch()
+    return hook
+
+
 def pseudo_labels(net: ProbabilisticUnet, x1, n_samples: int, masking: bool, eps=None, upper=0.9, lower=0.1):
     """sample_from_teacher / sample_from_weak_model (mean_teacher_trainer.py:72-88, fixmatch_trainer.py:37-54), fused:
     forward(x1, None, False) then K7.  Returns float [B,1,H,W] tensors (y soft mean, z consensus)."""
@@ -268,6 +305,8 @@ def elbo_grad_pass(model: ProbabilisticUnet, gflat, x, y, z, eps, gscale: float,
 
 def fused_supervised_step(model, opt: FusedAdam, x, y, z=None, eps=None, reg_weight=1e-5):
     """PUNetTrainer / PseudoTrainerPUNet iteration (punet_trainer.py:24-36, punet_target_trainer.py:105-118)."""
+    if native_ok(model):
+        return fused_supervised_step_native(model, opt, x, y, z, eps, reg_weight)
     eng = model.engine
     rec, kl, st = elbo_grad_pass(model, opt.grad_flat, x, y, z, eps, 1.0, False, overlap=True)
     reg, norms = eng.l2_reg(model.flat_params)
@@ -281,6 +320,9 @@ def fused_self_training_step(model, teacher, opt: FusedAdam, x1, x2, n_samples: 
                              momentum: Optional[float] = 0.999, reg_weight=1e-5, source_distribution=None):
     """Mean-Teacher iteration (teacher = EMA copy, mean_teacher_trainer.py:101-131) or FixMatch iteration
     (teacher is the model itself and momentum is None, fixmatch_trainer.py:67-95)."""
+    if native_ok(model, teacher):
+        return fused_self_training_step_native(model, teacher, opt, x1, x2, n_samples, masking, eps_pl, eps_s, momentum, reg_weight,
+                                               source_distribution)
     eng = model.engine
     y, z = pseudo_labels(teacher, x1, n_samples, masking, eps_pl)
     ratio = None
@@ -295,6 +337,75 @@ def fused_self_training_step(model, teacher, opt: FusedAdam, x1, x2, n_samples: 
     return rec + model.beta * kl + reg_weight * reg[0], y, z, ratio
 
 
+def fused_self_training_step_native(model, teacher, opt: FusedAdam, x1, x2, n_samples: int, masking: bool, eps_pl=None, eps_s=None,
+                                    momentum: Optional[float] = 0.999, reg_weight=1e-5, source_distribution=None):
+    """fused_self_training_step with the graph walk done by the step-level native runtime (csrc/runtime.hip): the iteration is
+    FOUR library calls - pseudo-labels, ELBO forward / backward, regulariser, Adam + EMA - instead of ~500 per-op calls issued
+    from Python.  Same kernels in the same order: bit-identical to the Python-engine step (tests/test_gpu_runtime.py)."""
+    rt = model.native_runtime()
+    eng = model.engine
+    B = x1.shape[0]
+    with torch.no_grad():
+        y, z = rt.pseudo_labels(teacher.flat_params, eng.to_nhwc(x1), teacher._eps(n_samples, B, eps_pl), 0.9, 0.1, masking)
+    ratio = None
+    if source_distribution is not None:
+        y, ratio = distribution_alignment(y, source_distribution, eng)
+    cm = z if model.consensus_masking is True else None
+    started = {}
+    rec, kl = rt.elbo_fwd_bwd(model.flat_params, opt.grad_flat, eng.to_nhwc(x2), y, cm, model._eps(1, B, eps_s)[0], model.beta, 1.0,
+                              False, after_unet=_dp_hook(opt.grad_flat, model.layout.unet_numel, started))
+    reg = rt.l2_reg_grad(model.flat_params, opt.grad_flat, reg_weight)
+    scale = allreduce_grads(opt.grad_flat, started)
+    do_ema = momentum is not None and teacher is not model and bool(opt.lr)
+    opt.fused_step(teacher if do_ema else None, ema_momentum=momentum if do_ema else 0.0, grad_scale=scale)
+    return rec[0] + model.beta * kl[0] + reg_weight * reg[0], y, z, ratio
+
+
+def fused_supervised_step_native(model, opt: FusedAdam, x, y, z=None, eps=None, reg_weight=1e-5):
+    """fused_supervised_step through the native runtime (PUNetTrainer / PseudoTrainerPUNet iteration)."""
+    rt = model.native_runtime()
+    eng = model.engine
+    xn = eng.to_nhwc(x)
+    B, H, W = xn.shape[0], xn.shape[1], xn.shape[2]
+    yt = y.to(device=model.device, dtype=torch.float32).reshape(B, 1, H, W).contiguous()
+    cm = None
+    if model.consensus_masking is True and z is not None:
+        cm = z.to(device=model.device, dtype=torch.float32).reshape(B, 1, H, W).contiguous()
+    started = {}
+    rec, kl = rt.elbo_fwd_bwd(model.flat_params, opt.grad_flat, xn, yt, cm, model._eps(1, B, eps)[0], model.beta, 1.0, False,
+                              after_unet=_dp_hook(opt.grad_flat, model.layout.unet_numel, started))
+    reg = rt.l2_reg_grad(model.flat_params, opt.grad_flat, reg_weight)
+    scale = allreduce_grads(opt.grad_flat, started)
+    opt.fused_step(None, grad_scale=scale)
+    return rec[0] + model.beta * kl[0] + reg_weight * reg[0]
+
+
+def fused_joint_step_native(model, teacher, opt: FusedAdam, xs, ys, xt1, xt2, n_samples: int, masking: bool, eps_sup=None,
+                            eps_pl=None, eps_s=None, momentum: Optional[float] = None, use_consensus=True, reg_weight=1e-5,
+                            warmup_iteration: Optional[int] = None):
+    """fused_joint_step (AdaMT / AdaMatch) through the native runtime: two gradient passes at scale 0.5 accumulate."""
+    rt = model.native_runtime()
+    eng = model.engine
+    xsn = eng.to_nhwc(xs)
+    Bs, H, W = xsn.shape[0], xsn.shape[1], xsn.shape[2]
+    yst = ys.to(device=model.device, dtype=torch.float32).reshape(Bs, 1, H, W).contiguous()
+    rec_s, kl_s = rt.elbo_fwd_bwd(model.flat_params, opt.grad_flat, xsn, yst, None, model._eps(1, Bs, eps_sup)[0], model.beta, 0.5, False)
+    B = xt1.shape[0]
+    with torch.no_grad():
+        y, z = rt.pseudo_labels(teacher.flat_params, eng.to_nhwc(xt1), teacher._eps(n_samples, B, eps_pl), 0.9, 0.1, masking)
+    cm = z if (use_consensus and model.consensus_masking is True) else None
+    started = {}
+    rec_t, kl_t = rt.elbo_fwd_bwd(model.flat_params, opt.grad_flat, eng.to_nhwc(xt2), y, cm, model._eps(1, B, eps_s)[0], model.beta, 0.5,
+                                  True, after_unet=_dp_hook(opt.grad_flat, model.layout.unet_numel, started))
+    reg = rt.l2_reg_grad(model.flat_params, opt.grad_flat, reg_weight)  # (reg + reg) / 2
+    scale = allreduce_grads(opt.grad_flat, started)
+    ema = momentum is not None and teacher is not model
+    opt.fused_step(teacher if ema else None, ema_momentum=momentum if ema else 0.0, grad_scale=scale,
+                   warmup_iteration=warmup_iteration if ema else None)
+    loss = 0.5 * (rec_s[0] + model.beta * kl_s[0] + rec_t[0] + model.beta * kl_t[0]) + reg_weight * reg[0]
+    return loss, y, z
+
+
 def fused_joint_step(model, teacher, opt: FusedAdam, xs, ys, xt1, xt2, n_samples: int, masking: bool, eps_sup=None,
                      eps_pl=None, eps_s=None, momentum: Optional[float] = None, use_consensus=True, reg_weight=1e-5,
                      warmup_iteration: Optional[int] = None):
@@ -302,6 +413,9 @@ def fused_joint_step(model, teacher, opt: FusedAdam, xs, ys, xt1, xt2, n_samples
     loss = (supervised + target) / 2 with ONE optimizer step; two gradient passes at scale 0.5 accumulate.
     momentum = the EMA momentum (cap); warmup_iteration = the trainer's iteration `it` for AdaMT's rule
     min(1 - 1/(it + 1), momentum) (adamt_trainer.py:41), evaluated on the device."""
+    if native_ok(model, teacher):
+        return fused_joint_step_native(model, teacher, opt, xs, ys, xt1, xt2, n_samples, masking, eps_sup, eps_pl, eps_s, momentum,
+                                       use_consensus, reg_weight, warmup_iteration)
     eng = model.engine
     rec_s, kl_s, _ = elbo_grad_pass(model, opt.grad_flat, xs, ys, None, eps_sup, 0.5, False)
     y, z = pseudo_labels(teacher, xt1, n_samples, masking, eps_pl)
@@ -353,7 +467,9 @@ class GraphedStep:
         # the capture bakes the engines' workspace pointers into the graph: from here on a workspace that has to grow (an
         # eager call at a larger shape) retires its old buffer instead of freeing it
         from ..engine import Workspace
+        from ..runtime import pin_all as pin_runtime_arenas
         Workspace.pin_all(dev)
+        pin_runtime_arenas(dev)
         if opt is not None:  # the device state block must be current before the capture (no uploads inside a graph)
             opt.sync_device_state(ema_momentum if ema else 0.0, 1.0 / _world(), warmup_iteration if ema else None)
         # (2) capture, cutting at collectives

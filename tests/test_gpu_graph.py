@@ -95,12 +95,14 @@ def test_mean_teacher_graph_equals_eager_with_lr_change(dev):
     assert len(b._graphs) == 1 and a.optimizer.step_count == 5
 
 
-def test_graph_survives_larger_eager_shapes_on_the_same_engine(dev):
+@pytest.mark.parametrize("runtime", ["native", "python"])
+def test_graph_survives_larger_eager_shapes_on_the_same_engine(dev, monkeypatch, runtime):
     """the captured graph holds raw pointers of the engines' grow-only workspaces.  A validation pass with four
     times the pixels and twice the batch makes every workspace grow (the old buffers are retired, not freed), tensors that
     stay alive are allocated meanwhile, and the replay afterwards still equals the eager step bit for bit; a second capture
     at the larger shape works next to the first."""
     from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam, MeanTeacherTrainer
+    monkeypatch.setenv("PUNET_RUNTIME", runtime)  # who walks the graph: the native runtime (its arena) or the Python engine (its workspaces)
     data = _batches(4)
     big = [O.synth_batch(4, 1, 64, 64, 77)]
 
@@ -122,7 +124,9 @@ def test_graph_survives_larger_eager_shapes_on_the_same_engine(dev):
     torch.cuda.synchronize()
     _same(a, b)
     ws = b.model.engine.ws
-    assert ws.pinned and len(ws.retired) > 0  # the small-shape buffers the graph uses were kept
+    assert ws.pinned
+    if runtime == "python":
+        assert len(ws.retired) > 0  # the small-shape buffers the graph uses were kept
     for tr in (a, b):  # a second capture at the larger shape, then the first graph again
         tr.train_loader = big
         tr._train_epoch_impl(_P(), contextlib.nullcontext, None)
@@ -131,6 +135,9 @@ def test_graph_survives_larger_eager_shapes_on_the_same_engine(dev):
     torch.cuda.synchronize()
     _same(a, b)
     assert len(b._graphs) == 2
+    if runtime == "native":  # the second capture needed a larger arena: the first graph's arena was retired, not freed
+        rt = b.model.native_runtime()
+        assert rt.pinned and len(rt._retired) > 0
     for i, t in enumerate(keep[1]):
         assert float(t[0]) == float(i) and float(t[-1]) == float(i)
 

@@ -1,0 +1,143 @@
+"""GPU: the step-level native runtime (csrc/runtime.hip: forward / sample / elbo / backward as native host code behind the C ABI)
+against the Python engine, which enqueues the same kernels in the same order: bit-identical pseudo-labels, logits, loss scalars and
+gradients; a whole Mean-Teacher step driven through four library calls equals the fused Python step; an arena that is too small is
+refused before anything is launched."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import punet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _model(dev, nf, C=1, nfc=3, latent=6, seed=1):
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    m = ProbabilisticUnet(C, 1, nf, latent, nfc, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=0)
+    cfg = O.PUNetConfig(C, 1, nf, latent, nfc, 1.0, consensus_masking=True, rl_swap=False)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in O.synth_params(cfg.spec(), seed).items()})
+    return m
+
+
+@pytest.mark.parametrize("nf,C,nfc,latent,B,H,W", [([32, 64, 64, 96], 1, 3, 6, 2, 32, 64), ([64, 40, 72], 3, 2, 2, 1, 24, 40),
+                                                    ([32, 32, 64, 64, 96], 2, 3, 6, 2, 48, 80)],
+                         ids=["nf4", "depth3_rgb_fcomb2_latent2", "depth5_two_channels"])
+def test_native_runtime_equals_python_engine_bit_for_bit(dev, nf, C, nfc, latent, B, H, W):
+    from probabilistic_domain_adaptation_amd.runtime import NativeRuntime
+    m = _model(dev, nf, C, nfc, latent)
+    eng, flat = m.engine, m.flat_params
+    rt = NativeRuntime(m.layout, dev)
+    assert [e[:3] for e in rt.entries()] == [e[:3] for e in m.layout.entries] and rt.unet_numel == m.layout.unet_numel
+    x, x1, x2, y = [t.to(dev) for t in O.synth_batch(B, C, H, W, 7)]
+    g = torch.Generator().manual_seed(3)
+    n = 4
+    eps_n, eps_s = torch.randn(n, B, latent, generator=g).to(dev), torch.randn(B, latent, generator=g).to(dev)
+    consm = (torch.rand(B, 1, H, W, generator=g) > 0.3).float().to(dev)
+    # ---- teacher / inference path
+    with torch.no_grad():
+        out = eng.forward_features(flat, eng.to_nhwc(x1))
+        ye, ze, le = eng.sample(flat, out["features"], eng.reparam(out["prior_muls"], eps_n), 0.9, 0.1, True, want_logits=True)
+    yr, zr, lr = rt.pseudo_labels(flat, eng.to_nhwc(x1), eps_n, 0.9, 0.1, True, want_logits=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ye, yr) and torch.equal(ze, zr) and torch.equal(le, lr)
+    used = rt_used = None
+    # ---- student path: loss scalars, logits, every gradient; then the accumulate form on top
+    st = eng.elbo_forward(flat, eng.to_nhwc(x2), y, consm, eps_s, "bce", 1.0, 0.5, True)
+    SENT = 12345.678  # (the flat buffer has alignment pads nobody writes: a NaN fill would defeat torch.equal)
+    ge = torch.full_like(flat, SENT)
+    eng.elbo_backward(flat, ge, st, False)
+    gr = torch.full_like(flat, SENT)
+    hits = []
+    rec, kl, lg = rt.elbo_fwd_bwd(flat, gr, eng.to_nhwc(x2), y, consm, eps_s, 1.0, 0.5, False, after_unet=lambda: hits.append(1),
+                                  want_logits=True)
+    torch.cuda.synchronize()
+    assert hits == [1]  # the data-parallel hook fired once (and not in the sizing walk)
+    assert torch.equal(rec, st["rec"]) and torch.equal(kl, st["kl"]) and torch.equal(lg, st["logits"])
+    assert torch.isfinite(gr).all() and torch.equal(ge, gr)
+    for k, v in m.layout.views(gr).items():
+        assert not (v == SENT).any(), k  # every gradient tensor was written
+    eng.elbo_backward(flat, ge, eng.elbo_forward(flat, eng.to_nhwc(x1), y, None, eps_s, "bce", 1.0, 0.5, True), True)
+    rt.elbo_fwd_bwd(flat, gr, eng.to_nhwc(x1), y, None, eps_s, 1.0, 0.5, True)
+    torch.cuda.synchronize()
+    assert torch.equal(ge, gr)
+    # ---- regulariser
+    reg_e, norms = eng.l2_reg(flat)
+    eng.l2_reg_add_grad(flat, ge, norms, 1e-5)
+    reg_r = rt.l2_reg_grad(flat, gr, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(reg_e, reg_r) and torch.equal(ge, gr)
+    # ---- the arena bound is exact, and a smaller arena is refused before anything runs
+    need = rt.arena_bytes(B, H, W, 1, True)
+    from probabilistic_domain_adaptation_amd import _lib
+    assert _lib.call("punet_rt_last_arena_used", rt._h) > 0
+    small = torch.empty(need // 2, dtype=torch.uint8, device=dev)
+    before = gr.clone()
+    with pytest.raises(RuntimeError, match="arena"):
+        rt.elbo_fwd_bwd(flat, gr, eng.to_nhwc(x2), y, consm, eps_s, arena=small)
+    torch.cuda.synchronize()
+    assert torch.equal(before, gr)
+
+
+def test_mean_teacher_step_through_four_library_calls(dev, monkeypatch):
+    """pseudo-labels, ELBO forward / backward, regulariser, Adam + EMA: the fused Python step (my_trainer/fused.py) and the same
+    step driven through the native runtime leave identical weights, teacher and Adam moments."""
+    import copy
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    from probabilistic_domain_adaptation_amd.runtime import NativeRuntime
+    nf, B, H, W, n = [64, 64, 96, 128], 2, 64, 96, 4
+    x, x1, x2, y = [t.to(dev) for t in O.synth_batch(B, 1, H, W, 0)]
+    g = torch.Generator().manual_seed(5)
+    eps_n, eps_s = torch.randn(n, B, 6, generator=g).to(dev), torch.randn(1, B, 6, generator=g).to(dev)
+    res = []
+    for native in (False, True):
+        monkeypatch.setenv("PUNET_RUNTIME", "native" if native else "python")  # the fused steps dispatch on it (FU.native_ok)
+        m = _model(dev, nf)
+        assert FU.native_ok(m) == native
+        t = copy.deepcopy(m)
+        opt = FusedAdam(m, lr=1e-3)
+        for it in range(2):
+            loss, ys, zs, _ = FU.fused_self_training_step(m, t, opt, x1, x2, n, True, eps_pl=eps_n, eps_s=eps_s)
+        torch.cuda.synchronize()
+        res.append((float(loss), m.flat_params.clone(), t.flat_params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), ys.clone(),
+                    zs.clone()))
+    assert np.isfinite(res[0][0]) and res[0][0] == res[1][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert torch.equal(a, b)
+    assert not torch.equal(res[0][1], res[0][2])  # the EMA teacher really differs from the student
+
+
+def test_joint_and_supervised_steps_native_equal_python(dev, monkeypatch):
+    """AdaMT-style joint step (two accumulating gradient passes, warm-up EMA momentum from the device counter) and the supervised
+    step: native runtime == Python engine, bit for bit, over two iterations."""
+    import copy
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    nf, B, H, W, n = [32, 64, 64, 96], 2, 32, 64, 4
+    xs, _, _, ys = [t.to(dev) for t in O.synth_batch(B, 1, H, W, 11)]
+    x, x1, x2, y = [t.to(dev) for t in O.synth_batch(B, 1, H, W, 12)]
+    g = torch.Generator().manual_seed(6)
+    e_sup, e_pl, e_s = torch.randn(1, B, 6, generator=g).to(dev), torch.randn(n, B, 6, generator=g).to(dev), torch.randn(1, B, 6, generator=g).to(dev)
+    res = {}
+    for rtm in ("python", "native"):
+        monkeypatch.setenv("PUNET_RUNTIME", rtm)
+        m = _model(dev, nf)
+        t = copy.deepcopy(m)
+        opt = FusedAdam(m, lr=1e-3)
+        for it in range(2):
+            loss, yy, zz = FU.fused_joint_step(m, t, opt, xs, ys, x1, x2, n, True, e_sup, e_pl, e_s, 0.999, True, 1e-5, it)
+        m2 = _model(dev, nf, seed=2)
+        opt2 = FusedAdam(m2, lr=1e-3)
+        l2 = FU.fused_supervised_step(m2, opt2, x2, y, None, e_s, 1e-5)
+        torch.cuda.synchronize()
+        res[rtm] = (float(loss), m.flat_params.clone(), t.flat_params.clone(), yy.clone(), zz.clone(), float(l2), m2.flat_params.clone())
+    assert res["python"][0] == res["native"][0] and res["python"][5] == res["native"][5]
+    for a, b in zip(res["python"][1:5] + res["python"][6:], res["native"][1:5] + res["native"][6:]):
+        assert torch.equal(a, b)
