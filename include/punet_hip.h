@@ -406,6 +406,22 @@ int punet_rt_elbo_fwd_bwd(PunetRt* rt, const float* flat, float* gflat, const fl
                           void* stream);
 int punet_rt_l2_reg_grad(PunetRt* rt, const float* flat, float* gflat, float coef, float* reg_out, void* arena, size_t arena_bytes,
                          void* stream);
+/* ONE call per self-training iteration (MeanTeacherTrainer._train_epoch_impl, mean_teacher_trainer.py:101-131; FixMatchTrainer with
+ * labeller == student and ema == 0): pseudo-labels from `labeller` on view x1, ELBO forward / backward of `student` on view x2,
+ * regulariser, Adam with the EMA of the teacher fused in.  hstate / hyper: the device state block of punet_adam_hyper (lr, step
+ * count, EMA rule, gradient scale 1 / world_size live there).  scalars[3] (device) = {reconstruction loss, kl, reg};
+ * loss = scalars[0] + beta * scalars[1] + reg_weight * scalars[2].  hooks (nullable) let a data-parallel host enqueue its
+ * all-reduces: after_unet - the slice [0, punet_rt_unet_floats) of gflat is final and enqueued; before_update - all of it is. */
+typedef struct {
+    void (*after_unet)(void* ctx);
+    void (*before_update)(void* ctx);
+    void* ctx;
+} PunetRtHooks;
+int punet_rt_self_training_step(PunetRt* rt, float* student, float* labeller, float* gflat, float* exp_avg, float* exp_avg_sq,
+                                double* hstate, float* hyper, int ema, const float* x1, const float* x2, int B, int H, int W,
+                                const float* eps_pl, int N, const float* eps_s, float upper, float lower, int masking, int use_consensus,
+                                float beta, float reg_weight, float adam_beta1, float adam_beta2, float adam_eps, float* y, float* z,
+                                float* scalars, const PunetRtHooks* hooks, void* arena, size_t arena_bytes, void* stream);
 
 #ifdef __cplusplus
 }

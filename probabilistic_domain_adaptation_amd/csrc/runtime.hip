@@ -649,3 +649,28 @@ extern "C" int punet_rt_l2_reg_grad(PunetRt* rt, const float* flat, float* gflat
     if (gflat) RT_CALL(punet_l2_reg_add_grad(flat, gflat, (const int64_t*)rt->d_l2, rt->l2_nchunks, norms, coef, stream));
     return PUNET_OK;
 }
+
+// ONE call per self-training iteration (mean_teacher_trainer.py:101-131; fixmatch_trainer.py:67-95 with labeller == student and
+// ema == 0): pseudo-labels from `labeller` on view x1, ELBO forward / backward of `student` on view x2 against them (consensus z as
+// criterion mask when use_consensus != 0), regulariser, Adam on the flat buffers with the EMA of the teacher fused in (ema != 0:
+// labeller is updated as the student's EMA).  hstate / hyper: the device state block of punet_adam_hyper (the host keeps lr, step
+// count, EMA rule and the gradient scale 1 / world_size there).  scalars[3] = {reconstruction loss, kl, reg} (device);
+// loss = scalars[0] + beta * scalars[1] + reg_weight * scalars[2].  hooks (nullable): after_unet = the U-Net slice of gflat is
+// final and enqueued; before_update = all of gflat is - a data-parallel host enqueues its all-reduces there.
+extern "C" int punet_rt_self_training_step(PunetRt* rt, float* student, float* labeller, float* gflat, float* exp_avg, float* exp_avg_sq,
+                                           double* hstate, float* hyper, int ema, const float* x1, const float* x2, int B, int H, int W,
+                                           const float* eps_pl, int N, const float* eps_s, float upper, float lower, int masking,
+                                           int use_consensus, float beta, float reg_weight, float adam_beta1, float adam_beta2,
+                                           float adam_eps, float* y, float* z, float* scalars, const PunetRtHooks* hooks, void* arena,
+                                           size_t arena_bytes, void* stream) {
+    PUNET_CHECK_ARG(rt && student && labeller && gflat && exp_avg && exp_avg_sq && hstate && hyper && x1 && x2 && eps_pl && eps_s && y && z &&
+                        scalars && arena, "punet_rt_self_training_step: null pointer");
+    RT_CALL(punet_rt_pseudo_labels(rt, labeller, x1, B, H, W, eps_pl, N, upper, lower, masking, y, z, nullptr, arena, arena_bytes, stream));
+    RT_CALL(punet_rt_elbo_fwd_bwd(rt, student, gflat, x2, y, use_consensus ? z : nullptr, eps_s, B, H, W, beta, 1.f, 0, scalars, scalars + 1,
+                                  nullptr, hooks ? hooks->after_unet : nullptr, hooks ? hooks->ctx : nullptr, arena, arena_bytes, stream));
+    RT_CALL(punet_rt_l2_reg_grad(rt, student, gflat, reg_weight, scalars + 2, arena, arena_bytes, stream));
+    if (hooks && hooks->before_update) hooks->before_update(hooks->ctx);
+    RT_CALL(punet_adam_hyper(hstate, hyper, stream));
+    return punet_adam_ema_dev(student, gflat, exp_avg, exp_avg_sq, (ema && labeller != student) ? labeller : nullptr, rt->numel, hyper,
+                              adam_beta1, adam_beta2, adam_eps, stream);
+}

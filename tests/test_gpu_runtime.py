@@ -141,3 +141,42 @@ def test_joint_and_supervised_steps_native_equal_python(dev, monkeypatch):
     assert res["python"][0] == res["native"][0] and res["python"][5] == res["native"][5]
     for a, b in zip(res["python"][1:5] + res["python"][6:], res["native"][1:5] + res["native"][6:]):
         assert torch.equal(a, b)
+
+
+def test_one_call_self_training_step(dev, monkeypatch):
+    """punet_rt_self_training_step - the whole Mean-Teacher iteration as ONE library call (what a non-Python host would issue) -
+    against the fused Python step: same weights, teacher, moments, pseudo-labels and loss scalars after two iterations."""
+    import copy
+    from probabilistic_domain_adaptation_amd import _lib
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    nf, B, H, W, n = [32, 64, 64, 96], 2, 32, 64, 4
+    x, x1, x2, y = [t.to(dev) for t in O.synth_batch(B, 1, H, W, 21)]
+    g = torch.Generator().manual_seed(8)
+    eps_n, eps_s = torch.randn(n, B, 6, generator=g).to(dev), torch.randn(1, B, 6, generator=g).to(dev)
+    monkeypatch.setenv("PUNET_RUNTIME", "python")
+    ma = _model(dev, nf)
+    ta = copy.deepcopy(ma)
+    oa = FusedAdam(ma, lr=1e-3)
+    for it in range(2):
+        la, ya, za, _ = FU.fused_self_training_step(ma, ta, oa, x1, x2, n, True, eps_pl=eps_n, eps_s=eps_s)
+    mb = _model(dev, nf)
+    tb = copy.deepcopy(mb)
+    ob = FusedAdam(mb, lr=1e-3)
+    rt = mb.native_runtime()
+    ar = rt.arena(max(rt.arena_bytes(B, H, W, n, True), rt.arena_bytes(B, H, W, n, False)))
+    yb, zb = torch.empty(B, 1, H, W, device=dev), torch.empty(B, 1, H, W, device=dev)
+    sc = torch.zeros(3, device=dev)
+    eng = mb.engine
+    for it in range(2):
+        want = ob.sync_device_state(0.999, 1.0, None)  # the host's part of the optimizer: the device state block
+        _lib.call("punet_rt_self_training_step", rt._h, mb.flat_params.data_ptr(), tb.flat_params.data_ptr(), ob.grad_flat.data_ptr(),
+                  ob.exp_avg.data_ptr(), ob.exp_avg_sq.data_ptr(), ob.hstate.data_ptr(), ob.hyper.data_ptr(), 1, eng.to_nhwc(x1).data_ptr(),
+                  eng.to_nhwc(x2).data_ptr(), B, H, W, eps_n.data_ptr(), n, eps_s.data_ptr(), 0.9, 0.1, 1, 1, 1.0, 1e-5, 0.9, 0.999, 1e-8,
+                  yb.data_ptr(), zb.data_ptr(), sc.data_ptr(), None, ar.data_ptr(), ar.numel(), torch.cuda.current_stream().cuda_stream)
+        ob._advance_mirrors(want)
+    torch.cuda.synchronize()
+    assert torch.equal(ma.flat_params, mb.flat_params) and torch.equal(ta.flat_params, tb.flat_params)
+    assert torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
+    assert torch.equal(ya, yb) and torch.equal(za, zb)
+    assert float(la) == float(sc[0] + 1.0 * sc[1] + 1e-5 * sc[2])
