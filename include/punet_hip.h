@@ -390,6 +390,9 @@ typedef struct {
 } PunetRtConfig;
 int punet_rt_create(const PunetRtConfig* cfg, PunetRt** out);
 void punet_rt_destroy(PunetRt* rt);
+/* arithmetic of the 3x3 convolutions of every later call: 6 = six-product parity arithmetic (default), 3 = "f16x3", 1 = "f16"
+ * (the fp16-operand fast modes above: amax slots are carved from the arena and handled inside the runtime) */
+int punet_rt_set_arithmetic(PunetRt* rt, int products);
 long punet_rt_param_floats(const PunetRt* rt);
 long punet_rt_unet_floats(const PunetRt* rt); /* [0, this) of the flat buffers = the U-Net's tensors (final first in the backward) */
 int punet_rt_num_entries(const PunetRt* rt);

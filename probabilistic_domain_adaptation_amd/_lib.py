@@ -122,6 +122,7 @@ AFTER_UNET_CB = C.CFUNCTYPE(None, _p)  # void (*after_unet)(void* ctx)
 _SIGS.update({
     "punet_rt_create": (_i, [C.POINTER(PunetRtConfig), C.POINTER(_p)]),
     "punet_rt_destroy": (None, [_p]),
+    "punet_rt_set_arithmetic": (_i, [_p, _i]),
     "punet_rt_param_floats": (_l, [_p]),
     "punet_rt_unet_floats": (_l, [_p]),
     "punet_rt_num_entries": (_i, [_p]),

@@ -31,6 +31,7 @@ struct Conv {
     std::string name;
     int cin, cout, k;
     long w_off, b_off;
+    int x6_index = -1;  // row of the weight-split table (= slot of its amax in the fp16-operand arithmetics)
     long w_numel() const { return (long)k * k * cin * cout; }
 };
 
@@ -47,6 +48,8 @@ struct Act {
     bool relu_out = false, needs_grad = true;
     unsigned* bits = nullptr;
     float* grad = nullptr;  // gradient buffer once one exists (the "gm" map of engine.py)
+    float* amax = nullptr;   // fp16-operand arithmetics: amax slot of t (common.h); gamax: of grad
+    float* gamax = nullptr;
     size_t numel() const { return (size_t)B * H * W * C; }
 };
 
@@ -84,6 +87,7 @@ struct PunetRt {
     int l2_nchunks = 0, l2_ntensors = 0;
     long* d_x6 = nullptr;
     long* d_l2 = nullptr;
+    int f16_planes = 0;  // 0: six-product bf16 parity arithmetic; 2: "f16x3"; 1: "f16" (punet_rt_set_arithmetic)
     // per-call state
     size_t last_arena_used = 0;
     std::vector<Act*> acts;
@@ -145,13 +149,35 @@ struct Pass {  // one forward / backward walk
     float* ws_chan = nullptr;
     bool fuse_pool = true;
     bool dry = false;
+    int f16 = 0;              // fp16 planes per operand (0: bf16 six-product arithmetic)
+    float* wamax = nullptr;   // [nconv] amax slots of the weight slabs
+    float* slots = nullptr;   // zeroed pool of activation / gradient amax slots
+    int nslots = 0, next_slot = 0;
+
+    int begin_slots(int n) {  // (fp16-operand arithmetics) a zeroed pool for this pass
+        if (!f16) return PUNET_OK;
+        wamax = ar->floats(rt->x6_nconv);
+        slots = ar->floats(n);
+        nslots = n;
+        next_slot = 0;
+        if (!dry && hipMemsetAsync(slots, 0, (size_t)n * 4, (hipStream_t)stream) != hipSuccess) {
+            punet_set_error("punet_rt: memset of the amax slots failed");
+            return PUNET_ERR_HIP;
+        }
+        return PUNET_OK;
+    }
+    float* slot() { return f16 && next_slot < nslots ? slots + next_slot++ : nullptr; }
+    const float* wslot(const Conv& c) const { return wamax + c.x6_index; }
 
     const float* w(const Conv& c) const { return flat + c.w_off; }
     const float* b(const Conv& c) const { return flat + c.b_off; }
 
     int split(int mode, const __bf16** out) {
         __bf16* p = (__bf16*)ar->take((size_t)3 * rt->numel * 2);
-        RT_LAUNCH(punet_split_weights_x6_batch(flat, p, rt->d_x6, rt->x6_nconv, rt->x6_units, mode, stream));
+        if (f16)
+            RT_LAUNCH(punet_split_weights_f16_batch(flat, p, rt->d_x6, rt->x6_nconv, rt->x6_units, mode, wamax, 1, stream));
+        else
+            RT_LAUNCH(punet_split_weights_x6_batch(flat, p, rt->d_x6, rt->x6_nconv, rt->x6_units, mode, stream));
         *out = p;
         return PUNET_OK;
     }
@@ -167,7 +193,24 @@ struct Pass {  // one forward / backward walk
         }
         Act* y = rt->new_act(ar->floats((size_t)B * H * W * c.cout), B, H, W, c.cout, relu);
         if (cin <= SMALL_CIN) {
-            RT_LAUNCH(punet_conv3x3_small_fwd(x0->t, cin, w(c), b(c), y->t, c.cout, B, H, W, relu ? 1 : 0, stream));
+            if (f16) {
+                y->amax = slot();
+                RT_LAUNCH(punet_conv3x3_small_fwd_amax(x0->t, cin, w(c), b(c), y->t, c.cout, B, H, W, relu ? 1 : 0, y->amax, stream));
+            } else {
+                RT_LAUNCH(punet_conv3x3_small_fwd(x0->t, cin, w(c), b(c), y->t, c.cout, B, H, W, relu ? 1 : 0, stream));
+            }
+        } else if (f16) {  // fp16 planes scaled from the operands' amax slots; publishes y's amax (engine.py, conv())
+            if (relu && tape) y->bits = (unsigned*)ar->take(punet_gate_dwords(B, H, W, c.cout) * 4);
+            Act* q = nullptr;
+            if (pooled && H % 2 == 0 && W % 2 == 0) {
+                q = rt->new_act(ar->floats((size_t)B * (H / 2) * (W / 2) * c.cout), B, H / 2, W / 2, c.cout, false);
+                *pooled = q;
+            }
+            y->amax = slot();
+            if (q) q->amax = y->amax;  // an average never exceeds the maximum
+            RT_LAUNCH(punet_conv3x3_f16(x0->t, x0->C, x1 ? x1->t : nullptr, x1 ? x1->C : 0, planes0 + 3 * c.w_off, c.w_numel(), c.cout, 0,
+                                        b(c), 0, y->t, c.cout, nullptr, nullptr, y->bits, q ? q->t : nullptr, 0, relu ? 1 : 0, B, H, W, f16,
+                                        x0->amax, x1 ? x1->amax : nullptr, wslot(c), y->amax, stream));
         } else {
             if (relu && tape) y->bits = (unsigned*)ar->take(punet_gate_dwords(B, H, W, c.cout) * 4);
             const void* wp = planes0 + 3 * c.w_off;
@@ -190,6 +233,7 @@ struct Pass {  // one forward / backward walk
         const int OH = (x->H + 1) / 2, OW = (x->W + 1) / 2;
         Act* y = rt->new_act(ar->floats((size_t)x->B * OH * OW * x->C), x->B, OH, OW, x->C, false);
         RT_LAUNCH(punet_pool2x2_fwd(x->t, y->t, x->B, x->H, x->W, x->C, stream));
+        y->amax = x->amax;
         if (tape) tape->push_back(Op{1, -1, x, nullptr, y});
         *out = y;
         return PUNET_OK;
@@ -228,6 +272,7 @@ struct Pass {  // one forward / backward walk
         RT_CALL(encoder_stack(rt->unet_down, x, tape, &outs, &x));
         for (size_t j = 0; j < rt->unet_up.size(); ++j) {
             Act* up = rt->new_act(ar->floats((size_t)x->B * 4 * x->H * x->W * x->C), x->B, 2 * x->H, 2 * x->W, x->C, false);
+            up->amax = x->amax;  // a bound: bilinear interpolation is a convex combination
             RT_LAUNCH(punet_upsample2x_fwd(x->t, up->t, x->B, x->H, x->W, x->C, stream));
             if (tape) tape->push_back(Op{2, -1, x, nullptr, up});
             Act* bridge = outs[outs.size() - 2 - j];
@@ -260,13 +305,16 @@ struct Pass {  // one forward / backward walk
         return a->grad;
     }
 
-    int wgrad(const Conv& c, Act* x, int ci_off, const float* dz, bool with_bias, int accumulate) {
+    int wgrad(const Conv& c, Act* x, int ci_off, const float* dz, const float* dz_amax, bool with_bias, int accumulate) {
         float* dw = gflat + c.w_off;
         float* db = gflat + c.b_off;
         if (dry) return PUNET_OK;
         if (c.cin <= SMALL_CIN)
             return punet_conv3x3_small_wgrad(x->t, c.cin, dz, c.cout, dw, db, ws_wgrad, x->B, x->H, x->W, accumulate, 1.f, stream);
         const int ns = punet_wgrad_x6_slices(x->C, c.cout, x->B, x->H, x->W);
+        if (f16)
+            return punet_conv_wgrad_f16(x->t, x->C, dz, c.cout, dw, c.cin, ci_off, with_bias ? db : nullptr, ws_wgrad, ns, x->B, x->H, x->W,
+                                        accumulate, 1.f, f16, 0, x->amax, dz_amax, stream);
         return punet_conv_wgrad_x6(x->t, x->C, dz, c.cout, dw, c.cin, ci_off, with_bias ? db : nullptr, ws_wgrad, ns, x->B, x->H, x->W,
                                    accumulate, 1.f, X6_OPTS, stream);
     }
@@ -281,8 +329,8 @@ struct Pass {  // one forward / backward walk
                     punet_set_error("punet_rt: no gradient reached %s", c.name.c_str());
                     return PUNET_ERR_ARG;
                 }
-                RT_CALL(wgrad(c, op.x0, 0, dz, true, accumulate));
-                if (op.x1) RT_CALL(wgrad(c, op.x1, op.x0->C, dz, false, accumulate));
+                RT_CALL(wgrad(c, op.x0, 0, dz, op.y->gamax, true, accumulate));
+                if (op.x1) RT_CALL(wgrad(c, op.x1, op.x0->C, dz, op.y->gamax, false, accumulate));
                 int off = 0;
                 for (Act* src : {op.x0, op.x1}) {
                     if (!src) continue;
@@ -291,9 +339,17 @@ struct Pass {  // one forward / backward walk
                         float* g = grad_into(src, &acc);
                         const float* mask = src->relu_out ? src->t : nullptr;
                         const bool use_bits = src->bits && mask;
-                        RT_LAUNCH(punet_conv3x3_x6_gated(dz, c.cout, nullptr, 0, planes1 + 3 * c.w_off, c.w_numel(), c.cin, off, nullptr, 0, g,
-                                                       src->C, use_bits ? nullptr : mask, use_bits ? src->bits : nullptr, nullptr, acc, 0,
-                                                       src->B, src->H, src->W, X6_OPTS, stream));
+                        if (f16) {
+                            if (!src->gamax) src->gamax = slot();  // (accumulating: the slot keeps max(previous, new total) - a bound)
+                            RT_LAUNCH(punet_conv3x3_f16(dz, c.cout, nullptr, 0, planes1 + 3 * c.w_off, c.w_numel(), c.cin, off, nullptr, 0, g,
+                                                        src->C, use_bits ? nullptr : mask, use_bits ? src->bits : nullptr, nullptr, nullptr,
+                                                        acc, 0, src->B, src->H, src->W, f16, op.y->gamax, nullptr, wslot(c), src->gamax,
+                                                        stream));
+                        } else {
+                            RT_LAUNCH(punet_conv3x3_x6_gated(dz, c.cout, nullptr, 0, planes1 + 3 * c.w_off, c.w_numel(), c.cin, off, nullptr, 0,
+                                                           g, src->C, use_bits ? nullptr : mask, use_bits ? src->bits : nullptr, nullptr,
+                                                           acc, 0, src->B, src->H, src->W, X6_OPTS, stream));
+                        }
                     }
                     off += src->C;
                 }
@@ -303,12 +359,22 @@ struct Pass {  // one forward / backward walk
                 const void* bits = (op.x0->relu_out && op.x0->bits) ? op.x0->bits : nullptr;
                 RT_LAUNCH(punet_pool2x2_bwd_gated(op.y->grad, (op.x0->relu_out && !bits) ? op.x0->t : nullptr, bits, g, op.x0->B, op.x0->H,
                                                 op.x0->W, op.x0->C, acc, stream));
+                if (f16) {  // |dx| <= |dy| / 4 (+ what was there): a bound from the slots
+                    float* prev = acc ? op.x0->gamax : nullptr;
+                    float* sl = prev ? prev : slot();
+                    RT_LAUNCH(punet_amax_bound(op.y->gamax, 0.25f, prev, 1.f, sl, stream));
+                    op.x0->gamax = sl;
+                }
             } else {
                 int acc = 0;
                 float* g = grad_into(op.x0, &acc);
                 const void* bits = (op.x0->relu_out && op.x0->bits) ? op.x0->bits : nullptr;
                 RT_LAUNCH(punet_upsample2x_bwd_gated(op.y->grad, (op.x0->relu_out && !bits) ? op.x0->t : nullptr, bits, g, op.x0->B, op.x0->H,
                                                    op.x0->W, op.x0->C, stream));
+                if (f16) {  // the transposed x2 interpolation sums weights of at most 2 per dimension
+                    op.x0->gamax = slot();
+                    RT_LAUNCH(punet_amax_bound(op.y->gamax, 4.f, nullptr, 0.f, op.x0->gamax, stream));
+                }
             }
         }
         return PUNET_OK;
@@ -422,8 +488,9 @@ extern "C" int punet_rt_create(const PunetRtConfig* cfg, PunetRt** out) {
     for (const Entry& e : rt->entries)
         if (e.name.compare(0, 5, "unet.") != 0) { rt->unet_numel = e.off; break; }
     long units = 0;
-    for (const Conv& c : rt->convs)
+    for (Conv& c : rt->convs)
         if (c.k == 3 && c.cin > SMALL_CIN) {
+            c.x6_index = rt->x6_nconv;
             rt->x6_table.insert(rt->x6_table.end(), {c.w_off, (long)c.cin, (long)c.cout, units});
             units += c.w_numel() / 8;
             ++rt->x6_nconv;
@@ -442,6 +509,14 @@ extern "C" int punet_rt_create(const PunetRtConfig* cfg, PunetRt** out) {
     }
     rt->l2_ntensors = t;
     *out = rt;
+    return PUNET_OK;
+}
+
+// 3x3 conv arithmetic of every later call on this handle: 6 = the six-product bf16 parity arithmetic (default), 3 = "f16x3" (two
+// fp16 planes, per-tensor power-of-two scaling: what the trainers' mixed_precision=True selects), 1 = "f16" (one fp16 plane)
+extern "C" int punet_rt_set_arithmetic(PunetRt* rt, int products) {
+    PUNET_CHECK_ARG(rt && (products == 6 || products == 3 || products == 1), "punet_rt_set_arithmetic: products must be 6, 3 (f16x3) or 1 (f16)");
+    rt->f16_planes = products == 6 ? 0 : (products == 3 ? 2 : 1);
     return PUNET_OK;
 }
 
@@ -490,7 +565,9 @@ static int pseudo_labels_body(PunetRt* rt, const float* flat, const float* x, in
     rt->clear_acts();
     Pass p{rt, flat, nullptr, &ar, stream};
     p.dry = dry;
+    p.f16 = rt->f16_planes;
     const int n = rt->cfg.levels, CH = rt->cfg.num_filters[0], L = rt->cfg.latent_dim, nmid = rt->cfg.no_convs_fcomb - 2;
+    RT_CALL(p.begin_slots(256));
     p.ws_chan = ar.floats(punet_chan_sum_workspace_floats(B, H * W, rt->cfg.num_filters[n - 1]));
     Act* xin = rt->new_act(const_cast<float*>(x), B, H, W, rt->cfg.input_channels, false, false);
     float* zs = ar.floats((size_t)N * B * L);
@@ -541,6 +618,8 @@ static int elbo_body(PunetRt* rt, const float* flat, float* gflat, const float* 
     rt->clear_acts();
     Pass p{rt, flat, gflat, &ar, stream};
     p.dry = dry;
+    p.f16 = rt->f16_planes;
+    RT_CALL(p.begin_slots(1024));
     p.ws_chan = ar.floats(punet_chan_sum_workspace_floats(B, H * W, rt->cfg.num_filters[n - 1] > CH ? rt->cfg.num_filters[n - 1] : CH));
     p.ws_wgrad = ar.floats(max_wgrad_ws_floats(rt, B, H, W));
     // ---- forward: posterior on [patch, segm], prior, U-Net (tapes recorded)
@@ -584,6 +663,10 @@ static int elbo_body(PunetRt* rt, const float* flat, float* gflat, const float* 
         RT_CALL(punet_fcomb_z_bwd(S, zq, p.w(c1), gflat + c1.w_off, dz, B, L, CH, accumulate, stream));
     }
     feat->grad = dfeat;
+    if (p.f16) {  // d loss / d features comes from the Fcomb kernel (fp32 arithmetic): it publishes no amax
+        feat->gamax = p.slot();
+        if (!dry) RT_CALL(punet_amax(dfeat, (long)B * H * W * CH, feat->gamax, 0, stream));
+    }
     RT_CALL(p.backward_tape(tu, accumulate));
     if (after_unet && !dry) after_unet(ctx);
     if (!dry)
@@ -596,6 +679,10 @@ static int elbo_body(PunetRt* rt, const float* flat, float* gflat, const float* 
         if (!dry)
             RT_CALL(punet_latent_head_bwd(which == 0 ? dq : dp, which == 0 ? mean_q : mean_p, p.w(ch), enc->t, gflat + ch.w_off,
                                           gflat + ch.b_off, dmean, denc, B, enc->H * enc->W, enc->C, ch.cout, accumulate, stream));
+        if (p.f16) {
+            enc->gamax = p.slot();
+            if (!dry) RT_CALL(punet_amax(denc, (long)enc->numel(), enc->gamax, 0, stream));
+        }
         RT_CALL(p.backward_tape(which == 0 ? tq : tp, accumulate));
     }
     return PUNET_OK;

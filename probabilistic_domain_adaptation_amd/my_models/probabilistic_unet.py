@@ -144,13 +144,11 @@ class ProbabilisticUnet(nn.Module):
     def native_runtime(self):
         """The step-level native runtime of this model's configuration (runtime.NativeRuntime: the graph walk as host code
         inside libpunet_hip.so), created on first use; raises ValueError outside its domain (num_classes 1, num_filters[0] in
-        {32, 64}, no_convs_fcomb 2 or 3) and for arithmetics other than the parity default."""
+        {32, 64}, no_convs_fcomb 2 or 3) and for arithmetics other than "x6" (parity), "f16x3" and "f16"."""
         rt = getattr(self, "_native_rt", None)
-        if rt is None:
+        if rt is None or rt.conv_mode != self.engine.conv_mode:
             from ..runtime import NativeRuntime
-            if self.engine.conv_mode != "x6":
-                raise ValueError("the native runtime computes in the parity arithmetic (conv_mode 'x6')")
-            rt = self._native_rt = NativeRuntime(self.layout, self.device)
+            rt = self._native_rt = NativeRuntime(self.layout, self.device, self.engine.conv_mode)
         return rt
 
     def set_conv_mode(self, conv_mode: str):
@@ -234,6 +232,18 @@ class ProbabilisticUnet(nn.Module):
         self.z_prior_sample = z[0]
         _, _, logits = self.engine.sample(self._flat, st["features"], z, want_logits=True, want_consensus=False)
         return logits[0]
+
+    def pseudo_labels(self, patch, n_samples: int, upper=0.9, lower=0.1, masking=False, eps: Optional[torch.Tensor] = None):
+        """forward(patch, None, training=False) + sample_consensus(...) in one go: (mean of N sigmoids, consensus), float
+        [B,1,H,W] - the body of sample_from_teacher / sample_from_weak_model (mean_teacher_trainer.py:72-88) and of the MC
+        prediction (punet_predictions.py:29-33).  One call into the step-level native runtime where it covers this model
+        (the forward state - unet_features, prior_latent_space - is then NOT kept: use forward() for that), else the engine."""
+        from ..my_trainer.fused import native_ok
+        x = self.engine.to_nhwc(patch)
+        if native_ok(self) and (x.shape[1] * x.shape[2]) % 32 == 0:
+            return self.native_runtime().pseudo_labels(self._flat, x, self._eps(n_samples, x.shape[0], eps), upper, lower, masking)
+        self.forward(patch, None, training=False)
+        return self.sample_consensus(n_samples, upper, lower, masking, eps)
 
     def sample_consensus(self, n_samples: int, upper=0.9, lower=0.1, masking=False, eps: Optional[torch.Tensor] = None):
         """Fused form of `[sigmoid(sample()) for _ in range(n)]` + thresholds + stack/sum

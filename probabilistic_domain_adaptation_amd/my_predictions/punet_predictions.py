@@ -29,8 +29,11 @@ def standardize(raw: np.ndarray, eps: float = 1e-7) -> np.ndarray:
 def mc_prediction(model, raw: torch.Tensor, prior_samples: int = 8, eps=None) -> torch.Tensor:
     """_custom_punet_prediction (punet_predictions.py:29-33): forward(raw, None, False), then the mean of
     `prior_samples` sigmoid(sample(testing=True)) - one fused K7 launch instead of N Fcomb passes."""
-    model.forward(raw, None, training=False)
-    y, _ = model.sample_consensus(prior_samples, eps=eps)
+    if hasattr(model, "pseudo_labels"):  # one call (the native runtime where it applies)
+        y, _ = model.pseudo_labels(raw, prior_samples, eps=eps)
+    else:  # any object with the reference's forward() / sample_consensus() surface
+        model.forward(raw, None, training=False)
+        y, _ = model.sample_consensus(prior_samples, eps=eps)
     return y
 
 
@@ -96,8 +99,11 @@ def pseudo_predict_image(model, image: np.ndarray, prior_samples: int = 8, upper
     """Whole-image forward, mean of N sigmoids and the binary consensus mask (punet_predictions.py:96-124):
     returns (mean float32 [H, W], consensus uint8 [H, W])."""
     patch = torch.from_numpy(standardize(image))[None, None].to(model.device)
-    model.forward(patch, None, training=False)
-    y, z = model.sample_consensus(prior_samples, upper_threshold, lower_threshold, masking=True, eps=eps)
+    if hasattr(model, "pseudo_labels"):
+        y, z = model.pseudo_labels(patch, prior_samples, upper_threshold, lower_threshold, masking=True, eps=eps)
+    else:
+        model.forward(patch, None, training=False)
+        y, z = model.sample_consensus(prior_samples, upper_threshold, lower_threshold, masking=True, eps=eps)
     if getattr(model, "num_classes", 1) > 1:
         return y[0].cpu().numpy(), z[0].cpu().numpy().astype("uint8")
     return y[0, 0].cpu().numpy(), z[0, 0].cpu().numpy().astype("uint8")

@@ -224,7 +224,8 @@ def allreduce_grads(gflat: torch.Tensor, started: Optional[dict] = None) -> floa
 
 def native_ok(*models) -> bool:
     """May the fused steps hand the graph walk to the step-level native runtime (csrc/runtime.hip)?  Yes for the configuration
-    class it covers (runtime.supported), the parity arithmetic, the BCE criterion and the default kernel selection; $PUNET_RUNTIME
+    class it covers (runtime.supported), the parity arithmetic or the fp16-operand modes f16x3 / f16, the BCE criterion and the
+    default kernel selection; $PUNET_RUNTIME
     = python keeps the Python engine (the two enqueue the same kernels in the same order and give the same bits)."""
     import os
     from ..runtime import supported
@@ -232,8 +233,8 @@ def native_ok(*models) -> bool:
         return False
     for m in models:
         e = m.engine
-        if not (supported(m.layout) and e.conv_mode == "x6" and not m.rl_swap and e.fuse_fcomb and e.fuse_pool and e.sampler_x6
-                and e.prof is None and e.x6_opts == 6 | (16 << 8)):
+        if not (supported(m.layout) and e.conv_mode in ("x6", "f16x3", "f16") and not m.rl_swap and e.fuse_fcomb and e.fuse_pool
+                and e.sampler_x6 and e.prof is None and (e.x6_opts >> 8) == 16):
             return False
     return True
 
@@ -263,8 +264,7 @@ def pseudo_labels(net: ProbabilisticUnet, x1, n_samples: int, masking: bool, eps
     """sample_from_teacher / sample_from_weak_model (mean_teacher_trainer.py:72-88, fixmatch_trainer.py:37-54), fused:
     forward(x1, None, False) then K7.  Returns float [B,1,H,W] tensors (y soft mean, z consensus)."""
     with torch.no_grad():
-        net.forward(x1, None, training=False)
-        return net.sample_consensus(n_samples, upper, lower, masking, eps)
+        return net.pseudo_labels(x1, n_samples, upper, lower, masking, eps)
 
 
 def elbo_grad_pass(model: ProbabilisticUnet, gflat, x, y, z, eps, gscale: float, accumulate: bool, overlap: bool = False):

@@ -33,7 +33,9 @@ def pin_all(device):
 class NativeRuntime:
     _live = weakref.WeakSet()
 
-    def __init__(self, layout, device):
+    ARITHMETICS = {"x6": 6, "f16x3": 3, "f16": 1}  # conv_mode -> punet_rt_set_arithmetic
+
+    def __init__(self, layout, device, conv_mode: str = "x6"):
         _lib.load()
         if not supported(layout):
             raise ValueError("the native runtime covers num_classes = 1, num_filters[0] in {32, 64}, no_convs_fcomb in {2, 3}")
@@ -43,6 +45,10 @@ class NativeRuntime:
         h = C.c_void_p()
         _lib.call("punet_rt_create", C.byref(cfg), C.byref(h))
         self._h = h
+        if conv_mode not in self.ARITHMETICS:
+            raise ValueError(f"the native runtime computes in {sorted(self.ARITHMETICS)}, not '{conv_mode}'")
+        self.conv_mode = conv_mode
+        _lib.call("punet_rt_set_arithmetic", h, self.ARITHMETICS[conv_mode])
         if _lib.call("punet_rt_param_floats", h) != layout.numel:
             raise RuntimeError("native runtime and ParamLayout disagree about the flat parameter layout")
         self.tables = torch.empty(_lib.call("punet_rt_tables_bytes", h), dtype=torch.uint8, device=self.device)

@@ -180,3 +180,32 @@ def test_one_call_self_training_step(dev, monkeypatch):
     assert torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
     assert torch.equal(ya, yb) and torch.equal(za, zb)
     assert float(la) == float(sc[0] + 1.0 * sc[1] + 1e-5 * sc[2])
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f16"])
+def test_native_runtime_in_the_fp16_operand_modes(dev, monkeypatch, mode):
+    """The runtime carves the amax slots out of its arena and handles them itself (first-layer publication, inherited slots through
+    fused pooling and up-sampling, bounds through their backward, standalone passes behind the Fcomb / latent-head backward): a
+    Mean-Teacher step in f16x3 / f16 equals the Python engine's bit for bit."""
+    import copy
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    nf, B, H, W, n = [64, 64, 96, 128], 2, 64, 96, 4
+    x, x1, x2, y = [t.to(dev) for t in O.synth_batch(B, 1, H, W, 0)]
+    g = torch.Generator().manual_seed(5)
+    eps_n, eps_s = torch.randn(n, B, 6, generator=g).to(dev), torch.randn(1, B, 6, generator=g).to(dev)
+    res = {}
+    for rtm in ("python", "native"):
+        monkeypatch.setenv("PUNET_RUNTIME", rtm)
+        m = ProbabilisticUnet(1, 1, nf, 6, 3, 1.0, consensus_masking=True, device=dev, seed=1, conv_mode=mode)
+        t = copy.deepcopy(m)
+        assert FU.native_ok(m, t) == (rtm == "native")
+        opt = FusedAdam(m, lr=1e-3)
+        for it in range(2):
+            loss, ys, zs, _ = FU.fused_self_training_step(m, t, opt, x1, x2, n, False, eps_pl=eps_n, eps_s=eps_s)
+        torch.cuda.synchronize()
+        res[rtm] = (float(loss), m.flat_params.clone(), t.flat_params.clone(), ys.clone(), zs.clone())
+    assert np.isfinite(res["native"][0]) and res["python"][0] == res["native"][0]
+    for a, b in zip(res["python"][1:], res["native"][1:]):
+        assert torch.equal(a, b)
