@@ -393,7 +393,9 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "launch": "hipGraph replay of the captured fused step (one graph launch per step"
                                  + (f"; {len(run.graphed.segments)} segments cut at the gradient all-reduces)" if world > 1 else ")")
-                                 if use_graph else (graph_note or "eager: ~500 kernel launches per step from Python"),
+                                 if use_graph else (graph_note or ("eager: ~500 kernel launches per step, issued by the native runtime inside "
+                                                                    "4-5 library calls" if FU.native_ok(run.model)
+                                                                    else "eager: ~500 kernel launches per step from Python")),
                        "graph_walk": ("native runtime inside libpunet_hip.so (csrc/runtime.hip): pseudo-labels, ELBO forward/backward, "
                                       "regulariser, Adam+EMA = 4-5 library calls per step" if FU.native_ok(run.model)
                                       else "Python engine (engine.py): one library call per kernel"),
