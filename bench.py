@@ -119,8 +119,8 @@ class Runner:
         from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
         from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
         self.FU, self.workload, self.N, self.B = FU, workload, N, B
-        self.model = ProbabilisticUnet(channels, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=1,
-                                       conv_mode=conv_mode)
+        self.model = ProbabilisticUnet(channels, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=bool(getattr(a, "dice", False)),
+                                       device=dev, seed=1, conv_mode=conv_mode)
         self.teacher = copy.deepcopy(self.model) if workload in ("mean_teacher", "adamt") else None
         self.opt = FusedAdam(self.model, lr=1e-5)
         x, x1, x2, y = synth(B, H, W, 100 + rank, dev, channels)  # every rank its own shard of the synthetic stream
@@ -255,6 +255,9 @@ def main():
     ap.add_argument("--runtime", default=None, choices=["native", "python"],
                     help="who walks the layer graph of a step: the step-level native runtime inside libpunet_hip.so (default where it "
                          "applies: four library calls per step) or the Python engine (~500 per-op calls); same kernels, same bits")
+    ap.add_argument("--dice", action="store_true",
+                    help="rl_swap=True: the Dice criterion every LIVECell / MitoEM script of the reference uses (recalled torch_em "
+                         "definition, parity unpinned) instead of BCE (the criterion all parity gates use); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -388,7 +391,7 @@ def main():
                              "fp16 autocast; reduced precision)",
                       "f16s": "f16 (fp16 operands AND fp16 activation storage, fp32 gradients scaled per tensor; reduced precision)"}[eng.conv_mode],
             "data": "synthetic",
-            "config": {"workload": f"PUNet {a.workload} step: nf={NF}, latent 6, fcomb 3, BCE+KL, consensus masking, "
+            "config": {"workload": f"PUNet {a.workload} step: nf={NF}, latent 6, fcomb 3, {'Dice' if a.dice else 'BCE'}+KL, consensus masking, "
                                    f"{H}x{W}x{a.channels} patches, batch {B}/GPU, N={N} MC samples, Adam lr 1e-5, EMA 0.999",
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "launch": "hipGraph replay of the captured fused step (one graph launch per step"
@@ -549,7 +552,7 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as ex:  # never lose the headline to an extra
                 out["config"]["fast_mode_f16x3"] = {"error": f"{type(ex).__name__}: {ex}"}
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and not a.dice:
             out["cpu_baseline"] = cpu_baseline(a.workload, N, H, W)
         print(json.dumps(out))
     if world > 1:

@@ -231,6 +231,13 @@ int punet_fcomb_train_fwd_bwd(const float* feat, const float* w1, const float* z
                               const float* w3, const float* b3, const float* target, const float* consm, float gscale,
                               float* logits, float* dfeat, float* loss_sum, float* workspace, int B, int HW, int CH, int nmid,
                               void* stream);
+/* the same with the Dice criterion of rl_swap=True (probabilistic_unet.py:347; every LIVECell / MitoEM script), recalled torch_em
+ * definition [parity unpinned]: the ratio is global, so the fused kernel runs twice (forward + partial sums, then forward +
+ * backward with the reduced sums); loss_out[0] = 1 - 2 sum(p t) / max(sum p^2 + sum t^2, 1e-7).  Same workspace, fp32 features. */
+int punet_fcomb_train_fwd_bwd_dice(const float* feat, const float* w1, const float* zb, const float* wmid, const float* bmid,
+                                   const float* w3, const float* b3, const float* target, const float* consm, float gscale,
+                                   float* logits, float* dfeat, float* loss_out, float* workspace, int B, int HW, int CH, int nmid,
+                                   void* stream);
 int punet_fcomb_train_reduce(const float* workspace, float* dw1, int w1_rows, float* db1, float* dwmid, float* dbmid, float* dw3,
                              float* db3, float* S, float* chan_workspace, int B, int HW, int CH, int nmid, int accumulate,
                              void* stream);
@@ -376,7 +383,8 @@ int punet_augment_view(const float* x, const float* stats, const float* noise, c
  *     punet_rt_l2_reg_grad     = the three l2_regularisation terms and their gradient (utils.py:32-40, mean_teacher_trainer.py:115-117)
  *     punet_adam_hyper + punet_adam_ema_dev (above) = optimizer.step() + _momentum_update()
  * Covered: num_classes = 1, num_filters[0] in {32, 64}, no_convs_fcomb in {2, 3}, filters multiples of 8, input_channels <= 6,
- * the BCE criterion, the six-product parity arithmetic - every configuration the reference's scripts build with rl_swap=False.
+ * BCE or Dice criterion, the six-product parity arithmetic or the fp16-operand fast modes - every configuration the reference's
+ * scripts build.
  * Parameters: ONE flat fp32 buffer in the reference's state-dict order, conv weights [ky][kx][cin][cout] (punet_rt_param_entry
  * lists name / offset / logical shape of every tensor).  The runtime owns NOTHING on the device: every call carves its
  * activations, gate bits, gradients, weight planes and split-K slabs out of a caller-provided ARENA (punet_rt_arena_bytes) and
@@ -393,6 +401,9 @@ void punet_rt_destroy(PunetRt* rt);
 /* arithmetic of the 3x3 convolutions of every later call: 6 = six-product parity arithmetic (default), 3 = "f16x3", 1 = "f16"
  * (the fp16-operand fast modes above: amax slots are carved from the arena and handled inside the runtime) */
 int punet_rt_set_arithmetic(PunetRt* rt, int products);
+/* criterion of every later punet_rt_elbo_fwd_bwd: 0 = BCEWithLogits (rl_swap=False), 1 = Dice (rl_swap=True; recalled torch_em
+ * definition, parity unpinned) */
+int punet_rt_set_criterion(PunetRt* rt, int dice);
 long punet_rt_param_floats(const PunetRt* rt);
 long punet_rt_unet_floats(const PunetRt* rt); /* [0, this) of the flat buffers = the U-Net's tensors (final first in the backward) */
 int punet_rt_num_entries(const PunetRt* rt);

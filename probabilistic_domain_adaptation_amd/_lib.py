@@ -76,6 +76,7 @@ _SIGS = {
     "punet_fcomb_train_supported": (_i, [_i, _i, _i]),
     "punet_fcomb_train_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "punet_fcomb_train_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "punet_fcomb_train_fwd_bwd_dice": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "punet_fcomb_train_reduce": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "punet_conv3x3_small_fwd_bf16s": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "punet_conv3x3_bf16s": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p]),
@@ -123,6 +124,7 @@ _SIGS.update({
     "punet_rt_create": (_i, [C.POINTER(PunetRtConfig), C.POINTER(_p)]),
     "punet_rt_destroy": (None, [_p]),
     "punet_rt_set_arithmetic": (_i, [_p, _i]),
+    "punet_rt_set_criterion": (_i, [_p, _i]),
     "punet_rt_param_floats": (_l, [_p]),
     "punet_rt_unet_floats": (_l, [_p]),
     "punet_rt_num_entries": (_i, [_p]),

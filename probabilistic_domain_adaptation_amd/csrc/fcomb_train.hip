@@ -45,7 +45,8 @@ struct TrainArgs {
     float* dfeat;         // [P][CH]
     float* slabs;         // [grid][slab_stride]: dW1f [CH][CH] | dWm [CH][CH] | dbm [CH] | dW3 [CH] | db3 [1]
     float* stile;         // [ntiles][CH]: per-tile column sums of dZ0 (-> per-image sums -> z gradient, b1 gradient)
-    float* loss_part;     // [grid]
+    float* loss_part;     // [grid] (BCE) / [3][grid] partial Dice sums (CRIT 1)
+    const float* dice_sums;  // CRIT 2: {sum p t, sum p^2, sum t^2} over all pixels (device)
     float gscale;
     int B, HW, ntiles, slab_stride;
 };
@@ -72,7 +73,10 @@ __device__ __forceinline__ auto& pick(A& a, B& b) {
 }
 
 // F16: a.feat holds 1 = bf16 (the "bf16s" fast mode), 2 = fp16 ("f16s")
-template <int NBLK, int NMID, int F16 = 0>
+// CRIT: the criterion - 0 = BCE (probabilistic_unet.py:348); the Dice criterion (:347, [recalled torch_em definition, parity
+// unpinned]: 1 - 2 sum(p t) / max(sum p^2 + sum t^2, eps) over batch and pixels) is a global ratio, so it takes two launches:
+// 1 = forward only (logits + the three partial sums per workgroup), 2 = forward + backward given the reduced sums.
+template <int NBLK, int NMID, int F16 = 0, int CRIT = 0>
 __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
     typedef typename std::conditional<F16 == 2, _Float16, __bf16>::type ft_t16;
     // four consecutive channels of one pixel / one channel of one pixel, from either storage
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
     // channel sums kept ONE register per 32-channel block: lane (l31, half) owns channel 32 cb + l31; the two halves hold
     // partial sums over the pixels of their parity and are combined at the end
     float accBm[NBLK], accW3[NBLK];
-    float accB3 = 0.f, accLoss = 0.f;
+    float accB3 = 0.f, accLoss = 0.f, accDice = 0.f;
 #pragma unroll
     for (int i = 0; i < NBLK; ++i) {
         accBm[i] = accW3[i] = 0.f;
@@ -229,11 +233,35 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
             for (int r = 0; r < 16; ++r) part = fmaf(hl[cb][r], sW3[cb * 32 + mfma32_row(r, half)], part);
         const float logit = part + __shfl_xor(part, 32) + b3;
         const float x = logit * cm, t = tgt * cm;
-        const float dlogit = a.gscale * (sigm(x) - t) * cm;  // both halves hold the pixel's value
-        if (half == 0) {
-            a.logits[pix] = logit;
-            accLoss += (1.f - t) * x - (fminf(x, 0.f) - log1pf(expf(-fabsf(x))));
-            accB3 += dlogit;
+        float dlogit;
+        if constexpr (CRIT == 0) {
+            dlogit = a.gscale * (sigm(x) - t) * cm;  // both halves hold the pixel's value
+            if (half == 0) {
+                a.logits[pix] = logit;
+                accLoss += (1.f - t) * x - (fminf(x, 0.f) - log1pf(expf(-fabsf(x))));
+                accB3 += dlogit;
+            }
+        } else if constexpr (CRIT == 1) {  // Dice, first launch: logits and the partial sums; no backward
+            const float pr = sigm(x);
+            if (half == 0) {
+                a.logits[pix] = logit;
+                accLoss += pr * t;   // sum p t
+                accB3 += pr * pr;    // sum p^2
+                accDice += t * t;    // sum t^2
+            }
+            continue;
+        } else {  // Dice, second launch: d loss / d logit from the global sums (dice_bwd_kernel's formula)
+            const float sa = a.dice_sums[0], den = a.dice_sums[1] + a.dice_sums[2];
+            const bool clamped = den < 1e-7f;
+            const float D = clamped ? 1e-7f : den;
+            const float pr = sigm(x);
+            float dp = -2.f * t / D;
+            if (!clamped) dp += 2.f * sa * 2.f * pr / (D * D);
+            dlogit = a.gscale * dp * pr * (1.f - pr) * cm;
+            if (half == 0) {
+                a.logits[pix] = logit;
+                accB3 += dlogit;
+            }
         }
         const float dl = dlogit;
 
@@ -361,6 +389,15 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
     __syncthreads();
     float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
     float* red = sT;  // [4 waves][CH * CH] fits: 4 x 2 x 32 x TP >= 4 x CH x CH for CH in {32, 64}
+    if constexpr (CRIT == 1) {  // Dice, first launch: the three partial sums of this workgroup, nothing else
+        float u = accLoss, v = accB3, w = accDice;
+        for (int off = 32; off > 0; off >>= 1) { u += __shfl_xor(u, off); v += __shfl_xor(v, off); w += __shfl_xor(w, off); }
+        if (lane == 0) { red[wave] = u; red[4 + wave] = v; red[8 + wave] = w; }
+        __syncthreads();
+        if (tid < 3)
+            a.loss_part[(size_t)tid * gridDim.x + blockIdx.x] = ((red[4 * tid] + red[4 * tid + 1]) + red[4 * tid + 2]) + red[4 * tid + 3];
+        return;
+    }
     auto reduce_matrix = [&](const f32x16 (&acc)[NBLK][NBLK], float* out) __attribute__((always_inline)) {
 #pragma unroll
         for (int kb = 0; kb < NBLK; ++kb)
@@ -442,12 +479,12 @@ extern "C" int punet_fcomb_train_supported(int CH, int nmid, int HW) {
 extern "C" size_t punet_fcomb_train_workspace_floats(int B, int HW, int CH, int nmid) {
     const int ntiles = (int)(((size_t)B * HW) / 32);
     const int grid = train_grid(ntiles);
-    return (size_t)grid * slab_floats(CH, nmid) + (size_t)ntiles * CH + (size_t)grid + 4;
+    return (size_t)grid * slab_floats(CH, nmid) + (size_t)ntiles * CH + (size_t)3 * grid + 8;  // (+ 3 x grid: the Dice partial sums)
 }
 
 static int fcomb_train_impl(int f16, const float* feat, const float* w1, const float* zb, const float* wmid, const float* bmid,
                             const float* w3, const float* b3, const float* target, const float* consm, float gscale, float* logits,
-                            float* dfeat, float* loss_sum, float* workspace, int B, int HW, int CH, int nmid, void* stream_);
+                            float* dfeat, float* loss_sum, float* workspace, int B, int HW, int CH, int nmid, void* stream_, int dice = 0);
 
 extern "C" int punet_fcomb_train_fwd_bwd(const float* feat, const float* w1, const float* zb, const float* wmid, const float* bmid,
                                          const float* w3, const float* b3, const float* target, const float* consm, float gscale,
@@ -473,9 +510,30 @@ extern "C" int punet_fcomb_train_fwd_bwd_f16s(const void* feat, const float* w1,
                             workspace, B, HW, CH, nmid, stream_);
 }
 
+// sums[3] <- the [3][n] partial Dice sums (double accumulation, deterministic); loss[0] = 1 - 2 a / max(b + c, eps)
+__global__ void dice_finish_kernel(const float* __restrict__ part, int n, float* __restrict__ sums, float* __restrict__ loss) {
+    __shared__ double sh[256];
+    for (int k = 0; k < 3; ++k) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) acc += (double)part[(size_t)k * n + i];
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sums[k] = (float)sh[0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float den = sums[1] + sums[2];
+        loss[0] = 1.f - 2.f * sums[0] / (den < 1e-7f ? 1e-7f : den);
+    }
+}
+
 static int fcomb_train_impl(int f16, const float* feat, const float* w1, const float* zb, const float* wmid, const float* bmid,
                             const float* w3, const float* b3, const float* target, const float* consm, float gscale, float* logits,
-                            float* dfeat, float* loss_sum, float* workspace, int B, int HW, int CH, int nmid, void* stream_) {
+                            float* dfeat, float* loss_sum, float* workspace, int B, int HW, int CH, int nmid, void* stream_, int dice) {
     hipStream_t stream = (hipStream_t)stream_;
     PUNET_CHECK_ARG(feat && w1 && zb && w3 && b3 && target && logits && dfeat && loss_sum && workspace,
                     "punet_fcomb_train_fwd_bwd: null pointer");
@@ -491,32 +549,63 @@ static int fcomb_train_impl(int f16, const float* feat, const float* w1, const f
     a.slabs = workspace;
     a.stile = workspace + (size_t)grid * a.slab_stride;
     a.loss_part = a.stile + (size_t)a.ntiles * CH;
-#define PUNET_TRAIN_LAUNCH1(NB, NM, F)                                                                                       \
+#define PUNET_TRAIN_LAUNCH1(NB, NM, F, CR)                                                                                   \
     do {                                                                                                                     \
         const size_t sh = train_smem_bytes<NB, NM>();                                                                        \
-        if (hipFuncSetAttribute((const void*)fcomb_train_kernel<NB, NM, F>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+        if (hipFuncSetAttribute((const void*)fcomb_train_kernel<NB, NM, F, CR>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                 (int)sh) != hipSuccess) {                                                                    \
             punet_set_error("punet_fcomb_train_fwd_bwd: cannot reserve %zu bytes of LDS", sh);                               \
             return PUNET_ERR_HIP;                                                                                            \
         }                                                                                                                    \
-        fcomb_train_kernel<NB, NM, F><<<grid, 256, sh, stream>>>(a);                                                         \
+        fcomb_train_kernel<NB, NM, F, CR><<<grid, 256, sh, stream>>>(a);                                                     \
     } while (0)
-#define PUNET_TRAIN_LAUNCH(NB, NM)                \
-    do {                                          \
-        if (f16 == 2) PUNET_TRAIN_LAUNCH1(NB, NM, 2); \
-        else if (f16 == 1) PUNET_TRAIN_LAUNCH1(NB, NM, 1); \
-        else PUNET_TRAIN_LAUNCH1(NB, NM, 0);  \
+#define PUNET_TRAIN_LAUNCH(NB, NM, CR)                    \
+    do {                                                  \
+        if (f16 == 2) PUNET_TRAIN_LAUNCH1(NB, NM, 2, CR); \
+        else if (f16 == 1) PUNET_TRAIN_LAUNCH1(NB, NM, 1, CR); \
+        else PUNET_TRAIN_LAUNCH1(NB, NM, 0, CR);          \
     } while (0)
-    if (CH == 64 && nmid == 1) PUNET_TRAIN_LAUNCH(2, 1);
-    else if (CH == 64) PUNET_TRAIN_LAUNCH(2, 0);
-    else if (nmid == 1) PUNET_TRAIN_LAUNCH(1, 1);
-    else PUNET_TRAIN_LAUNCH(1, 0);
+#define PUNET_TRAIN_DISPATCH(L, CR)                     \
+    do {                                                \
+        if (CH == 64 && nmid == 1) L(2, 1, CR);         \
+        else if (CH == 64) L(2, 0, CR);                 \
+        else if (nmid == 1) L(1, 1, CR);                \
+        else L(1, 0, CR);                               \
+    } while (0)
+#define PUNET_TRAIN_LAUNCH_F32(NB, NM, CR) PUNET_TRAIN_LAUNCH1(NB, NM, 0, CR)  // (the Dice launches: fp32 feature storage only)
+    if (!dice) {
+        PUNET_TRAIN_DISPATCH(PUNET_TRAIN_LAUNCH, 0);
+        PUNET_LAUNCH_CHECK("fcomb_train");
+        sum_loss_parts_kernel<<<1, 256, 0, stream>>>(a.loss_part, grid, loss_sum);
+        PUNET_LAUNCH_CHECK("sum_loss_parts");
+        return PUNET_OK;
+    }
+    // Dice: a global ratio - forward launch (logits + partial sums), the reduced sums and the loss, then forward + backward
+    float* sums = a.loss_part + (size_t)3 * grid;
+    PUNET_CHECK_ARG(f16 == 0, "punet_fcomb_train_fwd_bwd_dice: fp32 feature storage only");
+    PUNET_TRAIN_DISPATCH(PUNET_TRAIN_LAUNCH_F32, 1);
+    PUNET_LAUNCH_CHECK("fcomb_train (Dice sums)");
+    dice_finish_kernel<<<1, 256, 0, stream>>>(a.loss_part, grid, sums, loss_sum);
+    PUNET_LAUNCH_CHECK("dice_finish");
+    a.dice_sums = sums;
+    PUNET_TRAIN_DISPATCH(PUNET_TRAIN_LAUNCH_F32, 2);
+    PUNET_LAUNCH_CHECK("fcomb_train (Dice)");
+#undef PUNET_TRAIN_LAUNCH_F32
+#undef PUNET_TRAIN_DISPATCH
 #undef PUNET_TRAIN_LAUNCH
 #undef PUNET_TRAIN_LAUNCH1
-    PUNET_LAUNCH_CHECK("fcomb_train");
-    sum_loss_parts_kernel<<<1, 256, 0, stream>>>(a.loss_part, grid, loss_sum);
-    PUNET_LAUNCH_CHECK("sum_loss_parts");
     return PUNET_OK;
+}
+
+// The same with the Dice criterion of rl_swap=True (probabilistic_unet.py:347; every LIVECell / MitoEM script) under the recalled
+// torch_em definition [parity unpinned]: loss_out[0] = 1 - 2 sum(p t) / max(sum p^2 + sum t^2, 1e-7) with p = sigmoid(logit * consm),
+// t = target * consm over batch and pixels.  Two launches of the fused kernel (the ratio is global) - fp32 feature storage.
+extern "C" int punet_fcomb_train_fwd_bwd_dice(const float* feat, const float* w1, const float* zb, const float* wmid, const float* bmid,
+                                              const float* w3, const float* b3, const float* target, const float* consm, float gscale,
+                                              float* logits, float* dfeat, float* loss_out, float* workspace, int B, int HW, int CH,
+                                              int nmid, void* stream_) {
+    return fcomb_train_impl(0, feat, w1, zb, wmid, bmid, w3, b3, target, consm, gscale, logits, dfeat, loss_out, workspace, B, HW, CH,
+                            nmid, stream_, 1);
 }
 
 // second pass: the partial slabs of punet_fcomb_train_fwd_bwd (same workspace, same B / HW / CH / nmid) into the gradient tensors;

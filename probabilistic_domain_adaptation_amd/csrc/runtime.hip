@@ -6,8 +6,8 @@
 // not cover and enqueues exactly the same kernels in the same order, so the two agree bit for bit (tests/test_gpu_runtime.py).
 //
 // Covered: num_classes = 1, num_filters[0] in {32, 64} (the fused Fcomb kernels), no_convs_fcomb in {2, 3}, every other filter
-// count a multiple of 8, input_channels + 1 <= 7, the BCE criterion, the six-product parity arithmetic ("x6") - i.e. every
-// configuration the reference's scripts build with rl_swap=False, and the bench workload.
+// count a multiple of 8, input_channels + 1 <= 7, the BCE and Dice criteria, the six-product parity arithmetic ("x6") and the
+// fp16-operand fast modes - i.e. every configuration the reference's scripts build, and the bench workload.
 //
 // Memory: the runtime owns nothing on the device.  The caller hands every call an ARENA (device bytes, punet_rt_arena_bytes) that
 // is carved up by a bump allocator - activations, gate bits, gradients, weight planes, split-K slabs - and a small TABLES buffer
@@ -88,6 +88,7 @@ struct PunetRt {
     long* d_x6 = nullptr;
     long* d_l2 = nullptr;
     int f16_planes = 0;  // 0: six-product bf16 parity arithmetic; 2: "f16x3"; 1: "f16" (punet_rt_set_arithmetic)
+    int dice = 0;        // criterion of punet_rt_elbo_fwd_bwd: 0 BCE, 1 Dice (punet_rt_set_criterion)
     // per-call state
     size_t last_arena_used = 0;
     std::vector<Act*> acts;
@@ -520,6 +521,14 @@ extern "C" int punet_rt_set_arithmetic(PunetRt* rt, int products) {
     return PUNET_OK;
 }
 
+// criterion of every later punet_rt_elbo_fwd_bwd on this handle: 0 = BCEWithLogits (rl_swap=False, probabilistic_unet.py:348),
+// 1 = Dice (rl_swap=True, :347; recalled torch_em definition, parity unpinned)
+extern "C" int punet_rt_set_criterion(PunetRt* rt, int dice) {
+    PUNET_CHECK_ARG(rt && (dice == 0 || dice == 1), "punet_rt_set_criterion: 0 (BCE) or 1 (Dice)");
+    rt->dice = dice;
+    return PUNET_OK;
+}
+
 extern "C" void punet_rt_destroy(PunetRt* rt) {
     if (!rt) return;
     rt->clear_acts();
@@ -651,8 +660,9 @@ static int elbo_body(PunetRt* rt, const float* flat, float* gflat, const float* 
         RT_CALL(punet_reparam(muls_q, eps, zq, 1, B, L, stream));
         RT_CALL(punet_latent_kl_rows(muls_q, muls_p, nullptr, kl_rows, kl_out, B, L, stream));
         RT_CALL(punet_fcomb_zbias(zq, p.w(c1), p.b(c1), zb, B, L, CH, stream));
-        RT_CALL(punet_fcomb_train_fwd_bwd(feat->t, p.w(c1), zb, cm ? p.w(*cm) : nullptr, cm ? p.b(*cm) : nullptr, p.w(c3), p.b(c3), target,
-                                          consm, gscale, logits, dfeat, rec_out, ws_f, B, H * W, CH, nmid, stream));
+        RT_CALL((rt->dice ? punet_fcomb_train_fwd_bwd_dice : punet_fcomb_train_fwd_bwd)(
+            feat->t, p.w(c1), zb, cm ? p.w(*cm) : nullptr, cm ? p.b(*cm) : nullptr, p.w(c3), p.b(c3), target, consm, gscale, logits, dfeat,
+            rec_out, ws_f, B, H * W, CH, nmid, stream));
     }
     // ---- backward
     RT_CALL(p.split(1, &p.planes1));

@@ -740,7 +740,8 @@ class PUNetEngine:
                   _stream())
         nmid = len(L.fcomb_mid)
         K = c3.cout
-        if (record and loss_kind == "bce" and taps is None and self.fuse_fcomb and K == 1
+        if (record and loss_kind in ("bce", "dice") and taps is None and self.fuse_fcomb and K == 1
+                and (loss_kind == "bce" or feat.t.dtype == torch.float32)
                 and _lib.call("punet_fcomb_train_supported", CH, nmid, H * W)):
             # K7t: forward, criterion and the whole Fcomb backward in one kernel; the weight-gradient slabs wait in `ws` for
             # elbo_backward (a fresh buffer per pass: the joint trainers hold two passes' worth between forward and backward)
@@ -748,6 +749,7 @@ class PUNetEngine:
             ws = self._empty(_lib.call("punet_fcomb_train_workspace_floats", B, H * W, CH, nmid))
             logits, dfeat, rec = self._empty(B, 1, H, W), self._empty(B, H, W, CH), self._empty(1)
             self._timed("fcomb_train", 2.0 * 3 * B * H * W * CH * (CH * (1 + nmid) + 1),
+                        "punet_fcomb_train_fwd_bwd_dice" if loss_kind == "dice" else
                         {torch.bfloat16: "punet_fcomb_train_fwd_bwd_bf16s", torch.float16: "punet_fcomb_train_fwd_bwd_f16s",
                          torch.float32: "punet_fcomb_train_fwd_bwd"}[feat.t.dtype], feat.ptr,
                         self._wptr(flat, c1), zb.data_ptr(), self._wptr(flat, cm_) if nmid else None,

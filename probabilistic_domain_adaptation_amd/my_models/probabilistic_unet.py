@@ -146,9 +146,9 @@ class ProbabilisticUnet(nn.Module):
         inside libpunet_hip.so), created on first use; raises ValueError outside its domain (num_classes 1, num_filters[0] in
         {32, 64}, no_convs_fcomb 2 or 3) and for arithmetics other than "x6" (parity), "f16x3" and "f16"."""
         rt = getattr(self, "_native_rt", None)
-        if rt is None or rt.conv_mode != self.engine.conv_mode:
+        if rt is None or rt.conv_mode != self.engine.conv_mode or rt.dice != bool(self.rl_swap):
             from ..runtime import NativeRuntime
-            rt = self._native_rt = NativeRuntime(self.layout, self.device, self.engine.conv_mode)
+            rt = self._native_rt = NativeRuntime(self.layout, self.device, self.engine.conv_mode, dice=bool(self.rl_swap))
         return rt
 
     def set_conv_mode(self, conv_mode: str):

@@ -224,8 +224,8 @@ def allreduce_grads(gflat: torch.Tensor, started: Optional[dict] = None) -> floa
 
 def native_ok(*models) -> bool:
     """May the fused steps hand the graph walk to the step-level native runtime (csrc/runtime.hip)?  Yes for the configuration
-    class it covers (runtime.supported), the parity arithmetic or the fp16-operand modes f16x3 / f16, the BCE criterion and the
-    default kernel selection; $PUNET_RUNTIME
+    class it covers (runtime.supported), the parity arithmetic or the fp16-operand modes f16x3 / f16 (BCE or Dice criterion) and
+    the default kernel selection; $PUNET_RUNTIME
     = python keeps the Python engine (the two enqueue the same kernels in the same order and give the same bits)."""
     import os
     from ..runtime import supported
@@ -233,7 +233,7 @@ def native_ok(*models) -> bool:
         return False
     for m in models:
         e = m.engine
-        if not (supported(m.layout) and e.conv_mode in ("x6", "f16x3", "f16") and not m.rl_swap and e.fuse_fcomb and e.fuse_pool
+        if not (supported(m.layout) and e.conv_mode in ("x6", "f16x3", "f16") and e.fuse_fcomb and e.fuse_pool
                 and e.sampler_x6 and e.prof is None and (e.x6_opts >> 8) == 16):
             return False
     return True

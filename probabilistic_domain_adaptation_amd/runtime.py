@@ -35,7 +35,7 @@ class NativeRuntime:
 
     ARITHMETICS = {"x6": 6, "f16x3": 3, "f16": 1}  # conv_mode -> punet_rt_set_arithmetic
 
-    def __init__(self, layout, device, conv_mode: str = "x6"):
+    def __init__(self, layout, device, conv_mode: str = "x6", dice: bool = False):
         _lib.load()
         if not supported(layout):
             raise ValueError("the native runtime covers num_classes = 1, num_filters[0] in {32, 64}, no_convs_fcomb in {2, 3}")
@@ -49,6 +49,8 @@ class NativeRuntime:
             raise ValueError(f"the native runtime computes in {sorted(self.ARITHMETICS)}, not '{conv_mode}'")
         self.conv_mode = conv_mode
         _lib.call("punet_rt_set_arithmetic", h, self.ARITHMETICS[conv_mode])
+        self.dice = bool(dice)
+        _lib.call("punet_rt_set_criterion", h, int(self.dice))
         if _lib.call("punet_rt_param_floats", h) != layout.numel:
             raise RuntimeError("native runtime and ParamLayout disagree about the flat parameter layout")
         self.tables = torch.empty(_lib.call("punet_rt_tables_bytes", h), dtype=torch.uint8, device=self.device)

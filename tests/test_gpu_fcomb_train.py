@@ -31,13 +31,14 @@ def _setup(dev, nf, no_convs_fcomb, B, H, W, fuse):
     return cfg, Pnp, lay, eng, flat
 
 
-def _run(dev, nf, ncf, B, H, W, fuse, masked, accumulate=False):
+def _run(dev, nf, ncf, B, H, W, fuse, masked, accumulate=False, loss_kind="bce"):
     cfg, Pnp, lay, eng, flat = _setup(dev, nf, ncf, B, H, W, fuse)
+    cfg.rl_swap = loss_kind == "dice"
     x, x1, x2, y = O.synth_batch(B, 1, H, W, 5)
     g = torch.Generator().manual_seed(6)
     eps = torch.randn(B, 6, generator=g)
     consm = (torch.rand(B, 1, H, W, generator=g) > 0.3).float() if masked else None
-    st = eng.elbo_forward(flat, eng.to_nhwc(x2.to(dev)), y.to(dev), consm.to(dev) if masked else None, eps.to(dev), "bce", 1.0, 0.5, True)
+    st = eng.elbo_forward(flat, eng.to_nhwc(x2.to(dev)), y.to(dev), consm.to(dev) if masked else None, eps.to(dev), loss_kind, 1.0, 0.5, True)
     assert (st.get("fused_fcomb") is not None) == fuse
     gflat = torch.full((lay.numel,), 0.25 if accumulate else 0.0, device=dev)  # (alignment pads keep the fill value)
     eng.elbo_backward(flat, gflat, st, accumulate=accumulate)
@@ -81,8 +82,34 @@ def test_fused_accumulates_and_is_bit_reproducible(dev):
         assert (v3[k] - (v1[k] + 0.25)).abs().max().item() <= 1e-6 * v1[k].abs().max().item() + 1e-6, k
 
 
+@pytest.mark.parametrize("nf,ncf", [([64, 64, 64, 64], 3), ([32, 32, 64, 64], 2)], ids=["C64-mid1", "C32-mid0"])
+@pytest.mark.parametrize("masked", [True, False])
+def test_fused_dice_equals_per_op_path_and_oracle(dev, nf, ncf, masked):
+    """The Dice criterion (rl_swap=True: every LIVECell / MitoEM script; recalled torch_em definition, parity unpinned) through the
+    fused kernel - two launches, the ratio is global - against the per-op path (dot, dice_sums, dice_bwd, ...) and the oracle's
+    restatement of the same definition: logits, loss, every gradient."""
+    B, H, W = 2, 40, 24
+    cfg, Pnp, lay, st_f, g_f, (x2, y, consm, eps) = _run(dev, nf, ncf, B, H, W, True, masked, loss_kind="dice")
+    _, _, _, st_u, g_u, _ = _run(dev, nf, ncf, B, H, W, False, masked, loss_kind="dice")
+    assert (st_f["logits"] - st_u["logits"]).abs().max().item() < 2e-5
+    np.testing.assert_allclose(st_f["rec"].item(), st_u["rec"].item(), rtol=1e-5)
+    vf, vu = lay.views(g_f), lay.views(g_u)
+    for k in vf:
+        a, b = vf[k], vu[k]
+        assert torch.isfinite(a).all(), k
+        assert (a - b).abs().max().item() <= 5e-5 * b.abs().max().item() + 1e-9, k
+    P = O.to_torch(Pnp, requires_grad=True)
+    lo, aux = O.training_loss(P, cfg, x2, y, consm, eps, reg_weight=0.0)
+    go = O.grads_of(0.5 * lo, P)
+    np.testing.assert_allclose(st_f["rec"].item(), aux["reconstruction_loss"].item(), rtol=2e-4)
+    for k, ref in go.items():
+        if k.startswith("fcomb."):
+            e = (vf[k].cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-8)
+            assert e < 2e-3, (k, e)
+
+
 def test_unsupported_configurations_use_the_per_op_path(dev):
-    """Two middle layers (the reference's default no_convs_fcomb = 4) and the Dice criterion keep the per-op kernels."""
+    """Two middle layers (the reference's default no_convs_fcomb = 4) keep the per-op kernels."""
     cfg, Pnp, lay, eng, flat = _setup(dev, [32, 64, 64, 64], 4, 1, 32, 32, True)
     x, x1, x2, y = O.synth_batch(1, 1, 32, 32, 5)
     eps = torch.zeros(1, 6)
@@ -90,4 +117,4 @@ def test_unsupported_configurations_use_the_per_op_path(dev):
     assert st.get("fused_fcomb") is None
     cfg, Pnp, lay, eng, flat = _setup(dev, [32, 64, 64, 64], 3, 1, 32, 32, True)
     st = eng.elbo_forward(flat, eng.to_nhwc(x2.to(dev)), y.to(dev), None, eps.to(dev), "dice", 1.0, 1.0, True)
-    assert st.get("fused_fcomb") is None
+    assert st.get("fused_fcomb") is not None  # (round 3: the Dice criterion runs through the fused kernel too)

@@ -209,3 +209,30 @@ def test_native_runtime_in_the_fp16_operand_modes(dev, monkeypatch, mode):
     assert np.isfinite(res["native"][0]) and res["python"][0] == res["native"][0]
     for a, b in zip(res["python"][1:], res["native"][1:]):
         assert torch.equal(a, b)
+
+
+def test_native_runtime_with_the_dice_criterion(dev, monkeypatch):
+    """rl_swap=True - what every LIVECell / MitoEM script of the reference builds: the Mean-Teacher step through the native runtime
+    (punet_rt_set_criterion) equals the Python engine's, bit for bit."""
+    import copy
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    nf, B, H, W, n = [64, 64, 96, 128], 2, 64, 96, 4
+    x, x1, x2, y = [t.to(dev) for t in O.synth_batch(B, 1, H, W, 0)]
+    g = torch.Generator().manual_seed(5)
+    eps_n, eps_s = torch.randn(n, B, 6, generator=g).to(dev), torch.randn(1, B, 6, generator=g).to(dev)
+    res = {}
+    for rtm in ("python", "native"):
+        monkeypatch.setenv("PUNET_RUNTIME", rtm)
+        m = ProbabilisticUnet(1, 1, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=True, device=dev, seed=1)
+        t = copy.deepcopy(m)
+        assert FU.native_ok(m, t) == (rtm == "native")
+        opt = FusedAdam(m, lr=1e-3)
+        for it in range(2):
+            loss, ys, zs, _ = FU.fused_self_training_step(m, t, opt, x1, x2, n, True, eps_pl=eps_n, eps_s=eps_s)
+        torch.cuda.synchronize()
+        res[rtm] = (float(loss), m.flat_params.clone(), t.flat_params.clone(), ys.clone(), zs.clone())
+    assert np.isfinite(res["native"][0]) and 0.0 < res["native"][0] and res["python"][0] == res["native"][0]
+    for a, b in zip(res["python"][1:], res["native"][1:]):
+        assert torch.equal(a, b)
