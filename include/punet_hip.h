@@ -436,6 +436,19 @@ int punet_rt_self_training_step(PunetRt* rt, float* student, float* labeller, fl
                                 const float* eps_pl, int N, const float* eps_s, float upper, float lower, int masking, int use_consensus,
                                 float beta, float reg_weight, float adam_beta1, float adam_beta2, float adam_eps, float* y, float* z,
                                 float* scalars, const PunetRtHooks* hooks, void* arena, size_t arena_bytes, void* stream);
+/* the other trainers, one call per iteration each: supervised (PUNetTrainer / PseudoTrainerPUNet, punet_trainer.py:24-36,
+ * punet_target_trainer.py:105-118; z nullable; scalars[3] = {rec, kl, reg}) and joint (AdaMTTrainer / AdaMatchTrainer,
+ * adamt_trainer.py:89-128, adamatch_trainer.py:62-107: source + target ELBO at scale 1/2 each, one optimizer step;
+ * scalars[5] = {rec_src, kl_src, rec_tgt, kl_tgt, reg}) */
+int punet_rt_supervised_step(PunetRt* rt, float* model, float* gflat, float* exp_avg, float* exp_avg_sq, double* hstate, float* hyper,
+                             const float* x, const float* y, const float* z, int B, int H, int W, const float* eps, float beta,
+                             float reg_weight, float adam_beta1, float adam_beta2, float adam_eps, float* scalars,
+                             const PunetRtHooks* hooks, void* arena, size_t arena_bytes, void* stream);
+int punet_rt_joint_step(PunetRt* rt, float* student, float* labeller, float* gflat, float* exp_avg, float* exp_avg_sq, double* hstate,
+                        float* hyper, int ema, const float* xs, const float* ys, int Bs, const float* xt1, const float* xt2, int B, int H,
+                        int W, const float* eps_sup, const float* eps_pl, int N, const float* eps_s, float upper, float lower, int masking,
+                        int use_consensus, float beta, float reg_weight, float adam_beta1, float adam_beta2, float adam_eps, float* y,
+                        float* z, float* scalars, const PunetRtHooks* hooks, void* arena, size_t arena_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -136,6 +136,9 @@ _SIGS.update({
     "punet_rt_pseudo_labels": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _f, _f, _i, _p, _p, _p, _p, _sz, _p]),
     "punet_rt_elbo_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _p, _p, _p, AFTER_UNET_CB, _p, _p, _sz, _p]),
     "punet_rt_l2_reg_grad": (_i, [_p, _p, _p, _f, _p, _p, _sz, _p]),
+    "punet_rt_supervised_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _f, _f, _f, _f, _f, _p, _p, _p, _sz, _p]),
+    "punet_rt_joint_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _p, _p, _i, _p, _f, _f, _i, _i, _f, _f,
+                                 _f, _f, _f, _p, _p, _p, _p, _p, _sz, _p]),
     "punet_rt_self_training_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _f, _f, _i, _i, _f, _f, _f, _f,
                                          _f, _p, _p, _p, _p, _p, _sz, _p]),
 })

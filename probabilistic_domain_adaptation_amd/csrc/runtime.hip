@@ -771,3 +771,45 @@ extern "C" int punet_rt_self_training_step(PunetRt* rt, float* student, float* l
     return punet_adam_ema_dev(student, gflat, exp_avg, exp_avg_sq, (ema && labeller != student) ? labeller : nullptr, rt->numel, hyper,
                               adam_beta1, adam_beta2, adam_eps, stream);
 }
+
+// ONE call per supervised iteration (PUNetTrainer / PseudoTrainerPUNet, punet_trainer.py:24-36, punet_target_trainer.py:105-118):
+// ELBO forward / backward on (x, y[, consensus weights z]), regulariser, Adam.  scalars[3] = {reconstruction loss, kl, reg}.
+extern "C" int punet_rt_supervised_step(PunetRt* rt, float* model, float* gflat, float* exp_avg, float* exp_avg_sq, double* hstate,
+                                        float* hyper, const float* x, const float* y, const float* z, int B, int H, int W, const float* eps,
+                                        float beta, float reg_weight, float adam_beta1, float adam_beta2, float adam_eps, float* scalars,
+                                        const PunetRtHooks* hooks, void* arena, size_t arena_bytes, void* stream) {
+    PUNET_CHECK_ARG(rt && model && gflat && exp_avg && exp_avg_sq && hstate && hyper && x && y && eps && scalars && arena,
+                    "punet_rt_supervised_step: null pointer");
+    RT_CALL(punet_rt_elbo_fwd_bwd(rt, model, gflat, x, y, z, eps, B, H, W, beta, 1.f, 0, scalars, scalars + 1, nullptr,
+                                  hooks ? hooks->after_unet : nullptr, hooks ? hooks->ctx : nullptr, arena, arena_bytes, stream));
+    RT_CALL(punet_rt_l2_reg_grad(rt, model, gflat, reg_weight, scalars + 2, arena, arena_bytes, stream));
+    if (hooks && hooks->before_update) hooks->before_update(hooks->ctx);
+    RT_CALL(punet_adam_hyper(hstate, hyper, stream));
+    return punet_adam_ema_dev(model, gflat, exp_avg, exp_avg_sq, nullptr, rt->numel, hyper, adam_beta1, adam_beta2, adam_eps, stream);
+}
+
+// ONE call per joint iteration (AdaMTTrainer / AdaMatchTrainer, adamt_trainer.py:89-128, adamatch_trainer.py:62-107): supervised
+// ELBO on the source batch and self-training ELBO on the target batch at scale 1/2 each (two accumulating gradient passes, one
+// optimizer step), pseudo-labels from `labeller` (the EMA teacher; == student and ema == 0 for AdaMatch).  The EMA rule - constant
+// or AdaMT's warm-up min(1 - 1/(it + 1), m) - lives in hstate.  scalars[5] = {rec_src, kl_src, rec_tgt, kl_tgt, reg};
+// loss = (scalars[0] + beta scalars[1] + scalars[2] + beta scalars[3]) / 2 + reg_weight scalars[4].
+extern "C" int punet_rt_joint_step(PunetRt* rt, float* student, float* labeller, float* gflat, float* exp_avg, float* exp_avg_sq,
+                                   double* hstate, float* hyper, int ema, const float* xs, const float* ys, int Bs, const float* xt1,
+                                   const float* xt2, int B, int H, int W, const float* eps_sup, const float* eps_pl, int N,
+                                   const float* eps_s, float upper, float lower, int masking, int use_consensus, float beta,
+                                   float reg_weight, float adam_beta1, float adam_beta2, float adam_eps, float* y, float* z, float* scalars,
+                                   const PunetRtHooks* hooks, void* arena, size_t arena_bytes, void* stream) {
+    PUNET_CHECK_ARG(rt && student && labeller && gflat && exp_avg && exp_avg_sq && hstate && hyper && xs && ys && xt1 && xt2 && eps_sup &&
+                        eps_pl && eps_s && y && z && scalars && arena, "punet_rt_joint_step: null pointer");
+    RT_CALL(punet_rt_elbo_fwd_bwd(rt, student, gflat, xs, ys, nullptr, eps_sup, Bs, H, W, beta, 0.5f, 0, scalars, scalars + 1, nullptr, nullptr,
+                                  nullptr, arena, arena_bytes, stream));
+    RT_CALL(punet_rt_pseudo_labels(rt, labeller, xt1, B, H, W, eps_pl, N, upper, lower, masking, y, z, nullptr, arena, arena_bytes, stream));
+    RT_CALL(punet_rt_elbo_fwd_bwd(rt, student, gflat, xt2, y, use_consensus ? z : nullptr, eps_s, B, H, W, beta, 0.5f, 1, scalars + 2,
+                                  scalars + 3, nullptr, hooks ? hooks->after_unet : nullptr, hooks ? hooks->ctx : nullptr, arena, arena_bytes,
+                                  stream));
+    RT_CALL(punet_rt_l2_reg_grad(rt, student, gflat, reg_weight, scalars + 4, arena, arena_bytes, stream));  // (reg + reg) / 2
+    if (hooks && hooks->before_update) hooks->before_update(hooks->ctx);
+    RT_CALL(punet_adam_hyper(hstate, hyper, stream));
+    return punet_adam_ema_dev(student, gflat, exp_avg, exp_avg_sq, (ema && labeller != student) ? labeller : nullptr, rt->numel, hyper,
+                              adam_beta1, adam_beta2, adam_eps, stream);
+}

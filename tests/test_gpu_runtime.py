@@ -236,3 +236,53 @@ def test_native_runtime_with_the_dice_criterion(dev, monkeypatch):
     assert np.isfinite(res["native"][0]) and 0.0 < res["native"][0] and res["python"][0] == res["native"][0]
     for a, b in zip(res["python"][1:], res["native"][1:]):
         assert torch.equal(a, b)
+
+
+def test_one_call_supervised_and_joint_steps(dev, monkeypatch):
+    """punet_rt_supervised_step / punet_rt_joint_step (AdaMT with its warm-up EMA momentum from the device counter) as single
+    library calls against the fused Python steps."""
+    import copy
+    from probabilistic_domain_adaptation_amd import _lib
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    nf, B, H, W, n = [32, 64, 64, 96], 2, 32, 64, 4
+    xs, _, _, ys = [t.to(dev) for t in O.synth_batch(B, 1, H, W, 11)]
+    x, x1, x2, y = [t.to(dev) for t in O.synth_batch(B, 1, H, W, 12)]
+    g = torch.Generator().manual_seed(6)
+    e_sup, e_pl, e_s = torch.randn(1, B, 6, generator=g).to(dev), torch.randn(n, B, 6, generator=g).to(dev), torch.randn(1, B, 6, generator=g).to(dev)
+    S = torch.cuda.current_stream().cuda_stream
+    monkeypatch.setenv("PUNET_RUNTIME", "python")
+    ma = _model(dev, nf); ta = copy.deepcopy(ma); oa = FusedAdam(ma, lr=1e-3)
+    for it in range(2):
+        la, ya, za = FU.fused_joint_step(ma, ta, oa, xs, ys, x1, x2, n, True, e_sup, e_pl, e_s, 0.999, True, 1e-5, it)
+    ms = _model(dev, nf, seed=2); os_ = FusedAdam(ms, lr=1e-3)
+    ls = FU.fused_supervised_step(ms, os_, x2, y, None, e_s, 1e-5)
+    # ---- the same through single library calls
+    mb = _model(dev, nf); tb = copy.deepcopy(mb); ob = FusedAdam(mb, lr=1e-3)
+    rt = mb.native_runtime()
+    ar = rt.arena(max(rt.arena_bytes(B, H, W, n, True), rt.arena_bytes(B, H, W, n, False)))
+    yb, zb, sc = torch.empty(B, 1, H, W, device=dev), torch.empty(B, 1, H, W, device=dev), torch.zeros(5, device=dev)
+    eng = mb.engine
+    for it in range(2):
+        want = ob.sync_device_state(0.999, 1.0, it)  # AdaMT: momentum min(1 - 1/(it + 1), 0.999), evaluated on the device
+        _lib.call("punet_rt_joint_step", rt._h, mb.flat_params.data_ptr(), tb.flat_params.data_ptr(), ob.grad_flat.data_ptr(),
+                  ob.exp_avg.data_ptr(), ob.exp_avg_sq.data_ptr(), ob.hstate.data_ptr(), ob.hyper.data_ptr(), 1, eng.to_nhwc(xs).data_ptr(),
+                  ys.data_ptr(), B, eng.to_nhwc(x1).data_ptr(), eng.to_nhwc(x2).data_ptr(), B, H, W, e_sup.data_ptr(), e_pl.data_ptr(), n,
+                  e_s.data_ptr(), 0.9, 0.1, 1, 1, 1.0, 1e-5, 0.9, 0.999, 1e-8, yb.data_ptr(), zb.data_ptr(), sc.data_ptr(), None,
+                  ar.data_ptr(), ar.numel(), S)
+        ob._advance_mirrors(want)
+    mt = _model(dev, nf, seed=2); ot = FusedAdam(mt, lr=1e-3)
+    rt2 = mt.native_runtime()
+    ar2 = rt2.arena(rt2.arena_bytes(B, H, W, 1, True))
+    sc2 = torch.zeros(3, device=dev)
+    want = ot.sync_device_state(0.0, 1.0, None)
+    _lib.call("punet_rt_supervised_step", rt2._h, mt.flat_params.data_ptr(), ot.grad_flat.data_ptr(), ot.exp_avg.data_ptr(),
+              ot.exp_avg_sq.data_ptr(), ot.hstate.data_ptr(), ot.hyper.data_ptr(), mt.engine.to_nhwc(x2).data_ptr(), y.data_ptr(), None,
+              B, H, W, e_s.data_ptr(), 1.0, 1e-5, 0.9, 0.999, 1e-8, sc2.data_ptr(), None, ar2.data_ptr(), ar2.numel(), S)
+    ot._advance_mirrors(want)
+    torch.cuda.synchronize()
+    assert torch.equal(ma.flat_params, mb.flat_params) and torch.equal(ta.flat_params, tb.flat_params)
+    assert torch.equal(ya, yb) and torch.equal(za, zb)
+    assert abs(float(la) - float(0.5 * (sc[0] + sc[1] + sc[2] + sc[3]) + 1e-5 * sc[4])) <= 1e-6 * abs(float(la))
+    assert torch.equal(ms.flat_params, mt.flat_params)
+    assert abs(float(ls) - float(sc2[0] + sc2[1] + 1e-5 * sc2[2])) <= 1e-6 * abs(float(ls))
