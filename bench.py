@@ -206,7 +206,7 @@ class Runner:
         self.it += 1
 
 
-def timed_region(runner, steps, graph, sync, world, dev):
+def timed_region(runner, steps, graph, sync, dp, dev):
     """EXACTLY `steps` steps between two barriers + synchronisations; returns (seconds, max over ranks; host enqueue
     seconds; per-step GPU milliseconds)."""
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]  # per-step GPU timeline (diagnostic)
@@ -219,7 +219,7 @@ def timed_region(runner, steps, graph, sync, world, dev):
     t_enq = time.perf_counter() - t0  # host time to enqueue the K steps (the GPU runs behind; must stay below dt)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -266,8 +266,18 @@ def main():
                     help="HIP-event brackets in the instrumented region: only the roofline kernel's launches (default; 73 per "
                          "step) or every MFMA launch (adds ~1 ms of bubbles per step)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI; the default) or gloo (rehearsal on one GPU)")
+    ap.add_argument("--rehearse-rccl", action="store_true",
+                    help="one-GPU rehearsal of the data-parallel path over the REAL backend: a one-rank RCCL group with the trainers' "
+                         "world size forced to 2 (one-rank collectives are the identity; the gradient scale is 1/2), so that every "
+                         "data-parallel code path of this file and of the fused steps runs through ProcessGroupNCCL; not a measurement")
     a = ap.parse_args()
 
+    # stdout carries the ONE JSON line and nothing else: native libraries write to file descriptor 1 behind Python's back (RCCL
+    # prints a version banner there when its first communicator is built), so fd 1 is pointed at stderr for the whole run and
+    # the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     if a.runtime:
         os.environ["PUNET_RUNTIME"] = a.runtime
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -278,7 +288,15 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)  # gloo rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    dp = world > 1 or a.rehearse_rccl
+    if a.rehearse_rccl:
+        if world != 1 or a.backend != "nccl":
+            raise SystemExit("--rehearse-rccl is a single-process run over the nccl (= RCCL) backend")
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_PORT=str(sk.getsockname()[1]))
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # "nccl" == RCCL on ROCm
@@ -288,13 +306,15 @@ def main():
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
-    if world > 1:
+    if dp:
         dist.barrier()
     from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    if a.rehearse_rccl:
+        FU._world = lambda: 2
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -312,7 +332,7 @@ def main():
             print("[bench] " + graph_note, file=sys.stderr)
             use_graph = False
             FU._CAPTURE = None
-        if world > 1:
+        if dp:
             # Data parallel: the capture is cut at the gradient all-reduces and the collectives run eagerly between the segment
             # replays.  Before that path is trusted with the measurement it must reproduce the eager step bit for bit, from the
             # same state and latent draws, on every rank (one extra eager + one replayed step; the state is restored in between).
@@ -333,12 +353,12 @@ def main():
             use_graph = use_graph and graph_selfcheck
     for _ in range(a.warmup):
         run.step(use_graph)
-    comm = [] if world > 1 else None
+    comm = [] if dp else None
     FU.COMM_EVENTS = comm  # HIP events around the exposed part of the gradient all-reduce (rank-local)
-    comm_host = [0.0] if world > 1 else None
+    comm_host = [0.0] if dp else None
     FU.COMM_HOST_S = comm_host  # host seconds inside the collective calls of the timed region
     # ---- the timed region: K steps, barrier + synchronize on both sides, max over ranks
-    dt, t_enq, ms_each = timed_region(run, a.steps, use_graph, sync, world, dev)
+    dt, t_enq, ms_each = timed_region(run, a.steps, use_graph, sync, dp, dev)
     FU.COMM_EVENTS = None
     FU.COMM_HOST_S = None
     exposed_ms = None
@@ -347,7 +367,7 @@ def main():
     # ---- data parallel: the replicas must still be bit-identical after the timed steps (same initial weights, summed gradients,
     # rank-local Adam / EMA on identical inputs): MIN and MAX over ranks of exact digests of the student and the teacher
     replicas = None
-    if world > 1:
+    if dp:
         digests = [Runner.checksum(run.model.flat_params)] + ([Runner.checksum(run.teacher.flat_params)] if run.teacher is not None else [])
         cdev = dev if a.backend == "nccl" else "cpu"
         lo = torch.tensor(digests, dtype=torch.int64, device=cdev)
@@ -371,7 +391,7 @@ def main():
         run.step(False)  # the first use of ~1000 events in a process costs tens of ms: not in the measured steps
         sync()
         prof.clear()
-        dt_eager, t_enq_eager, ms_each_eager = timed_region(run, a.steps, False, sync, world, dev)
+        dt_eager, t_enq_eager, ms_each_eager = timed_region(run, a.steps, False, sync, dp, dev)
         for e in run.engines:
             e.prof = None
 
@@ -395,7 +415,7 @@ def main():
                                    f"{H}x{W}x{a.channels} patches, batch {B}/GPU, N={N} MC samples, Adam lr 1e-5, EMA 0.999",
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "launch": "hipGraph replay of the captured fused step (one graph launch per step"
-                                 + (f"; {len(run.graphed.segments)} segments cut at the gradient all-reduces)" if world > 1 else ")")
+                                 + (f"; {len(run.graphed.segments)} segments cut at the gradient all-reduces)" if dp else ")")
                                  if use_graph else (graph_note or ("eager: ~500 kernel launches per step, issued by the native runtime inside "
                                                                     "4-5 library calls" if FU.native_ok(run.model)
                                                                     else "eager: ~500 kernel launches per step from Python")),
@@ -407,7 +427,10 @@ def main():
                        "host_enqueue_ms_per_step": round(1e3 * t_enq / a.steps, 2),
                        "ms_each_step": ms_each},
         }
-        if world > 1:
+        if dp:
+            if a.rehearse_rccl:
+                out["rehearsal"] = ("NOT a data-parallel measurement: ONE GPU, a one-rank RCCL group with the trainers' world size forced "
+                                    "to 2 (identity collectives, gradient scale 1/2) - the data-parallel code path over the real backend")
             out["replicas_identical"] = replicas["identical"]
             out["world_size_seen"] = dist.get_world_size()
             out["config"]["distributed"] = {
@@ -503,7 +526,7 @@ def main():
                                    "timing": "HIP events on the launch stream around every launch of the kernel, live in this run, "
                                              "over the K eagerly launched steps of config.instrumented_eager_region"}
             out["kernels"] = kernels
-        if not a.no_other_configs and world == 1 and a.workload == "mean_teacher" and (B, H, W, a.channels) == (4, 512, 512, 1):
+        if not a.no_other_configs and not dp and a.workload == "mean_teacher" and (B, H, W, a.channels) == (4, 512, 512, 1):
             # BASELINE.json configs[2] / configs[3] per GPU, timed in this same process (short: 2 warm-up + 5 steps each)
             others = []
             del run
@@ -518,7 +541,7 @@ def main():
                         g2ok, FU._CAPTURE = False, None
                 for _ in range(2):
                     r2.step(g2ok)
-                d2, e2, each2 = timed_region(r2, 5, g2ok, sync, world, dev)
+                d2, e2, each2 = timed_region(r2, 5, g2ok, sync, dp, dev)
                 g2 = gflop_per_patch(wl, N, size, size, ch)
                 others.append({"workload": f"{wl} (BASELINE.json configs[{2 if wl == 'adamt' else 3}], per GPU): {B} source + {B} target "
                                            f"patches {size}x{size}x{ch} per step, N={N}",
@@ -540,7 +563,7 @@ def main():
                         g3ok, FU._CAPTURE = False, None
                 for _ in range(2):
                     r3.step(g3ok)
-                d3, e3, each3 = timed_region(r3, 5, g3ok, sync, world, dev)
+                d3, e3, each3 = timed_region(r3, 5, g3ok, sync, dp, dev)
                 tf3 = gf * B * 5 / d3 / 1e3
                 out["config"]["fast_mode_f16x3"] = {
                     "workload": "the headline Mean-Teacher step in the f16x3 arithmetic (two fp16 planes per operand, per-tensor power-of-two "
@@ -552,10 +575,11 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as ex:  # never lose the headline to an extra
                 out["config"]["fast_mode_f16x3"] = {"error": f"{type(ex).__name__}: {ex}"}
-        if not a.no_cpu_baseline and world == 1 and not a.dice:
+        if not a.no_cpu_baseline and not dp and not a.dice:
             out["cpu_baseline"] = cpu_baseline(a.workload, N, H, W)
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(out) + "\n").encode())
+    if dp:
         dist.barrier()
         dist.destroy_process_group()
         if not replicas["identical"] or not replicas["weights_moved"]:

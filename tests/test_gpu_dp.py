@@ -144,3 +144,78 @@ def test_mean_teacher_fit_two_ranks(tmp_path):
     assert files == ["best.pt", "latest.pt"], files
     ck = torch.load(os.path.join(str(tmp_path), "checkpoints", "dp", "latest.pt"), weights_only=False)
     assert ck["epoch"] == 2 and ck["iteration"] == 4 and "teacher_state" in ck
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the REAL backend of the 8-GPU run (RCCL through ProcessGroupNCCL: its own stream, event hand-over, async work handles) on
+# the one GPU of the box: a one-rank group, with the trainers' world size forced to 2 so that every data-parallel code path
+# runs (the U-Net slice's asynchronous all-reduce under the encoders' backward, the remainder before the update, the graph
+# cut at both).  A one-rank all-reduce is the identity, so the step must equal the single-process step at gradient scale 1/2.
+def _rccl_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    import copy
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    from oracle import punet_oracle as O
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    x, x1, x2, y = [v.to(dev) for v in O.synth_batch(2, 1, 32, 32, 3)]
+    g = torch.Generator().manual_seed(2)
+    e_pl, e_s = torch.randn(4, 2, 6, generator=g).to(dev), torch.randn(1, 2, 6, generator=g).to(dev)
+
+    def run(graph, steps=3):
+        m, opt = _setup_model(dev)
+        t = copy.deepcopy(m)
+        body = lambda s: FU.fused_self_training_step(m, t, opt, s["x1"], s["x2"], 4, True, s["eps_pl"], s["eps_s"], 0.99, 1e-5)
+        inp = {"x1": x1.clone(), "x2": x2.clone(), "eps_pl": e_pl.clone(), "eps_s": e_s.clone()}
+        if graph:
+            gs = FU.GraphedStep(body, inp, opt, ema=True, ema_momentum=0.99, extra_state=[t.flat_params])
+            nseg = len(gs.segments)
+            for _ in range(steps):
+                out = gs.step()
+        else:
+            nseg = 0
+            for _ in range(steps):
+                out = body(inp)
+        torch.cuda.synchronize()
+        return m.flat_params.cpu().numpy(), t.flat_params.cpu().numpy(), float(out[0]), nseg
+
+    # (a) no process group: the single-process step with the 1/2 scale forced in by hand
+    real_world = FU._world
+    FU._world = lambda: 2
+    calls = []
+    real_allreduce = dist.all_reduce
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def identity(t, op=None, async_op=False):
+        calls.append(t.numel())
+        return _Done() if async_op else None
+    dist.all_reduce = identity
+    want = run(False)
+    dist.all_reduce = real_allreduce
+    # (b) the same through RCCL, eagerly and as graph segments with the collectives between them
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    eager = run(False)
+    graphed = run(True)
+    FU._world = real_world
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((want, eager, graphed, calls))
+
+
+def test_rccl_backend_one_rank_group_eager_and_graph_segments():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    want, eager, graphed, calls = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    assert len(calls) == 6 and calls[0] + calls[1] == calls[2] + calls[3]  # two collectives per step: U-Net slice + remainder
+    assert graphed[3] == 3, "the capture is cut at both all-reduces"
+    for got in (eager, graphed):
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]
