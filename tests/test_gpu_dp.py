@@ -151,7 +151,7 @@ def test_mean_teacher_fit_two_ranks(tmp_path):
 # the one GPU of the box: a one-rank group, with the trainers' world size forced to 2 so that every data-parallel code path
 # runs (the U-Net slice's asynchronous all-reduce under the encoders' backward, the remainder before the update, the graph
 # cut at both).  A one-rank all-reduce is the identity, so the step must equal the single-process step at gradient scale 1/2.
-def _rccl_worker(port, q):
+def _rccl_worker(port, q, save_root):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
     import copy
     dev = torch.device("cuda:0")
@@ -199,23 +199,39 @@ def _rccl_worker(port, q):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     eager = run(False)
     graphed = run(True)
+    # (c) the control plane of fit() over the same backend (state broadcast, metric / loss all-reduce on device tensors, loader
+    # sharding, rank-0 checkpoints): two epochs of a real trainer complete and leave finite replicas
+    from probabilistic_domain_adaptation_amd.my_trainer import MeanTeacherTrainer, default_trainer as DT
+    real_dp_world = DT.dp_world
+    DT.dp_world = lambda: 2
+    m, opt = _setup_model(dev)
+    data = [O.synth_batch(2, 1, 32, 32, 200 + i) for i in range(4)]
+    tr = MeanTeacherTrainer(name="rccl", train_loader=data, val_loader=data, model=m, optimizer=opt, device=dev, do_consensus_masking=True,
+                            save_root=save_root, shard_loaders=True)
+    tr.n_samples = 4
+    best = tr.fit(epochs=2)
+    torch.cuda.synchronize()
+    fit = (len(tr.train_loader), opt.step_count, bool(torch.isfinite(m.flat_params).all()), bool(np.isfinite(best)))
+    DT.dp_world = real_dp_world
     FU._world = real_world
     dist.barrier()
     dist.destroy_process_group()
-    q.put((want, eager, graphed, calls))
+    q.put((want, eager, graphed, calls, fit))
 
 
-def test_rccl_backend_one_rank_group_eager_and_graph_segments():
+def test_rccl_backend_one_rank_group_eager_and_graph_segments(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q, str(tmp_path)))
     p.start()
-    want, eager, graphed, calls = q.get(timeout=600)
+    want, eager, graphed, calls, fit = q.get(timeout=600)
     p.join(120)
     assert p.exitcode == 0
     assert len(calls) == 6 and calls[0] + calls[1] == calls[2] + calls[3]  # two collectives per step: U-Net slice + remainder
     assert graphed[3] == 3, "the capture is cut at both all-reduces"
     for got in (eager, graphed):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]
+    assert fit == (2, 4, True, True), fit  # half of the 4 batches per epoch (rank 0 of "2"), two epochs
+    assert sorted(os.listdir(os.path.join(str(tmp_path), "checkpoints", "rccl"))) == ["best.pt", "latest.pt"]
