@@ -12,7 +12,7 @@ python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_mfma -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-kernel-timing > $out/pmc_mfma_bench.json 2> $out/pmc_mfma.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-kernel-timing > /dev/null 2> $out/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-kernel-timing > /dev/null 2> $out/pmc_write.err
-for w in "--workload punet_source" "--workload fixmatch" "--workload inference --batch 1 --size 1024 --samples 16" "--workload mean_teacher --samples 16" "--conv-mode f16x3" "--conv-mode f16" "--conv-mode f16s" "--conv-mode x3" "--conv-mode bf16" "--conv-mode bf16s" "--conv-mode f16x3 --workload inference --batch 1 --size 1024 --samples 16" "--conv-mode f16s --workload inference --batch 1 --size 1024 --samples 16" "--conv-mode bf16s --workload inference --batch 1 --size 1024 --samples 16" "--conv-mode f32 --steps 4 --warmup 1"; do
+for w in "--dice" "--rehearse-rccl" "--workload punet_source" "--workload fixmatch" "--workload inference --batch 1 --size 1024 --samples 16" "--workload mean_teacher --samples 16" "--conv-mode f16x3" "--conv-mode f16" "--conv-mode f16s" "--conv-mode x3" "--conv-mode bf16" "--conv-mode bf16s" "--conv-mode f16x3 --workload inference --batch 1 --size 1024 --samples 16" "--conv-mode f16s --workload inference --batch 1 --size 1024 --samples 16" "--conv-mode bf16s --workload inference --batch 1 --size 1024 --samples 16" "--conv-mode f32 --steps 4 --warmup 1"; do
   echo "== $w" >> $out/other_workloads.jsonl
   timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-other-configs $w 2>/dev/null | tail -1 >> $out/other_workloads.jsonl
 done
