@@ -1119,12 +1119,13 @@ __global__ __launch_bounds__(256) void split_weights_x6_batch_kernel(const float
 // the slab's power-of-two scale (common.h); same [plane][t'][k/8][n][8] layout and placement as the bf16 planes (16-bit
 // elements), plane 2 unused.  A unit of the amax pass is 8 CONSECUTIVE floats of the slab (any partition does for a maximum).
 __global__ __launch_bounds__(256) void slab_amax_batch_kernel(const float* __restrict__ flat, const long* __restrict__ table, int nconv,
-                                                              float* __restrict__ wamax) {
+                                                              float* __restrict__ wamax, long per) {
     // every block owns a CONTIGUOUS range of units (so that it touches one slab, rarely two or three): per-thread running
     // maxima, published when the slab changes and at the end - a few atomics per block instead of one per wave and round
     // (42 hot addresses: contended atomics serialise at the memory side)
+    // `per` is ODD (host): with 2,048 units = 64 KB per block all blocks read the same offset of their ranges at the same time,
+    // i.e. addresses 64 KB apart - a handful of the memory channels - and the pass ran at 1.4 TB/s
     const long total = table[(size_t)nconv * 4 + 3];
-    const long per = (total + gridDim.x - 1) / gridDim.x;
     const long u0 = (long)blockIdx.x * per, u1 = u0 + per < total ? u0 + per : total;
     if (u0 >= u1) return;  // (block-uniform)
     int lo = 0, hi = nconv - 1;  // slab of the block's first unit
@@ -1260,7 +1261,9 @@ extern "C" int punet_split_weights_f16_batch(const float* flat, void* planes, co
             punet_set_error("punet_split_weights_f16_batch: memset failed");
             return PUNET_ERR_HIP;
         }
-        slab_amax_batch_kernel<<<total_units / 2048 < 2048 ? (int)(total_units / 2048 + 1) : 2048, 256, 0, st>>>(flat, table, nconv, wamax);
+        const int ablocks = total_units / 2048 < 2048 ? (int)(total_units / 2048 + 1) : 2048;
+        const long per = ((total_units + ablocks - 1) / ablocks) | 1;
+        slab_amax_batch_kernel<<<ablocks, 256, 0, st>>>(flat, table, nconv, wamax, per);
         PUNET_LAUNCH_CHECK("slab_amax_batch");
     }
     split_weights_f16_batch_kernel<<<(int)grid, 256, 0, st>>>(flat, (__bf16*)planes, table, nconv, mode, wamax);
