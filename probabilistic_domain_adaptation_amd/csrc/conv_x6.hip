@@ -572,6 +572,9 @@ __device__ unsigned long long punet_x6b_trace[4 * 16];  // top barrier passed, o
 #ifndef X6B_PIN_SPLIT
 #define X6B_PIN_SPLIT 1
 #endif
+#ifndef X6B_PLANE_IN
+#define X6B_PLANE_IN 0
+#endif
 #ifndef X6B_VECTOR_WAVE  // 1 = the wave index as a VGPR value (the form before round 2's scalar wave index), for A/B runs
 #define X6B_VECTOR_WAVE 0
 #endif
@@ -588,7 +591,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     // With a pitch of 48 the taps of one column kx are 0 mod 16 apart, and so are the two image buffers.
     constexpr int HTWP = 48;
     constexpr int NPIXA = (HTH - 1) * HTWP + HTW;  // 466 units per plane
+#if X6B_PLANE_IN  // TIMING-ONLY experiment (wrong results): activations arrive as NP stored 16-bit planes (plane-major, NHWC, x0 / x1
+                  // point at plane 0, plane p is B*H*W*c elements further): a staging unit = one {pixel, plane} = 16 bytes, no split
+    constexpr int XUNITS = NPIX * NP;
+#else
     constexpr int XUNITS = NPIX * (CK / 4);
+#endif
     constexpr int XITER = (XUNITS + 255) / 256;
     constexpr int WSLAB = 12 * TN;   // per plane: 12 slots of one {tap, 8 channels} row (64 output channels x 16 bytes)
     constexpr int XBUF = (NP * NPIXA + 15) / 16 * 16;  // one activation image (NP planes); two of them, by chunk parity
@@ -667,20 +675,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 #pragma unroll
         for (int it = 0; it < XITER; ++it) {
             const int u = min(tid + it * 256, XUNITS - 1);
+#if X6B_PLANE_IN
+            const int pix = u % NPIX;
+#else
             const int pix = u / (CK / 4);
+#endif
             const int py = pix / HTW, px = pix % HTW;
             const int gy = ti.ty0 + py - PAD, gx = ti.tx0 + px - PAD;
             xin[it] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             xpix[it] = min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1);  // inside image xb (32-bit); the image
         }                                                                          // base is a uniform 64-bit term
+#if X6B_PLANE_IN == 2
+        xbase0 = reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.x0) + (size_t)ti.b * ((size_t)(a.H * a.W) * 8));
+        xbase1 = reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.x1) + (size_t)ti.b * ((size_t)(a.H * a.W) * 8));
+#elif X6B_PLANE_IN
+        xbase0 = reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.x0) + (size_t)ti.b * ((size_t)(a.H * a.W) * a.c0));
+        xbase1 = reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.x1) + (size_t)ti.b * ((size_t)(a.H * a.W) * a.c1));
+#else
         xbase0 = a.x0 + (size_t)ti.b * ((size_t)(a.H * a.W) * a.c0);
         xbase1 = a.x1 + (size_t)ti.b * ((size_t)(a.H * a.W) * a.c1);
+#endif
         wlane = (unsigned)((a.n_off + min(ti.n0 + lane, N - 1)) * 8);  // columns beyond N copy column N - 1 (never stored)
     };
     auto load_x = [&](int ch, int it) __attribute__((always_inline)) -> float4 {
         const int kbase = ch * CK;
         const int cs = kbase < a.c0 ? a.c0 : a.c1, coff = kbase < a.c0 ? kbase : kbase - a.c0;
         const float* src = kbase < a.c0 ? xbase0 : xbase1;  // uniform image base (SGPR pair) + 32-bit lane offset
+#if X6B_PLANE_IN
+        {
+            const int pl = min(tid + it * 256, XUNITS - 1) / NPIX;
+            const __bf16* sp = reinterpret_cast<const __bf16*>(src) + (size_t)pl * ((size_t)a.B * a.H * a.W * cs);
+#if X6B_PLANE_IN == 2  // chunk-major planes [plane][c / 8][B][H][W][8]: a tile row of one chunk and plane is contiguous
+            return *reinterpret_cast<const float4*>(sp + ((size_t)(coff >> 3) * ((size_t)a.B * a.H * a.W) + (unsigned)xpix[it]) * 8);
+#else
+            return *reinterpret_cast<const float4*>(sp + (unsigned)(xpix[it] * cs + coff));  // NHWC planes: 8 channels of one plane
+#endif
+        }
+#endif
         const int q = min(tid + it * 256, XUNITS - 1) % (CK / 4);
 #if X6B_TIMING & 2
         return make_float4((float)(xpix[it] & 7), 1.f, (float)q, (float)(coff & 3));
@@ -696,6 +727,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     };
     bf16x4 px[XITER][NP];
     auto split_unit = [&](int it) __attribute__((always_inline)) {
+#if X6B_PLANE_IN
+        return;
+#endif
         const float4 r = xin[it] ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);
         uint2 ph_, pm, pl = make_uint2(0u, 0u);
         if constexpr (F16) splitf16_quad<NP>(r, sx, ph_, pm); else split3_quad<NP>(r, ph_, pm, pl);
@@ -719,6 +753,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 #pragma unroll
         for (int it = 0; it < XITER; ++it) {
             const int u = min(tid + it * 256, XUNITS - 1);
+#if X6B_PLANE_IN
+            {
+                const int pl = u / NPIX, pix = u % NPIX;
+                const int lpix = (pix / HTW) * HTWP + pix % HTW;
+                const float4 r = xin[it] ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (tid + it * 256 < XUNITS) *reinterpret_cast<float4*>(&sXc[pl * NPIXA + lpix]) = r;
+                continue;
+            }
+#endif
             const int q = u % (CK / 4), pix = u / (CK / 4);
             const int lpix = (pix / HTW) * HTWP + pix % HTW;
 #pragma unroll

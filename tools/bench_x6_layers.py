@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--slices-div", type=int, default=1, help="divide the split-K slice count of the weight gradient")
     ap.add_argument("--bits", type=int, default=1, help="1: input gradient gated by bits; 0: by the fp32 activation")
+    ap.add_argument("--plane-in", action="store_true",
+                    help="operands of the forward / input-gradient kernels as three stored bf16 planes (6 bytes per element, plane-major): "
+                         "ONLY with a library built with -DX6B_PLANE_IN=1 (timing-only experiment); the weight gradient is skipped")
     a = ap.parse_args()
     S = torch.cuda.current_stream().cuda_stream
     B = a.batch
@@ -45,8 +48,13 @@ def main():
     print(f"{'shape':22s} {'fwd TF':>8s} {'dgrad TF':>9s} {'wgrad TF':>9s}   ms: fwd dgrad wgrad")
     for c0, c1, cout, hw, nf_, nb_ in SHAPES:
         cin = c0 + c1
-        x0 = torch.randn(B, hw, hw, c0, device="cuda")
-        x1 = torch.randn(B, hw, hw, c1, device="cuda") if c1 else None
+        if a.plane_in:  # planes of post-ReLU-like data: h = bf16(v), m / l = the next 8 + 8 bits' worth of magnitude
+            mk = lambda c: torch.stack([t_ * s_ for t_, s_ in zip(torch.randn(3, B, hw, hw, c, device="cuda").unbind(0),
+                                                                   (1.0, 2.0 ** -8, 2.0 ** -16))]).bfloat16()
+            x0, x1 = mk(c0), (mk(c1) if c1 else None)
+        else:
+            x0 = torch.randn(B, hw, hw, c0, device="cuda")
+            x1 = torch.randn(B, hw, hw, c1, device="cuda") if c1 else None
         w = torch.randn(3, 3, cin, cout, device="cuda") * 0.05
         b = torch.randn(cout, device="cuda")
         nw = 9 * cin * cout
@@ -55,7 +63,7 @@ def main():
         L.call("punet_split_weights_x6", w.data_ptr(), pf.data_ptr(), nw, cin, cout, 3, 0, S)
         L.call("punet_split_weights_x6", w.data_ptr(), pd.data_ptr(), nw, cin, cout, 3, 1, S)
         y = torch.empty(B, hw, hw, cout, device="cuda")
-        dz = torch.randn(B, hw, hw, cout, device="cuda")
+        dz = mk(cout) if a.plane_in else torch.randn(B, hw, hw, cout, device="cuda")
         dx = torch.zeros(B, hw, hw, c0, device="cuda")
         dw = torch.empty(3, 3, cin, cout, device="cuda")
         db = torch.empty(cout, device="cuda")
@@ -80,6 +88,9 @@ def main():
               "wgrad": 2.0 * B * hw * hw * c0 * cout * 9}
         ms = {}
         for name, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
+            if a.plane_in and name == "wgrad":
+                ms[name] = float("nan")
+                continue
             fn()
             torch.cuda.synchronize()
             ms[name] = timeit(fn, a.rounds)
@@ -88,7 +99,7 @@ def main():
             tot_fl[name] += n * fl[name]
         print(f"{c0:4d}+{c1:<4d}->{cout:<4d}@{hw:<4d} " + " ".join(f"{fl[k] / ms[k] / 1e9:9.1f}" for k in ms) + "   " +
               " ".join(f"{ms[k]:.3f}" for k in ms), flush=True)
-    print("per MT step (weighted): " + "  ".join(f"{k} {tot_ms[k]:.2f} ms @ {tot_fl[k] / tot_ms[k] / 1e9:.1f} TF" for k in tot_ms))
+    print("per MT step (weighted): " + "  ".join(f"{k} {tot_ms[k]:.2f} ms @ {tot_fl[k] / tot_ms[k] / 1e9:.1f} TF" for k in tot_ms if tot_ms[k] > 0))
 
 
 if __name__ == "__main__":
