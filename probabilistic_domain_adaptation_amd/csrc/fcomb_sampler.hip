@@ -35,7 +35,7 @@ struct SamplerArgs {
     float* z;            // [P] consensus (nullable)
     float* logits;       // [N][P] (nullable)
     long wmid_stride, bmid_stride;  // elements between consecutive middle layers
-    int N, B, HW, nmid, masking, ntiles;
+    int N, B, HW, nmid, masking, ntiles, tpi;  // tpi = tiles per image = ceil(HW / 32)
     float upper, lower;
 };
 
@@ -64,8 +64,12 @@ __global__ __launch_bounds__(256) void fcomb_sampler_kernel(SamplerArgs a) {
     const size_t P = (size_t)a.B * a.HW;
 
     for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += gridDim.x * 4) {
-        const size_t pix = (size_t)tile * 32 + l31;
-        const int b = (int)(((size_t)tile * 32) / a.HW);
+        // tiles never straddle images (z differs per image): image b, 32 pixels from p0; the last tile of an image whose H * W is
+        // not a multiple of 32 is ragged - its dead lanes recompute the image's last pixel and store nothing
+        const int b = tile / a.tpi;
+        const int pl = (tile - b * a.tpi) * 32 + l31;
+        const bool live = pl < a.HW;
+        const size_t pix = (size_t)b * a.HW + (live ? pl : a.HW - 1);
 
         // ---- feature term, once per pixel: T1[co][pix] = sum_k W1[k][co] * F[pix][k]
         // k slot of half h in step (g, e) is channel 8g + 4h + e (A and B use the same bijection)
@@ -130,12 +134,12 @@ __global__ __launch_bounds__(256) void fcomb_sampler_kernel(SamplerArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) part = fmaf(ha[cb][r], sW3[cb * 32 + mfma32_row(r, half)], part);
             const float logit = part + __shfl_xor(part, 32) + b3;
-            if (a.logits && half == 0) a.logits[(size_t)n * P + pix] = logit;
+            if (a.logits && half == 0 && live) a.logits[(size_t)n * P + pix] = logit;
             const float s = 1.f / (1.f + expf(-logit));
             ysum += s;
             cnt += (s >= a.upper || s <= a.lower) ? 1.f : 0.f;
         }
-        if (half == 0) {
+        if (half == 0 && live) {
             if (a.y) a.y[pix] = ysum / (float)a.N;
             if (a.z) {
                 const float c = cnt / (float)a.N;
@@ -234,8 +238,12 @@ __global__ __launch_bounds__(256, PUNET_K7X_WGS) void fcomb_sampler_x6_kernel(Sa
     };
 
     for (int tile = blockIdx.x * 4 + wave; tile < a.ntiles; tile += gridDim.x * 4) {
-        const size_t pix = (size_t)tile * 32 + l31;
-        const int b = (int)(((size_t)tile * 32) / a.HW);
+        // tiles never straddle images (z differs per image): image b, 32 pixels from p0; the last tile of an image whose H * W is
+        // not a multiple of 32 is ragged - its dead lanes recompute the image's last pixel and store nothing
+        const int b = tile / a.tpi;
+        const int pl = (tile - b * a.tpi) * 32 + l31;
+        const bool live = pl < a.HW;
+        const size_t pix = (size_t)b * a.HW + (live ? pl : a.HW - 1);
 
         // ---- feature term, once per pixel: T1[co][pix] = sum_k W1[k][co] * F[pix][k]
         f32x16 t1[NBLK];
@@ -316,12 +324,12 @@ __global__ __launch_bounds__(256, PUNET_K7X_WGS) void fcomb_sampler_x6_kernel(Sa
 #pragma unroll
                 for (int r = 0; r < 16; ++r) part = fmaf(ha[cb][r], sW3[cb * 32 + mfma32_row(r, half)], part);
             const float logit = part + __shfl_xor(part, 32) + b3;
-            if (a.logits && half == 0) a.logits[(size_t)n * P + pix] = logit;
+            if (a.logits && half == 0 && live) a.logits[(size_t)n * P + pix] = logit;
             const float s = 1.f / (1.f + expf(-logit));
             ysum += s;
             cnt += (s >= a.upper || s <= a.lower) ? 1.f : 0.f;
         }
-        if (half == 0) {
+        if (half == 0 && live) {
             if (a.y) a.y[pix] = ysum / (float)a.N;
             if (a.z) {
                 const float c = cnt / (float)a.N;
@@ -339,12 +347,13 @@ static int fcomb_sample_launch(bool x6, int f16, const float* feat, const float*
     PUNET_CHECK_ARG(feat && w1 && zb && w3 && b3, "punet_fcomb_sample: null pointer");
     PUNET_CHECK_ARG(CH == 32 || CH == 64, "punet_fcomb_sample: num_filters[0] must be 32 or 64 (got %d)", CH);
     PUNET_CHECK_ARG(nmid >= 0 && nmid <= 4 && (nmid == 0 || (wmid && bmid)), "punet_fcomb_sample: bad nmid %d", nmid);
-    PUNET_CHECK_ARG(N > 0 && B > 0 && HW > 0 && HW % 32 == 0, "punet_fcomb_sample: H*W must be a multiple of 32 (got %d)", HW);
+    PUNET_CHECK_ARG(N > 0 && B > 0 && HW > 0, "punet_fcomb_sample: bad shape (N %d, B %d, H*W %d)", N, B, HW);
     SamplerArgs a{};
     a.feat = feat; a.w1 = w1; a.zb = zb; a.wmid = wmid; a.bmid = bmid; a.wmid_stride = wmid_stride; a.bmid_stride = bmid_stride; a.w3 = w3; a.b3 = b3;
     a.y = y; a.z = z; a.logits = logits;
     a.N = N; a.B = B; a.HW = HW; a.nmid = nmid; a.masking = masking;
-    a.ntiles = (int)(((size_t)B * HW) / 32);
+    a.tpi = (HW + 31) / 32;
+    a.ntiles = B * a.tpi;
     a.upper = upper; a.lower = lower;
     // fp32 kernel: fp32 weights in LDS; x6 kernel: three bf16 planes per weight (6 B instead of 4 B per element)
     const size_t shmem = x6 ? ((size_t)CH * CH * (1 + nmid) * 6 + ((size_t)nmid * CH + CH) * sizeof(float))

@@ -603,7 +603,7 @@ extern "C" int punet_rt_pseudo_labels(PunetRt* rt, const float* flat, const floa
                                       void* stream) {
     PUNET_CHECK_ARG(rt && flat && x && eps && arena && (y || logits) && (!y == !z), "punet_rt_pseudo_labels: null pointer");
     PUNET_CHECK_ARG(rt->d_x6, "punet_rt_pseudo_labels: punet_rt_init_tables has not run");
-    PUNET_CHECK_ARG(B > 0 && N > 0 && (H * W) % 32 == 0, "punet_rt_pseudo_labels: bad shape (H * W must be a multiple of 32)");
+    PUNET_CHECK_ARG(B > 0 && N > 0 && H > 0 && W > 0, "punet_rt_pseudo_labels: bad shape");
     Arena dry{DRY_BASE, (size_t)-1};  // first walk: sizes only, nothing is launched
     RT_CALL(pseudo_labels_body(rt, flat, x, B, H, W, eps, N, upper, lower, masking, y, z, logits, dry, true, stream));
     PUNET_CHECK_ARG(dry.used <= arena_bytes, "punet_rt_pseudo_labels: the arena holds %zu bytes, this call needs %zu (punet_rt_arena_bytes)",

@@ -240,7 +240,7 @@ class ProbabilisticUnet(nn.Module):
         (the forward state - unet_features, prior_latent_space - is then NOT kept: use forward() for that), else the engine."""
         from ..my_trainer.fused import native_ok
         x = self.engine.to_nhwc(patch)
-        if native_ok(self) and (x.shape[1] * x.shape[2]) % 32 == 0:
+        if native_ok(self):
             return self.native_runtime().pseudo_labels(self._flat, x, self._eps(n_samples, x.shape[0], eps), upper, lower, masking)
         self.forward(patch, None, training=False)
         return self.sample_consensus(n_samples, upper, lower, masking, eps)

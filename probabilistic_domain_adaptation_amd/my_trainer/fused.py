@@ -239,6 +239,12 @@ def native_ok(*models) -> bool:
     return True
 
 
+def native_shape(x) -> bool:
+    """The runtime's gradient pass runs the fused Fcomb training kernel: 32-pixel tiles that must not straddle images (H * W a
+    multiple of 32 - every shape with >= 4 levels); other shapes take the Python engine and its per-op Fcomb path."""
+    return (int(x.shape[-2]) * int(x.shape[-1])) % 32 == 0
+
+
 def _dp_hook(gflat, n, started):
     """after_unet callback of a data-parallel gradient pass: start the all-reduce of the U-Net slice gflat[:n] asynchronously
     (eagerly between graph segments while a step is being captured)."""
@@ -305,7 +311,7 @@ def elbo_grad_pass(model: ProbabilisticUnet, gflat, x, y, z, eps, gscale: float,
 
 def fused_supervised_step(model, opt: FusedAdam, x, y, z=None, eps=None, reg_weight=1e-5):
     """PUNetTrainer / PseudoTrainerPUNet iteration (punet_trainer.py:24-36, punet_target_trainer.py:105-118)."""
-    if native_ok(model):
+    if native_ok(model) and native_shape(x):
         return fused_supervised_step_native(model, opt, x, y, z, eps, reg_weight)
     eng = model.engine
     rec, kl, st = elbo_grad_pass(model, opt.grad_flat, x, y, z, eps, 1.0, False, overlap=True)
@@ -320,7 +326,7 @@ def fused_self_training_step(model, teacher, opt: FusedAdam, x1, x2, n_samples: 
                              momentum: Optional[float] = 0.999, reg_weight=1e-5, source_distribution=None):
     """Mean-Teacher iteration (teacher = EMA copy, mean_teacher_trainer.py:101-131) or FixMatch iteration
     (teacher is the model itself and momentum is None, fixmatch_trainer.py:67-95)."""
-    if native_ok(model, teacher):
+    if native_ok(model, teacher) and native_shape(x2):
         return fused_self_training_step_native(model, teacher, opt, x1, x2, n_samples, masking, eps_pl, eps_s, momentum, reg_weight,
                                                source_distribution)
     eng = model.engine
@@ -413,7 +419,7 @@ def fused_joint_step(model, teacher, opt: FusedAdam, xs, ys, xt1, xt2, n_samples
     loss = (supervised + target) / 2 with ONE optimizer step; two gradient passes at scale 0.5 accumulate.
     momentum = the EMA momentum (cap); warmup_iteration = the trainer's iteration `it` for AdaMT's rule
     min(1 - 1/(it + 1), momentum) (adamt_trainer.py:41), evaluated on the device."""
-    if native_ok(model, teacher):
+    if native_ok(model, teacher) and native_shape(xt2):
         return fused_joint_step_native(model, teacher, opt, xs, ys, xt1, xt2, n_samples, masking, eps_sup, eps_pl, eps_s, momentum,
                                        use_consensus, reg_weight, warmup_iteration)
     eng = model.engine

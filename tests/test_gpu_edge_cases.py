@@ -71,6 +71,50 @@ def test_smallest_and_ragged_shapes_match_oracle(model, B, H, W, n):
     assert (ym.cpu() - probs.mean(0)).abs().max() < 1e-4
 
 
+@pytest.mark.parametrize("B,H,W,n", [(2, 12, 12, 3), (1, 20, 28, 2), (3, 4, 4, 1)])
+def test_three_level_shapes_whose_pixel_count_is_not_a_multiple_of_32(B, H, W, n):
+    """With three levels a patch only has to be a multiple of 4: H * W = 144, 560, 16.  The MC sampler's 32-pixel tiles end ragged
+    at every image (dead lanes store nothing), the training path takes the per-op Fcomb kernels, and the trainers' fused step
+    takes the Python engine instead of the native runtime (whose gradient pass needs whole tiles): pseudo-labels against the
+    oracle and through both graph walkers, one Mean-Teacher iteration against the oracle's."""
+    import copy
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda:0")
+    nf = [32, 64, 96]
+    cfg = O.PUNetConfig(1, 1, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    Pnp = O.synth_params(cfg.spec(), 12)
+    m = ProbabilisticUnet(1, 1, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in Pnp.items()})
+    _, x1, x2, _ = O.synth_batch(B, 1, H, W, 77)
+    g = torch.Generator().manual_seed(4)
+    e_t, e_s = torch.randn(n, B, 6, generator=g), torch.randn(1, B, 6, generator=g)
+    Po = O.to_torch(Pnp)
+    with torch.no_grad():
+        yo, zo = O.sample_consensus(Po, cfg, x1, e_t, masking=True)
+        y_rt, z_rt = m.pseudo_labels(x1.to(dev), n, 0.9, 0.1, True, e_t.to(dev))          # the native runtime
+        m.forward(x1.to(dev), None, training=False)
+        y_en, z_en = m.sample_consensus(n, 0.9, 0.1, True, e_t.to(dev))                    # the Python engine
+    torch.cuda.synchronize()
+    assert FU.native_ok(m) and not FU.native_shape(x1) or (H * W) % 32 == 0
+    assert torch.equal(y_rt, y_en) and torch.equal(z_rt, z_en)
+    assert tuple(y_rt.shape) == (B, 1, H, W)
+    assert (y_rt.cpu() - yo).abs().max().item() < 1e-4 and int((z_rt.cpu() != zo).sum()) == 0
+    t = copy.deepcopy(m)
+    opt = FusedAdam(m, lr=1e-3)
+    loss, y, z, _ = FU.fused_self_training_step(m, t, opt, x1.to(dev), x2.to(dev), n, True, e_t.to(dev), e_s.to(dev), 0.99, 1e-5)
+    torch.cuda.synchronize()
+    Ps, Pt = O.to_torch(Pnp, True), O.to_torch(Pnp)
+    ref = O.mean_teacher_step(Ps, Pt, cfg, O.AdamState(Ps, lr=1e-3), x1, x2, e_t, e_s[0], True, momentum=0.99)
+    np.testing.assert_allclose(float(loss), ref["loss"].item(), rtol=2e-4)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    for k, v in Ps.items():
+        assert (sd[k] - v.detach()).abs().max().item() <= 2.5e-3, k  # (Adam's first step: sign(g) * lr; 2 lr where g is ~0)
+
+
 @pytest.mark.parametrize("nf,H,W,latent,nfc,C", [
     ([32, 40, 72, 104], 40, 56, 6, 3, 1),      # multiples of 8, not of 32: the 32x32x16 kernels
     ([32, 64, 128, 192], 32, 32, 6, 4, 1),     # the reference's constructor defaults (probabilistic_unet.py:227-237)

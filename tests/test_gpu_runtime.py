@@ -26,14 +26,32 @@ def _model(dev, nf, C=1, nfc=3, latent=6, seed=1, rl_swap=False):
     return m
 
 
-@pytest.mark.parametrize("nf,C,nfc,latent,B,H,W", [([32, 64, 64, 96], 1, 3, 6, 2, 32, 64), ([64, 40, 72], 3, 2, 2, 1, 24, 40),
-                                                    ([32, 32, 64, 64, 96], 2, 3, 6, 2, 48, 80)],
-                         ids=["nf4", "depth3_rgb_fcomb2_latent2", "depth5_two_channels"])
-def test_native_runtime_equals_python_engine_bit_for_bit(dev, nf, C, nfc, latent, B, H, W):
+def _random_configs(count, seed=2024):
+    """Seeded draws from the configuration class the runtime covers (runtime.supported): depth, widths, input channels, Fcomb depth,
+    latent size, batch, patch shape, arithmetic and criterion all vary together."""
+    import random
+    r = random.Random(seed)
+    out = []
+    for i in range(count):
+        levels = r.choice([3, 4, 4, 5])
+        nf = [r.choice([32, 64])] + [8 * r.randint(2, 12) for _ in range(levels - 1)]
+        q = 2 ** (levels - 1)
+        H, W = q * r.randint(2, 5), q * r.randint(2, 6)
+        out.append(pytest.param(nf, r.randint(1, 4), r.choice([2, 3]), r.choice([2, 4, 6]), r.randint(1, 3), H, W,
+                                r.choice(["x6", "x6", "f16x3", "f16"]), r.choice(["bce", "dice"]), id=f"random{i}"))
+    return out
+
+
+@pytest.mark.parametrize("nf,C,nfc,latent,B,H,W,mode,crit",
+                         [pytest.param([32, 64, 64, 96], 1, 3, 6, 2, 32, 64, "x6", "bce", id="nf4"),
+                          pytest.param([64, 40, 72], 3, 2, 2, 1, 24, 40, "x6", "bce", id="depth3_rgb_fcomb2_latent2"),
+                          pytest.param([32, 32, 64, 64, 96], 2, 3, 6, 2, 48, 80, "x6", "bce", id="depth5_two_channels")] + _random_configs(10))
+def test_native_runtime_equals_python_engine_bit_for_bit(dev, nf, C, nfc, latent, B, H, W, mode, crit):
     from probabilistic_domain_adaptation_amd.runtime import NativeRuntime
-    m = _model(dev, nf, C, nfc, latent)
+    m = _model(dev, nf, C, nfc, latent, rl_swap=crit == "dice")
+    m.set_conv_mode(mode)
     eng, flat = m.engine, m.flat_params
-    rt = NativeRuntime(m.layout, dev)
+    rt = NativeRuntime(m.layout, dev, conv_mode=mode, dice=crit == "dice")
     assert [e[:3] for e in rt.entries()] == [e[:3] for e in m.layout.entries] and rt.unet_numel == m.layout.unet_numel
     x, x1, x2, y = [t.to(dev) for t in O.synth_batch(B, C, H, W, 7)]
     g = torch.Generator().manual_seed(3)
@@ -47,9 +65,12 @@ def test_native_runtime_equals_python_engine_bit_for_bit(dev, nf, C, nfc, latent
     yr, zr, lr = rt.pseudo_labels(flat, eng.to_nhwc(x1), eps_n, 0.9, 0.1, True, want_logits=True)
     torch.cuda.synchronize()
     assert torch.equal(ye, yr) and torch.equal(ze, zr) and torch.equal(le, lr)
-    used = rt_used = None
+    if (H * W) % 32:  # the gradient pass needs whole 32-pixel tiles per image: refused loudly, the trainers take the Python engine
+        with pytest.raises(RuntimeError, match="multiple of 32"):
+            rt.elbo_fwd_bwd(flat, torch.zeros_like(flat), eng.to_nhwc(x2), y, consm, eps_s, 1.0, 0.5, False)
+        return
     # ---- student path: loss scalars, logits, every gradient; then the accumulate form on top
-    st = eng.elbo_forward(flat, eng.to_nhwc(x2), y, consm, eps_s, "bce", 1.0, 0.5, True)
+    st = eng.elbo_forward(flat, eng.to_nhwc(x2), y, consm, eps_s, crit, 1.0, 0.5, True)
     SENT = 12345.678  # (the flat buffer has alignment pads nobody writes: a NaN fill would defeat torch.equal)
     ge = torch.full_like(flat, SENT)
     eng.elbo_backward(flat, ge, st, False)
@@ -63,7 +84,7 @@ def test_native_runtime_equals_python_engine_bit_for_bit(dev, nf, C, nfc, latent
     assert torch.isfinite(gr).all() and torch.equal(ge, gr)
     for k, v in m.layout.views(gr).items():
         assert not (v == SENT).any(), k  # every gradient tensor was written
-    eng.elbo_backward(flat, ge, eng.elbo_forward(flat, eng.to_nhwc(x1), y, None, eps_s, "bce", 1.0, 0.5, True), True)
+    eng.elbo_backward(flat, ge, eng.elbo_forward(flat, eng.to_nhwc(x1), y, None, eps_s, crit, 1.0, 0.5, True), True)
     rt.elbo_fwd_bwd(flat, gr, eng.to_nhwc(x1), y, None, eps_s, 1.0, 0.5, True)
     torch.cuda.synchronize()
     assert torch.equal(ge, gr)
