@@ -1,5 +1,7 @@
 """GPU: edge cases of the model surface - the error behaviour the reference has (or the explicit error this build raises
 where the reference would fail later), smallest sizes, batch 1, a single MC sample, ragged (non multiple-of-32) widths."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -143,6 +145,31 @@ def test_constructor_space_in_f16x3(nf, H, W, latent, nfc, C):
     parity arithmetic: amax slots through fused and unfused pooling, up-sampling, concat convolutions with two sources, the
     accumulate path of skip connections, first-layer publications, other depths."""
     _constructor_case(nf, H, W, latent, nfc, C, "f16x3", fuse_pool=nf[0] != 16)
+
+
+def _random_constructor_cases(count, seed=31):
+    """Seeded draws over the WHOLE constructor space the layout accepts (not only what the native runtime covers): first widths
+    from 8 to 128, 2 ... 5 levels, 1 ... 6 input channels, Fcomb 2 ... 4, latent 1 ... 8, patch shapes down to one pixel at the
+    bottom, parity arithmetic or f16x3."""
+    import random
+    r = random.Random(seed)
+    out = []
+    for i in range(count):
+        levels = r.choice([2, 3, 4, 4, 5])
+        nf = [r.choice([8, 16, 32, 64, 128])] + [8 * r.randint(1, 10) for _ in range(levels - 1)]
+        q = 2 ** (levels - 1)
+        lo = max(1, 4 // q)  # (the synthetic batch blurs with a reflected 2-pixel border: at least 4 pixels)
+        out.append(pytest.param(nf, q * r.randint(lo, 5), q * r.randint(lo, 6), r.randint(1, 8), r.choice([2, 3, 4]), r.randint(1, 6),
+                                r.choice([None, None, "f16x3"]), id=f"random{i}"))
+    return out
+
+
+_FUZZ = [int(v) for v in os.environ.get("PUNET_FUZZ", "12:31").split(":")]  # count:seed (more draws: PUNET_FUZZ=60:7 pytest -k random)
+
+
+@pytest.mark.parametrize("nf,H,W,latent,nfc,C,mode", _random_constructor_cases(*_FUZZ))
+def test_random_constructor_cases_against_oracle(nf, H, W, latent, nfc, C, mode):
+    _constructor_case(nf, H, W, latent, nfc, C, mode)
 
 
 def _constructor_case(nf, H, W, latent, nfc, C, conv_mode, fuse_pool=True):
