@@ -248,6 +248,34 @@ def test_predict_image_reference_geometry_against_oracle_tiling(case, dev):
     assert pred.shape == img.shape and np.abs(pred - ref).max() < 1e-4
 
 
+def _random_tilings(count, seed=77):
+    import random
+    r = random.Random(seed)
+    out = []
+    for i in range(count):
+        while True:
+            bh, bw, hh, hw = r.choice([24, 40, 64, 104]), r.choice([24, 40, 64, 104]), r.choice([0, 4, 8, 12, 16]), r.choice([0, 4, 8, 12, 16])
+            if (bh + 2 * hh) % 8 == 0 and (bw + 2 * hw) % 8 == 0:
+                break
+        out.append(pytest.param(r.randint(9, 230), r.randint(9, 230), bh, bw, hh, hw, r.choice([1, 2, 5]), r.choice([1, 3]), id=f"random{i}"))
+    return out
+
+
+@pytest.mark.parametrize("H,W,bh,bw,hh,hw,tile_batch,n", _random_tilings(8))
+def test_predict_image_random_geometries_against_oracle_tiling(case, dev, H, W, bh, bw, hh, hw, tile_batch, n):
+    """Image sizes that are no multiple of anything (down to images smaller than one block or one halo), blocks and halos of
+    different sizes per axis, tile batches that do not divide the number of tiles: the blocking, the per-block reflect padding,
+    the per-tile standardisation and the halo crop against the oracle's tiling."""
+    from probabilistic_domain_adaptation_amd.my_predictions import predict_image
+    m = _model(case, dev)
+    img = (np.random.default_rng(H * 1000 + W).normal(size=(H, W)) * 20 + 90).astype("float32")
+    nt = -(-H // bh) * -(-W // bw)
+    eps = torch.randn(nt, n, L, generator=torch.Generator().manual_seed(H + W))
+    ref = O.tiled_prediction(O.to_torch(case["Pnp"]), case["cfg"], img, [eps[t][:, None] for t in range(nt)], (bh, bw), (hh, hw))
+    pred = predict_image(m, img, prior_samples=n, block_shape=(bh, bw), halo=(hh, hw), tile_batch=tile_batch, eps=eps)
+    assert pred.shape == img.shape and np.abs(pred - ref).max() < 1e-4
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_two_classes_facade_and_mean_teacher_step(dev, fused):
     """num_classes = 2 with two input channels (no reference script uses it; `two_classes.npz` pins the model level against the
