@@ -7,8 +7,22 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+import os
+import random
+
 CASES = [(1, 8, 32, 8, 0, 32), (2, 16, 16, 64, 0, 64), (1, 24, 40, 32, 0, 96), (2, 8, 8, 128, 0, 128),
          (1, 16, 32, 64, 32, 32), (1, 64, 64, 96, 64, 64), (1, 4, 4, 192, 0, 160)]
+
+
+def _random_cases(count, seed):
+    """Seeded draws over the shapes the C ABI accepts: any image size from one pixel up, channel counts that are multiples of 8
+    (one or two sources), batch 1-3 (PUNET_FUZZ_X6=count:seed widens them)."""
+    r = random.Random(seed)
+    return [(r.randint(1, 3), r.randint(1, 50), r.randint(1, 70), 8 * r.randint(1, 20), r.choice([0, 0, 8 * r.randint(1, 12)]),
+             8 * r.randint(1, 24)) for _ in range(count)]
+
+
+CASES += _random_cases(*[int(v) for v in os.environ.get("PUNET_FUZZ_X6", "8:5").split(":")])
 
 
 @pytest.fixture(scope="module")
