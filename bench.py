@@ -336,14 +336,19 @@ def main():
             # Data parallel: the capture is cut at the gradient all-reduces and the collectives run eagerly between the segment
             # replays.  Before that path is trusted with the measurement it must reproduce the eager step bit for bit, from the
             # same state and latent draws, on every rank (one extra eager + one replayed step; the state is restored in between).
+            # (the self-check runs steps with collectives inside: every rank must enter it or none - agree on the capture first)
+            cdev0 = dev if a.backend == "nccl" else "cpu"
+            t = torch.tensor([1.0 if use_graph else 0.0], device=cdev0)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            all_captured = bool(t.item() == 1.0)
             ok = 0.0
-            if use_graph:
+            if all_captured:
                 try:
                     ok = 1.0 if run.graph_matches_eager() else 0.0
                 except Exception as ex:
                     print(f"[bench] graph self-check raised {type(ex).__name__}: {ex}", file=sys.stderr)
                     FU._CAPTURE = None
-            t = torch.tensor([ok], device=dev if a.backend == "nccl" else "cpu")
+            t = torch.tensor([ok], device=cdev0)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             graph_selfcheck = bool(t.item() == 1.0)
             if use_graph and not graph_selfcheck:
