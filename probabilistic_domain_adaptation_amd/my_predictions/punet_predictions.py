@@ -147,3 +147,37 @@ def punet_pseudo_prediction(input_image_path, output_pred_path, model, prior_sam
         imageio.imwrite(dir1 + name, mypred)
         imageio.imwrite(dir2 + name, consensus)
         print(f"{name}'s predictions saved")
+
+
+# ---- tiled prediction of a plain model (prob_utils/my_predictions/unet_predictions.py:12-43) ---------------------------------------
+class _PlainModelAsMC:
+    """Adapter that lets predict_image() drive any callable model: one forward per tile batch, no latent draws."""
+
+    def __init__(self, model):
+        self.model = model
+        self.device = getattr(model, "device", None) or next(model.parameters()).device
+        self.num_classes = getattr(model, "num_classes", 1)
+
+    def pseudo_labels(self, raw, n_samples, *a, eps=None, **k):
+        return self.model(raw), None
+
+
+def unet_predict_image(model, image: np.ndarray, block_shape=(384, 384), halo=(64, 64), tile_batch: int = 4) -> np.ndarray:
+    """predict_with_halo(input_, model, block_shape=(384, 384), halo=(64, 64)) of unet_predictions.py:24-31 for a model that
+    maps a standardised [B, 1, h, w] tile to [B, K, h, w] (this package's `Unet`, my_models/unet.py): same blocking, reflect
+    padding, per-tile standardisation and halo crop as predict_image; returns the model's raw output map(s), squeezed."""
+    return predict_image(_PlainModelAsMC(model), image, prior_samples=1, block_shape=block_shape, halo=halo, tile_batch=tile_batch)
+
+
+@torch.no_grad()
+def unet_prediction(input_path: str, output_path: str, model, device: str = "cuda"):
+    """Reference signature (unet_predictions.py:12-43); the reference drives torch_em's UNet2d through it (third-party, out of
+    scope) - here any model with the `Unet` forward surface."""
+    imageio = _imageio()
+    model.eval()
+    os.makedirs(output_path, exist_ok=True)
+    for img_path in glob(input_path):
+        pred = unet_predict_image(model, imageio.imread(img_path)).squeeze()
+        out = os.path.join(output_path, f"{os.path.basename(img_path)[:-4]}.tif")
+        imageio.imwrite(out, pred, compression="zlib")
+        print(f"Saved image at '{out}'")

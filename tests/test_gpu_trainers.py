@@ -226,6 +226,30 @@ def test_plain_unet_config0(golden_dir, dev):
     assert np.abs(y.cpu().numpy() - fx["logits"]).max() < 1e-3
 
 
+def test_plain_unet_tiled_prediction(dev):
+    """unet_prediction's per-image body (unet_predictions.py:24-31) for the plain Unet: blocking, reflect padding, per-tile
+    standardisation and halo crop against the same tiling built from the oracle's plain U-Net forward."""
+    from probabilistic_domain_adaptation_amd.my_models import Unet
+    from probabilistic_domain_adaptation_amd.my_predictions import unet_predict_image
+    nf = [32, 64, 64]
+    spec = O.plain_unet_spec(1, 1, nf)
+    Pnp = O.synth_params(spec, 9)
+    m = Unet(1, 1, nf, device=dev, seed=0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in Pnp.items()})
+    img = (np.random.default_rng(3).normal(size=(150, 93)) * 20 + 90).astype("float32")
+    block, halo = (64, 40), (16, 12)
+    P = O.to_torch(Pnp)
+    ref = np.zeros(img.shape, dtype="float32")
+    with torch.no_grad():
+        for y0, y1, x0, x1 in O.halo_tiles(img.shape, block, halo):
+            tile = O.standardize_np(O.load_halo_block(img, y0, x0, block, halo))
+            out = O.plain_unet_forward(P, torch.from_numpy(tile)[None, None], len(nf))[0, 0].numpy()
+            ref[y0:y1, x0:x1] = out[halo[0]:halo[0] + (y1 - y0), halo[1]:halo[1] + (x1 - x0)]
+    for tb in (1, 3):
+        got = unet_predict_image(m, img, block, halo, tile_batch=tb)
+        assert got.shape == img.shape and np.abs(got - ref).max() < 1e-3 * max(1.0, np.abs(ref).max())
+
+
 def test_plain_unet_three_classes_three_channels(dev):
     """Unet(3, 3, ...): the 1x1 last layer with num_classes > 1 against the oracle's plain Unet."""
     from probabilistic_domain_adaptation_amd.my_models import Unet
