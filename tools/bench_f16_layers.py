@@ -33,14 +33,24 @@ def main():
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
+    ap.add_argument("--plane-in", action="store_true",
+                    help="operands as two STORED fp16 planes (h = fp16 of the scaled value, l = the residual; same 4 bytes per element as "
+                         "fp32): ONLY with a library built with -DX6B_PLANE_IN=2 and two-plane variants (timing-only experiment)")
+    ap.add_argument("--variants", default="x6,x3,bf16,f16x3,f16x3-noamax,f16",
+                    help="(a library built with -DX6B_PLANE_IN reads NP x 2 bytes per element from these fp32 buffers: leave x6 out)")
     a = ap.parse_args()
     S = torch.cuda.current_stream().cuda_stream
     B = a.batch
-    variants = ["x6", "x3", "bf16", "f16x3", "f16x3-noamax", "f16"]
+    variants = a.variants.split(",")
     kinds = a.kinds.split(",")
     tot = {(k, v): [0.0, 0.0] for k in kinds for v in variants}
     for c0, c1, cout, hw, nf_, nb_ in SHAPES:
         cin = c0 + c1
+        def planes(t):  # [2][...]: h, l of t * 2^k (amax at 2^14) as fp16, reinterpreted as the fp32 buffer the entry points expect
+            sc = 2.0 ** (14 - int(torch.floor(torch.log2(t.abs().max())).item()))
+            h = (t * sc).half()
+            l = (t * sc - h.float()).half()
+            return torch.stack([h, l]).contiguous().view(torch.float32)
         x0 = torch.relu(torch.randn(B, hw, hw, c0, device="cuda"))
         x1 = torch.relu(torch.randn(B, hw, hw, c1, device="cuda")) if c1 else None
         w = torch.randn(3, 3, cin, cout, device="cuda") * 0.05
@@ -70,6 +80,8 @@ def main():
         for i, t in enumerate([x0, x1, dz]):
             if t is not None:
                 L.call("punet_amax", t.data_ptr(), t.numel(), slots.data_ptr() + 4 * i, 0, S)
+        if a.plane_in:
+            x0, x1, dz = planes(x0), (planes(x1) if c1 else None), planes(dz)
         sp = lambda i: slots.data_ptr() + 4 * i
         row = f"{c0:4d}+{c1:<4d}->{cout:<4d}@{hw:<4d}"
         for kind in kinds:
