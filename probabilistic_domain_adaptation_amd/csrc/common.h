@@ -149,9 +149,22 @@ __device__ __forceinline__ void punet_amax_publish_block256(float* slot, float t
     if (threadIdx.x == 0) punet_amax_atomic(slot, fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3])));
 }
 
-// scaled fp32 -> fp16 planes h (+ l) of a PAIR of values (v_pk_mul_f32, v_cvt_pk_f16_f32, one v_pk_fma_f32 for the residual)
+// scaled fp32 -> fp16 planes h (+ l) of a PAIR of values: four mixed-precision fmas (v_fma_mixlo / mixhi_f16: fp32 fma, result
+// rounded into one half of the destination; the residual reads h straight from its fp16 half) instead of v_pk_mul_f32 +
+// v_cvt_pk_f16_f32 + 2 x v_cvt_f32_f16 + v_pk_fma_f32 + v_cvt_pk_f16_f32.  Same values bit for bit (s is a power of two: a * s is
+// exact) except that a * s = -0 gives h = +0.
 template <int NP>
 __device__ __forceinline__ void splitf16_pair(float a, float b, float s, unsigned& h, unsigned& l) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PUNET_NO_FMA_MIX)
+    if (NP > 1) {  // (one plane: the packed multiply + packed conversion below is as short and has no half-register dependency)
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a), "v"(s));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(b), "v"(s));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "v"(s), "v"(h));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "v"(s), "v"(h));
+        return;
+    }
+#endif
+    {
     const punet_f32x2 x = {a * s, b * s};
     const punet_f16x2 h2 = __builtin_convertvector(x, punet_f16x2);
     h = __builtin_bit_cast(unsigned, h2);
@@ -159,6 +172,7 @@ __device__ __forceinline__ void splitf16_pair(float a, float b, float s, unsigne
     if (NP > 1) {
         const punet_f32x2 r = x - __builtin_convertvector(h2, punet_f32x2);
         l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, punet_f16x2));
+    }
     }
 }
 template <int NP>

@@ -730,9 +730,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 #if X6B_PLANE_IN
         return;
 #endif
-        const float4 r = xin[it] ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);
         uint2 ph_, pm, pl = make_uint2(0u, 0u);
-        if constexpr (F16) splitf16_quad<NP>(r, sx, ph_, pm); else split3_quad<NP>(r, ph_, pm, pl);
+        if constexpr (F16) {
+            // outside the image the SCALE is zero (one select instead of four on the values: the clamped address holds a finite
+            // activation, its planes come out as signed zeros)
+            splitf16_quad<NP>(rx[it], xin[it] ? sx : 0.f, ph_, pm);
+        } else {
+            const float4 r = xin[it] ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+            split3_quad<NP>(r, ph_, pm, pl);
+        }
 #if X6B_PIN_SPLIT
         // the planes are only needed by the NEXT commit: without a use here the optimiser sinks the whole split behind the
         // chunk's last MFMA (a ~75-instruction vector blob in front of the barrier) instead of leaving it in their shadow
