@@ -548,7 +548,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
             const uint2 h = in ? make_uint2(__builtin_bit_cast(unsigned, r.x), __builtin_bit_cast(unsigned, r.y)) : make_uint2(0u, 0u);
             *reinterpret_cast<uint2*>(sX + off) = h;
         } else {
-            put_planes(sX, XIMGR, off, in ? r : make_float4(0.f, 0.f, 0.f, 0.f), sxs);
+            if constexpr (F16) put_planes(sX, XIMGR, off, r, in ? sxs : 0.f);  // zero SCALE outside the image: one select, not four
+            else put_planes(sX, XIMGR, off, in ? r : make_float4(0.f, 0.f, 0.f, 0.f), sxs);
         }
     };
     auto load_d = [&](const float* dbp, int gy, int gx_, int c4) __attribute__((always_inline)) -> float4 {
