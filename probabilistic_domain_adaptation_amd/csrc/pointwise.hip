@@ -1195,7 +1195,9 @@ static int chan_slices(int P, int C) {
     return s < 1 ? 1 : (s > 256 ? 256 : s);
 }
 
-extern "C" size_t punet_chan_sum_workspace_floats(int B, int P, int C) { return (size_t)B * chan_slices(P, C) * C; }
+extern "C" size_t punet_chan_sum_workspace_floats(int B, int P, int C) {
+    return B > 0 && P > 0 && C >= 4 ? (size_t)B * chan_slices(P, C) * C : 0;  // (0 for a shape punet_chan_sum would refuse)
+}
 
 extern "C" int punet_chan_sum(const float* x, float* out, float* workspace, int B, int P, int C, float scale,
                               void* stream) {

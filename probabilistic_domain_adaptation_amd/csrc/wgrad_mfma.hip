@@ -159,6 +159,7 @@ extern "C" size_t punet_wgrad_workspace_floats(int cs, int cout, int ksize, int 
 extern "C" int punet_wgrad_slices(int cs, int cout, int B, int H, int W) {
     const int ntiles = B * ceil_div(H, WTH) * ceil_div(W, WTW);
     const int pairs = ceil_div(cs, WC) * ceil_div(cout, WC);
+    if (pairs < 1 || ntiles < 1) return 1;  // (a shape the launch would refuse)
     // 2 workgroups are resident per CU (244 VGPRs, 51 KB LDS): size the grid to ONE full residency round
     int ns = 2 * punet_num_cus() / pairs;
     if (ns > ntiles) ns = ntiles;

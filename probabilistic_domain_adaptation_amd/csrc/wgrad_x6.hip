@@ -760,6 +760,7 @@ int launch_wgrad(const WgradX6Args& a, dim3 grid, hipStream_t stream) {
 extern "C" int punet_wgrad_x6_slices(int cs, int cout, int B, int H, int W) {
     const int ntiles = B * ceil_div(H, WTH) * ceil_div(W, WTW);
     const int pairs = ceil_div(cs, WC) * ceil_div(cout, WC);
+    if (pairs < 1 || ntiles < 1) return 1;  // (a shape the launch would refuse)
     int ns = punet_num_cus() / pairs;  // one resident workgroup per CU: one full round of the CUs
     if (ns > ntiles) ns = ntiles;
     return ns < 1 ? 1 : ns;

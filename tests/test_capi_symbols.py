@@ -65,3 +65,38 @@ def test_package_exports_cover_the_reference_packages():
         m = importlib.import_module("probabilistic_domain_adaptation_amd." + mod)
         for n in names:
             assert hasattr(m, n), (mod, n)
+
+
+def test_every_entry_point_survives_all_zero_arguments():
+    """The ABI's error behaviour (include/punet_hip.h: "nothing throws across the ABI"): every exported function called with null
+    pointers and zero sizes returns - the int-returning ones with an error code and a message in punet_last_error(), the size
+    helpers with a number - instead of dereferencing, dividing by zero or launching.  One child process so that a crash is a test
+    failure with the culprit's name, not the end of the test run.  No GPU is needed: argument validation precedes every HIP call."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, sys
+from probabilistic_domain_adaptation_amd import _lib
+_lib.load()
+for n in sorted(_lib._SIGS):
+    res, args = _lib._SIGS[n]
+    vals = []
+    for a in args:
+        if a in (C.c_float, C.c_double):
+            vals.append(0.0)
+        elif a in (C.c_int, C.c_long, C.c_size_t, C.c_uint, C.c_longlong):
+            vals.append(0)
+        elif isinstance(a, type) and issubclass(a, C._CFuncPtr):
+            vals.append(a())   # a null callback
+        else:
+            vals.append(None)  # pointers, handles
+    print("calling", n, flush=True)
+    r = _lib._fn[n](*vals)
+    if res is C.c_int and n not in _lib._NO_WRAP:
+        assert r != 0 and _lib.last_error(), (n, r)
+print("all returned")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    last = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("calling")][-1:]
+    assert p.returncode == 0 and "all returned" in p.stdout, (p.returncode, last, p.stdout[-600:])
