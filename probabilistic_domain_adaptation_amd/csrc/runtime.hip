@@ -167,7 +167,20 @@ struct Pass {  // one forward / backward walk
         }
         return PUNET_OK;
     }
-    float* slot() { return f16 && next_slot < nslots ? slots + next_slot++ : nullptr; }
+    bool slots_exhausted = false;
+    float* slot() {
+        if (!f16) return nullptr;
+        if (next_slot >= nslots) {  // (never with <= 8 levels; checked at the end of the walk: a missing slot would silently mean scale 1)
+            slots_exhausted = true;
+            return nullptr;
+        }
+        return slots + next_slot++;
+    }
+    int check_slots() const {
+        if (!slots_exhausted) return PUNET_OK;
+        punet_set_error("punet_rt: the amax slot pool (%d) is too small for this graph", nslots);
+        return PUNET_ERR_ARG;
+    }
     const float* wslot(const Conv& c) const { return wamax + c.x6_index; }
 
     const float* w(const Conv& c) const { return flat + c.w_off; }
@@ -586,6 +599,7 @@ static int pseudo_labels_body(PunetRt* rt, const float* flat, const float* x, in
     Act *enc = nullptr, *feat = nullptr;
     RT_CALL(p.latent(rt->enc_prior, rt->head_prior, xin, nullptr, &muls, &mean, &enc));
     RT_CALL(p.unet(xin, nullptr, &feat));
+    RT_CALL(p.check_slots());
     if (dry) return PUNET_OK;
     const Conv &c1 = rt->convs[rt->fc1], &c3 = rt->convs[rt->fc3];
     RT_CALL(punet_reparam(muls, eps, zs, N, B, L, stream));
@@ -695,7 +709,7 @@ static int elbo_body(PunetRt* rt, const float* flat, float* gflat, const float* 
         }
         RT_CALL(p.backward_tape(which == 0 ? tq : tp, accumulate));
     }
-    return PUNET_OK;
+    return p.check_slots();
 }
 
 extern "C" int punet_rt_elbo_fwd_bwd(PunetRt* rt, const float* flat, float* gflat, const float* x, const float* target, const float* consm,
