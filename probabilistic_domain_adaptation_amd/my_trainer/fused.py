@@ -231,6 +231,8 @@ def native_ok(*models) -> bool:
     from ..runtime import supported
     if os.environ.get("PUNET_RUNTIME", "native") == "python":
         return False
+    if len({(m.engine.conv_mode, bool(m.rl_swap)) for m in models}) > 1:
+        return False  # (one runtime handle walks both networks: student and teacher must share arithmetic and criterion)
     for m in models:
         e = m.engine
         if not (supported(m.layout) and e.conv_mode in ("x6", "f16x3", "f16") and e.fuse_fcomb and e.fuse_pool
