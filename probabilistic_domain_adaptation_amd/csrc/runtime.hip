@@ -189,7 +189,7 @@ struct Pass {  // one forward / backward walk
     int split(int mode, const __bf16** out) {
         __bf16* p = (__bf16*)ar->take((size_t)3 * rt->numel * 2);
         if (f16)
-            RT_LAUNCH(punet_split_weights_f16_batch(flat, p, rt->d_x6, rt->x6_nconv, rt->x6_units, mode, wamax, 1, stream));
+            RT_LAUNCH(punet_split_weights_f16_batch(flat, p, rt->d_x6, rt->x6_nconv, rt->x6_units, mode, wamax, mode == 0 ? 1 : 0, stream));  // (mode 1: same weights as this pass's forward planes, their amax stands)
         else
             RT_LAUNCH(punet_split_weights_x6_batch(flat, p, rt->d_x6, rt->x6_nconv, rt->x6_units, mode, stream));
         *out = p;

@@ -872,10 +872,12 @@ class PUNetEngine:
         table, nconv, units = self._x6_table
         if self.f16:  # fp16 planes h (+ l) of w * 2^k, k from the slab's amax (one slot per slab, recomputed with the planes)
             wam = self._wamax.get(flat.data_ptr())
-            if wam is None:
+            fresh = wam is None
+            if fresh:
                 wam = self._wamax[flat.data_ptr()] = torch.zeros(nconv, dtype=torch.float32, device=self.device)
+            # (the input-gradient orientation is split from the SAME weights as the forward planes of this step: their amax stands)
             _lib.call("punet_split_weights_f16_batch", flat.data_ptr(), planes.data_ptr(), table.data_ptr(), nconv, units, mode,
-                      wam.data_ptr(), 1, _stream())
+                      wam.data_ptr(), 1 if (mode == 0 or fresh) else 0, _stream())
             return planes
         _lib.call("punet_split_weights_x6_batch", flat.data_ptr(), planes.data_ptr(), table.data_ptr(), nconv, units, mode,
                   _stream())
