@@ -101,7 +101,7 @@ def test_three_level_shapes_whose_pixel_count_is_not_a_multiple_of_32(B, H, W, n
         m.forward(x1.to(dev), None, training=False)
         y_en, z_en = m.sample_consensus(n, 0.9, 0.1, True, e_t.to(dev))                    # the Python engine
     torch.cuda.synchronize()
-    assert FU.native_ok(m) and not FU.native_shape(x1) or (H * W) % 32 == 0
+    assert FU.native_shape(x1) == ((H * W) % 32 == 0)  # (the trainers' fused step takes the Python engine for these shapes)
     assert torch.equal(y_rt, y_en) and torch.equal(z_rt, z_en)
     assert tuple(y_rt.shape) == (B, 1, H, W)
     assert (y_rt.cpu() - yo).abs().max().item() < 1e-4 and int((z_rt.cpu() != zo).sum()) == 0
