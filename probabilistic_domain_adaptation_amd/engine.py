@@ -903,6 +903,10 @@ class PUNetEngine:
         return d
 
     def prepare_forward_weights(self, flat):
+        # every pass starts here: its amax slots come from a pool allocated INSIDE the pass (kept alive by the views handed out).
+        # A pool carried over from an earlier pass would be baked into a hipGraph captured now - not re-zeroed by the replay (slots
+        # accumulate with atomic max) and freed as soon as later eager passes have used it up.
+        self._amax_pool = None
         if self.x6:
             self._split_x6(flat, 0)
             self._split_x6_1x1(flat, 0)

@@ -327,8 +327,7 @@ def test_c_host_runs_the_training_loop(dev, tmp_path, dice, products):
     exe = ge.build_c_host()
     nf, B, H, W, n, iters, lr = [32, 64, 64, 96], 2, 32, 64, 4, 3, 1e-3
     m = _model(dev, nf, rl_swap=bool(dice))
-    if products == 3:
-        m.set_conv_mode("f16x3")
+    m.set_conv_mode("f16x3" if products == 3 else "x6")
     t = copy.deepcopy(m)
     x, x1, x2, y = [v.to(dev) for v in O.synth_batch(B, 1, H, W, 21)]
     g = torch.Generator().manual_seed(8)
