@@ -25,6 +25,7 @@ def _model(dev, nf, C=1, nfc=3, latent=6, seed=1, rl_swap=False):
     m = ProbabilisticUnet(C, 1, nf, latent, nfc, 1.0, consensus_masking=True, rl_swap=rl_swap, device=dev, seed=0)
     cfg = O.PUNetConfig(C, 1, nf, latent, nfc, 1.0, consensus_masking=True, rl_swap=False)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in O.synth_params(cfg.spec(), seed).items()})
+    m.set_conv_mode("x6")  # (explicit: these tests are about the graph walkers, whatever $PUNET_CONV_MODE says)
     return m
 
 
@@ -250,6 +251,7 @@ def test_native_runtime_with_the_dice_criterion(dev, monkeypatch):
     for rtm in ("python", "native"):
         monkeypatch.setenv("PUNET_RUNTIME", rtm)
         m = ProbabilisticUnet(1, 1, nf, 6, 3, 1.0, consensus_masking=True, rl_swap=True, device=dev, seed=1)
+        m.set_conv_mode("x6")
         t = copy.deepcopy(m)
         assert FU.native_ok(m, t) == (rtm == "native")
         opt = FusedAdam(m, lr=1e-3)
