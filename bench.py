@@ -178,21 +178,33 @@ class Runner:
         o = self.opt
         snap = [x.clone() for x in ts]
         mirrors = (o.step_count, o._iter_mirror, o._uploaded)
+
+        def restore():
+            with torch.no_grad():
+                for c, x in zip(snap, ts):
+                    x.copy_(c)
+            o.step_count, o._iter_mirror, o._uploaded = mirrors
+            o._uploaded = None  # the device state block was restored under the mirrors: upload again before the next step
+
+        def digests():
+            return [self.checksum(x) for x in (self.model.flat_params, o.exp_avg, o.exp_avg_sq)] + \
+                   ([self.checksum(self.teacher.flat_params)] if self.teacher is not None else [])
+
         for k in ("eps_pl", "eps_s", "eps_sup"):
             self.t[k].normal_(generator=self.gen)
-        self.body(self.t)
-        torch.cuda.synchronize()
-        eager = [self.checksum(x) for x in (self.model.flat_params, o.exp_avg, o.exp_avg_sq)] + \
-                ([self.checksum(self.teacher.flat_params)] if self.teacher is not None else [])
-        with torch.no_grad():
-            for c, x in zip(snap, ts):
-                x.copy_(c)
-        o.step_count, o._iter_mirror, o._uploaded = mirrors
-        o._uploaded = None  # the device state block was restored under the mirrors: upload again before the replay
-        self.graphed.step(warmup_iteration=self.it if self.workload == "adamt" else None)
-        torch.cuda.synchronize()
-        replay = [self.checksum(x) for x in (self.model.flat_params, o.exp_avg, o.exp_avg_sq)] + \
-                 ([self.checksum(self.teacher.flat_params)] if self.teacher is not None else [])
+        done = False
+        try:
+            self.body(self.t)
+            torch.cuda.synchronize()
+            eager = digests()
+            restore()
+            self.graphed.step(warmup_iteration=self.it if self.workload == "adamt" else None)
+            torch.cuda.synchronize()
+            replay = digests()
+            done = True
+        finally:
+            if not done:  # a step that raised half-way leaves no state behind; the caller decides what happens next
+                restore()
         self.it += 1
         return eager == replay
 
@@ -346,8 +358,14 @@ def main():
                 try:
                     ok = 1.0 if run.graph_matches_eager() else 0.0
                 except Exception as ex:
-                    print(f"[bench] graph self-check raised {type(ex).__name__}: {ex}", file=sys.stderr)
+                    # The self-check's steps contain collectives: a rank that raised half-way has left the others inside an
+                    # all-reduce it will never join, so "fall back to eager" is not available here - continuing would hang on
+                    # mismatched collectives.  The state was restored (graph_matches_eager's finally); leave with a non-zero
+                    # code and let the launcher take the other ranks down.
+                    print(f"[bench] rank {rank}: graph self-check raised {type(ex).__name__}: {ex}; exiting with code 4 "
+                          "(collectives of the other ranks are outstanding)", file=sys.stderr, flush=True)
                     FU._CAPTURE = None
+                    sys.exit(4)
             t = torch.tensor([ok], device=cdev0)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             graph_selfcheck = bool(t.item() == 1.0)

@@ -388,7 +388,9 @@ int punet_augment_view(const float* x, const float* stats, const float* noise, c
  * Parameters: ONE flat fp32 buffer in the reference's state-dict order, conv weights [ky][kx][cin][cout] (punet_rt_param_entry
  * lists name / offset / logical shape of every tensor).  The runtime owns NOTHING on the device: every call carves its
  * activations, gate bits, gradients, weight planes and split-K slabs out of a caller-provided ARENA (punet_rt_arena_bytes) and
- * reads two small index tables from a caller-provided TABLES buffer (punet_rt_tables_bytes / punet_rt_init_tables, once).  No
+ * reads two small index tables from a caller-provided TABLES buffer (punet_rt_tables_bytes / punet_rt_init_tables, once).  The
+ * arena's BASE must be 256-byte aligned (hipMalloc'ed memory is; a host that sub-allocates must round up): the runtime aligns the
+ * offsets of what it carves, the kernels read it with 16-byte vector loads, and a misaligned base is refused (PUNET_ERR_ARG).  No
  * allocation, no synchronisation, no host read inside a call: each is hipGraph-capturable.  x is NHWC fp32 ([B][H][W][C]; for
  * C = 1 the same bytes as NCHW); target / consm / y / z / logits are [B][1][H][W].  Not thread-safe per handle. */
 typedef struct PunetRt PunetRt;

@@ -70,6 +70,11 @@ struct Arena {
     float* floats(size_t n) { return (float*)take(n * sizeof(float)); }
 };
 
+// take() aligns OFFSETS to 256 bytes and the kernels read what it carves with 16-byte vector loads (planes by LDS-DMA rows): the
+// base the caller hands over has to be 256-byte aligned itself (hipMalloc and torch's allocator are; a sub-allocating C host may
+// not be - ADVICE r3).  Checked by every entry point that takes an arena, before anything is launched.
+inline bool arena_aligned(const void* arena) { return ((uintptr_t)arena & 255) == 0; }
+
 }  // namespace
 
 struct PunetRt {
@@ -618,6 +623,7 @@ extern "C" int punet_rt_pseudo_labels(PunetRt* rt, const float* flat, const floa
     PUNET_CHECK_ARG(rt && flat && x && eps && arena && (y || logits) && (!y == !z), "punet_rt_pseudo_labels: null pointer");
     PUNET_CHECK_ARG(rt->d_x6, "punet_rt_pseudo_labels: punet_rt_init_tables has not run");
     PUNET_CHECK_ARG(B > 0 && N > 0 && H > 0 && W > 0, "punet_rt_pseudo_labels: bad shape");
+    PUNET_CHECK_ARG(arena_aligned(arena), "punet_rt_pseudo_labels: the arena must be 256-byte aligned (got %p)", arena);
     Arena dry{DRY_BASE, (size_t)-1};  // first walk: sizes only, nothing is launched
     RT_CALL(pseudo_labels_body(rt, flat, x, B, H, W, eps, N, upper, lower, masking, y, z, logits, dry, true, stream));
     PUNET_CHECK_ARG(dry.used <= arena_bytes, "punet_rt_pseudo_labels: the arena holds %zu bytes, this call needs %zu (punet_rt_arena_bytes)",
@@ -718,6 +724,7 @@ extern "C" int punet_rt_elbo_fwd_bwd(PunetRt* rt, const float* flat, float* gfla
                                      void* stream) {
     PUNET_CHECK_ARG(rt && flat && gflat && x && target && eps && rec_out && kl_out && arena, "punet_rt_elbo_fwd_bwd: null pointer");
     PUNET_CHECK_ARG(rt->d_x6, "punet_rt_elbo_fwd_bwd: punet_rt_init_tables has not run");
+    PUNET_CHECK_ARG(arena_aligned(arena), "punet_rt_elbo_fwd_bwd: the arena must be 256-byte aligned (got %p)", arena);
     PUNET_CHECK_ARG(B > 0 && punet_fcomb_train_supported(rt->cfg.num_filters[0], rt->cfg.no_convs_fcomb - 2, H * W),
                     "punet_rt_elbo_fwd_bwd: H * W must be a multiple of 32");
     Arena dry{DRY_BASE, (size_t)-1};  // first walk: sizes only, nothing is launched, the callback is not called
@@ -752,6 +759,7 @@ extern "C" size_t punet_rt_last_arena_used(const PunetRt* rt) { return rt ? rt->
 extern "C" int punet_rt_l2_reg_grad(PunetRt* rt, const float* flat, float* gflat, float coef, float* reg_out, void* arena, size_t arena_bytes,
                                     void* stream) {
     PUNET_CHECK_ARG(rt && flat && reg_out && arena && rt->d_l2, "punet_rt_l2_reg_grad: null pointer / tables not initialised");
+    PUNET_CHECK_ARG(arena_aligned(arena), "punet_rt_l2_reg_grad: the arena must be 256-byte aligned (got %p)", arena);
     Arena ar{(char*)arena, arena_bytes};
     float* partial = ar.floats(rt->l2_nchunks);
     float* norms = ar.floats(rt->l2_ntensors);

@@ -213,35 +213,26 @@ class Workspace:
     """Grow-only scratch buffers keyed by purpose (split-K slabs, reduction partials).
 
     A captured hipGraph bakes the raw pointers of these buffers into its kernel nodes (my_trainer/fused.py::GraphedStep).
-    Once a graph exists on the device (`pin_all`), a buffer that has to grow is REPLACED, never freed: the old tensor moves
-    to `retired` and stays alive for the life of the workspace, so a later eager call with a larger shape (validation or
-    prediction with a bigger batch, a second capture) cannot hand the block a graph still writes through to the caching
-    allocator."""
+    While a capture is in progress every buffer handed out is also appended to `CAPTURE_KEEP`, and the GraphedStep holds that
+    list for as long as its graph lives: a buffer that has to grow later (an eager call with a larger shape: validation or
+    prediction with a bigger batch, a second capture) is simply replaced here - the old tensor stays alive exactly as long as a
+    graph still writes through it and is freed with that graph."""
 
-    _live = weakref.WeakSet()
+    CAPTURE_KEEP: Optional[list] = None
 
     def __init__(self, device):
         self.device = device
         self.bufs: Dict[str, torch.Tensor] = {}
-        self.retired: List[torch.Tensor] = []
-        self.pinned = False
-        Workspace._live.add(self)
 
     def get(self, key: str, nfloats: int) -> torch.Tensor:
         b = self.bufs.get(key)
         if b is None or b.numel() < nfloats:
-            if b is not None and self.pinned:
-                self.retired.append(b)
             b = torch.empty(max(int(nfloats), 1), dtype=torch.float32, device=self.device)
             self.bufs[key] = b
+        keep = Workspace.CAPTURE_KEEP
+        if keep is not None and not any(b is k for k in keep):
+            keep.append(b)
         return b
-
-    @classmethod
-    def pin_all(cls, device):
-        """Called when a graph is about to be captured on `device`: every live workspace there keeps what it has handed out."""
-        for w in list(cls._live):
-            if torch.device(w.device) == torch.device(device):
-                w.pinned = True
 
 
 class PUNetEngine:

@@ -153,11 +153,11 @@ class DefaultTrainer:
         # (default "f16x3": fp16 planes with per-tensor power-of-two scaling - logits within 1e-4 of the fp32 reference, 1.5x the
         # parity mode's throughput; "f16" = one fp16 plane, the literal analogue of autocast's arithmetic; "off" = ignore).  The
         # DEFAULT here is False (torch_em's is True [recalled]): a trainer built without the argument runs the parity arithmetic.
+        # The switch is made ON THE CALLER'S MODEL, in place (the arithmetic is a property of the model's engine, not of a call;
+        # see _apply_mixed_precision): fit() undoes it when it returns, restore_precision() does so on request.
         self.mixed_precision = bool(mixed_precision)
-        if self.mixed_precision and model is not None and hasattr(model, "set_conv_mode"):
-            mp_mode = os.environ.get("PUNET_MIXED_PRECISION_MODE", "f16x3")
-            if mp_mode != "off":
-                model.set_conv_mode(mp_mode)
+        self._mp_restore = {}  # id(model) -> (model, the arithmetic it had before this trainer switched it)
+        self._apply_mixed_precision()
         self.early_stopping = early_stopping
         self.logger = None  # tensorboard loggers are out of scope
         self.save_root = save_root
@@ -168,6 +168,48 @@ class DefaultTrainer:
         self.train_time = 0.0
         self.last_loss = None
         self.last_epoch_loss = float("nan")  # logged training loss of the last epoch's last step, mean over ranks
+
+    # ------------------------------------------------------------------ mixed precision
+    def _mp_mode(self):
+        mode = os.environ.get("PUNET_MIXED_PRECISION_MODE", "f16x3")
+        return None if (mode == "off" or not self.mixed_precision) else mode
+
+    def _apply_mixed_precision(self):
+        """mixed_precision=True: student AND teacher (the trainers' own deep copy, or one the caller assigned later) compute in
+        $PUNET_MIXED_PRECISION_MODE from here on; what they computed in before is remembered for restore_precision().  Autocast
+        in the reference is scoped to the trainer's passes; here the arithmetic belongs to the model's engine, so the switch is
+        visible on the model object while the trainer is at work - fit() re-applies it on entry and restores on exit.
+        mixed_precision=False: nothing is switched, but a student and a teacher that compute in DIFFERENT arithmetics are
+        reported (the fused steps then leave the native runtime for the Python engine: fused.native_ok)."""
+        mode = self._mp_mode()
+        nets = [m for m in (self.model, getattr(self, "teacher", None)) if m is not None and hasattr(m, "set_conv_mode")]
+        if mode is None:
+            if len({m.engine.conv_mode for m in nets}) > 1:
+                import warnings
+                warnings.warn("student and teacher compute in different conv arithmetics ("
+                              + ", ".join(m.engine.conv_mode for m in nets) + "): pseudo-labels and the gradient pass use different "
+                              "precisions and the fused steps take the Python engine; call teacher.set_conv_mode(...) to align them")
+            return
+        for m in nets:
+            if m.engine.conv_mode != mode:
+                self._mp_restore.setdefault(id(m), (m, m.engine.conv_mode))
+                m.set_conv_mode(mode)
+
+    def restore_precision(self):
+        """Give every model this trainer switched for mixed_precision=True its previous arithmetic back (fit() calls this when it
+        returns; call it yourself after driving _train_epoch_impl directly, before a parity evaluation or an export of the same
+        model object).  A teacher deep-copied from an already switched student is put back to the student's arithmetic."""
+        mode = self._mp_mode()
+        back = None
+        for m, prev in self._mp_restore.values():
+            m.set_conv_mode(prev)
+            if m is self.model:
+                back = prev
+        t = getattr(self, "teacher", None)
+        if back is not None and t is not None and id(t) not in self._mp_restore and hasattr(t, "set_conv_mode") \
+                and t.engine.conv_mode == mode:
+            t.set_conv_mode(back)
+        self._mp_restore = {}
 
     # ------------------------------------------------------------------ checkpoints
     @property
@@ -296,6 +338,15 @@ class DefaultTrainer:
         progress = progress or _Progress(self.max_iteration)
         forward_context = contextlib.nullcontext
         t0 = time.time()
+        self._apply_mixed_precision()  # (again: a previous fit() restored the models on its way out; also covers a teacher assigned since)
+        try:
+            best_metric = self._fit_loop(best_metric, progress, forward_context, t0, save_every_kth_epoch)
+        finally:
+            self.restore_precision()
+        self._best_metric = best_metric
+        return best_metric
+
+    def _fit_loop(self, best_metric, progress, forward_context, t0, save_every_kth_epoch):
         while self._iteration < self.max_iteration and self._epoch < self.max_epoch:
             self._train_epoch_impl(progress, forward_context, self._backprop)
             current_metric = float("nan")
@@ -316,7 +367,6 @@ class DefaultTrainer:
                 self.save_checkpoint("latest", current_metric, best_metric, train_time=total)
                 if save_every_kth_epoch and self._epoch % save_every_kth_epoch == 0:
                     self.save_checkpoint(f"epoch-{self._epoch}", current_metric, best_metric, train_time=total)
-        self._best_metric = best_metric
         return best_metric
 
     def _train_epoch_impl(self, progress, forward_context, backprop):

@@ -472,12 +472,12 @@ class GraphedStep:
         body(inputs)
         self._restore(snap)
         torch.cuda.synchronize(dev)
-        # the capture bakes the engines' workspace pointers into the graph: from here on a workspace that has to grow (an
-        # eager call at a larger shape) retires its old buffer instead of freeing it
+        # the capture bakes raw pointers of the engines' workspaces and of the native runtime's arena into the graph: whatever is
+        # handed out while capturing is recorded in self._keep, so those buffers live exactly as long as this graph does (a
+        # workspace / arena that grows later just replaces its own reference)
         from ..engine import Workspace
-        from ..runtime import pin_all as pin_runtime_arenas
-        Workspace.pin_all(dev)
-        pin_runtime_arenas(dev)
+        from .. import runtime as _rt
+        self._keep: list = []
         if opt is not None:  # the device state block must be current before the capture (no uploads inside a graph)
             opt.sync_device_state(ema_momentum if ema else 0.0, 1.0 / _world(), warmup_iteration if ema else None)
         # (2) capture, cutting at collectives
@@ -486,6 +486,7 @@ class GraphedStep:
         self._stream = torch.cuda.Stream(dev)
         self._stream.wait_stream(torch.cuda.current_stream(dev))
         _CAPTURE = self
+        Workspace.CAPTURE_KEEP = _rt.CAPTURE_KEEP = self._keep
         try:
             with torch.cuda.stream(self._stream):
                 self._begin()
@@ -495,6 +496,7 @@ class GraphedStep:
                     self._end()  # also on failure: never leave a stream in capture mode behind
         finally:
             _CAPTURE = None
+            Workspace.CAPTURE_KEEP = _rt.CAPTURE_KEEP = None
         torch.cuda.current_stream(dev).wait_stream(self._stream)
 
     # ---- capture plumbing

@@ -61,6 +61,13 @@ class _PUNetTrainerBase(DefaultTrainer):
     def _graphed(self, kind, tensors, body, **ema):
         """Replay (capturing first, once per kind / shapes / lr truthiness) the fused step `body` on `tensors`."""
         key = (kind, bool(self._lr())) + tuple((k, tuple(v.shape)) for k, v in tensors.items())
+        # a graph is captured against the ENGINES of the models it runs (weight planes, tables, workspaces they own): a
+        # set_conv_mode() since then - mixed_precision applied or restored - has replaced an engine, and replaying a graph of the
+        # old one would compute in the old arithmetic through buffers that may be gone
+        engines = tuple(id(m.engine) for m in (self.model, getattr(self, "teacher", None)) if m is not None)
+        if getattr(self, "_graph_engines", engines) != engines:
+            self._graphs.clear()
+        self._graph_engines = engines
         gs = self._graphs.get(key)
         if gs is None:
             static = {k: v.to(device=self.model.device, dtype=torch.float32).clone() for k, v in tensors.items()}

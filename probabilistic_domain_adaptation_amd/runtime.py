@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import weakref
-from typing import List, Optional
+from typing import Optional
 
 import torch
 
@@ -17,17 +17,25 @@ from . import _lib
 
 
 def supported(layout) -> bool:
-    """Does the native runtime cover this ParamLayout?  (num_classes 1, num_filters[0] in {32, 64}, Fcomb of 2 or 3 layers)"""
+    """Does the native runtime cover this ParamLayout?  Mirrors EVERY precondition of punet_rt_create (csrc/runtime.hip), so that
+    a configuration the runtime refuses takes the Python engine instead of raising: num_classes 1, num_filters[0] in
+    {32, 64}, filters multiples of 8, Fcomb of 2 or 3 layers, 2..8 levels, latent_dim 1..64, input_channels + 1 <= 7."""
     return (layout.kind == "punet" and layout.num_classes == 1 and layout.nf[0] in (32, 64) and layout.no_convs_fcomb in (2, 3)
-            and 2 <= len(layout.nf) <= 8)
+            and 2 <= len(layout.nf) <= 8 and all(f >= 8 and f % 8 == 0 for f in layout.nf)
+            and 1 <= layout.latent_dim <= 64 and 1 <= layout.input_channels and layout.input_channels + 1 <= 7)
 
 
-def pin_all(device):
-    """A hipGraph is about to be captured on `device`: from now on an arena that has to grow is retired, not freed (the graph
-    holds raw pointers into it) - the counterpart of engine.Workspace.pin_all."""
-    for r in list(NativeRuntime._live):
-        if r.device == torch.device(device):
-            r.pinned = True
+# While a hipGraph is being captured (my_trainer/fused.py::GraphedStep) every arena a call carves from is appended here: the graph
+# bakes raw pointers into it, so the GraphedStep keeps these tensors alive for exactly as long as the graph itself lives.  A
+# runtime whose arena has to grow afterwards simply drops its own reference: an arena no graph points into is freed at once, one
+# that a graph points into goes away with that graph (the trainers' LRU evicts graphs) - nothing is retired for the life of the
+# runtime any more (ADVICE r3: arenas are tens of GB).
+CAPTURE_KEEP: Optional[list] = None
+
+
+def _keep_for_capture(t: torch.Tensor):
+    if CAPTURE_KEEP is not None and not any(t is k for k in CAPTURE_KEEP):
+        CAPTURE_KEEP.append(t)
 
 
 class NativeRuntime:
@@ -57,8 +65,6 @@ class NativeRuntime:
         _lib.call("punet_rt_init_tables", h, self.tables.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.current_stream().synchronize()  # the tables come from host memory of the handle: copied before it can change
         self._arena: Optional[torch.Tensor] = None
-        self._retired: List[torch.Tensor] = []
-        self.pinned = False
         self._cb_keep = None
         NativeRuntime._live.add(self)
 
@@ -92,12 +98,13 @@ class NativeRuntime:
         return _lib.call("punet_rt_arena_bytes", self._h, B, H, W, N, int(training))
 
     def arena(self, nbytes: int) -> torch.Tensor:
-        """Grow-only arena (one per runtime: calls on one handle are sequential on one stream)."""
+        """Grow-only arena (one per runtime: calls on one handle are sequential on one stream).  A captured graph that points
+        into the current one holds its own reference (CAPTURE_KEEP above), so growing never pulls memory from under a graph and
+        never keeps an arena that no graph uses."""
         if self._arena is None or self._arena.numel() < nbytes:
-            if self._arena is not None and self.pinned:
-                self._retired.append(self._arena)
-            self._arena = None  # (free the old one first: arenas are tens of GB)
+            self._arena = None  # (drop ours first: arenas are tens of GB)
             self._arena = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        _keep_for_capture(self._arena)
         return self._arena
 
     def pseudo_labels(self, flat, x_nhwc, eps, upper=0.9, lower=0.1, masking=False, want_logits=False, arena=None):
@@ -105,6 +112,7 @@ class NativeRuntime:
         B, H, W, _ = x_nhwc.shape
         N = eps.shape[0]
         ar = arena if arena is not None else self.arena(self.arena_bytes(B, H, W, N, False))
+        _keep_for_capture(ar)
         y = torch.empty(B, 1, H, W, dtype=torch.float32, device=self.device)
         z = torch.empty(B, 1, H, W, dtype=torch.float32, device=self.device)
         lg = torch.empty(N, B, 1, H, W, dtype=torch.float32, device=self.device) if want_logits else None
@@ -118,6 +126,7 @@ class NativeRuntime:
         """model.forward(x, y, True); elbo(y, consm); backward into gflat -> (rec [1], kl [1][, logits])."""
         B, H, W, _ = x_nhwc.shape
         ar = arena if arena is not None else self.arena(self.arena_bytes(B, H, W, 1, True))
+        _keep_for_capture(ar)
         rec = torch.empty(1, dtype=torch.float32, device=self.device)
         kl = torch.empty(1, dtype=torch.float32, device=self.device)
         lg = torch.empty(B, 1, H, W, dtype=torch.float32, device=self.device) if want_logits else None

@@ -257,6 +257,25 @@ def test_mixed_precision_flag_selects_the_documented_mode(monkeypatch):
     assert b.model.engine.conv_mode == "f16x3" and b.teacher.engine.conv_mode == "f16x3"
     assert abs(float(b.last_loss) - float(a.last_loss)) <= 1e-5 * abs(float(a.last_loss))
     assert not torch.equal(a.model.flat_params, b.model.flat_params)  # (it really was a different arithmetic)
+    # the switch is made on the caller's model in place - restore_precision() undoes it for student and teacher ...
+    b.restore_precision()
+    assert b.model.engine.conv_mode == "x6" and b.teacher.engine.conv_mode == "x6"
+    # ... fit() applies it on entry (also to a teacher assigned since) and restores on exit, with graph replay across the switches
+    c = run(mixed_precision=True, graph=True)
+    c.restore_precision()
+    seen = []
+    step = c._train_epoch_impl
+    c._train_epoch_impl = lambda *a, **k: (seen.append((c.model.engine.conv_mode, c.teacher.engine.conv_mode)), step(*a, **k))[1]
+    c.fit(iterations=2)
+    torch.cuda.synchronize()
+    assert seen and all(s == ("f16x3", "f16x3") for s in seen)
+    assert c.model.engine.conv_mode == "x6" and c.teacher.engine.conv_mode == "x6"
+    assert torch.isfinite(c.model.flat_params).all() and len(c._graphs) == 1  # (graphs of a replaced engine are dropped, not replayed)
+    # a student and a teacher in different arithmetics without mixed_precision: reported, not silently mixed
+    d = run()
+    d.teacher.set_conv_mode("f16")
+    with pytest.warns(UserWarning, match="different conv arithmetics"):
+        d._apply_mixed_precision()
     monkeypatch.setenv("PUNET_MIXED_PRECISION_MODE", "f16")
     assert run(mixed_precision=True).model.engine.conv_mode == "f16"
     monkeypatch.setenv("PUNET_MIXED_PRECISION_MODE", "off")

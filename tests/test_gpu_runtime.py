@@ -108,6 +108,14 @@ def test_native_runtime_equals_python_engine_bit_for_bit(dev, nf, C, nfc, latent
         rt.elbo_fwd_bwd(flat, gr, eng.to_nhwc(x2), y, consm, eps_s, arena=small)
     torch.cuda.synchronize()
     assert torch.equal(before, gr)
+    # ---- so is an arena whose base is not 256-byte aligned (the kernels read what is carved from it with 16-byte vector loads)
+    skew = torch.empty(need + 512, dtype=torch.uint8, device=dev)[16:]
+    with pytest.raises(RuntimeError, match="256-byte aligned"):
+        rt.elbo_fwd_bwd(flat, gr, eng.to_nhwc(x2), y, consm, eps_s, arena=skew)
+    with pytest.raises(RuntimeError, match="256-byte aligned"):
+        rt.pseudo_labels(flat, eng.to_nhwc(x1), eps_n, 0.9, 0.1, True, arena=skew)
+    torch.cuda.synchronize()
+    assert torch.equal(before, gr)
 
 
 def test_mean_teacher_step_through_four_library_calls(dev, monkeypatch):
@@ -137,6 +145,35 @@ def test_mean_teacher_step_through_four_library_calls(dev, monkeypatch):
     for a, b in zip(res[0][1:], res[1][1:]):
         assert torch.equal(a, b)
     assert not torch.equal(res[0][1], res[0][2])  # the EMA teacher really differs from the student
+
+
+def test_a_latent_size_the_runtime_refuses_takes_the_python_engine(dev, monkeypatch):
+    """latent_dim = 65 is inside the per-op kernels' constructor space and outside punet_rt_create's; the fused step,
+    the MC pseudo-labels and the oracle must agree instead of the dispatch raising."""
+    import copy
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    from probabilistic_domain_adaptation_amd.runtime import supported
+    monkeypatch.setenv("PUNET_RUNTIME", "native")
+    nf, B, H, W, n, latent = [32, 32, 64, 64], 2, 32, 32, 3, 65
+    m = _model(dev, nf, latent=latent)
+    assert not supported(m.layout) and not FU.native_ok(m)
+    t = copy.deepcopy(m)
+    x, x1, x2, y = [v.to(dev) for v in O.synth_batch(B, 1, H, W, 0)]
+    g = torch.Generator().manual_seed(5)
+    eps_n, eps_s = torch.randn(n, B, latent, generator=g), torch.randn(1, B, latent, generator=g)
+    yp, zp = m.pseudo_labels(x1, n, masking=True, eps=eps_n.to(dev))
+    cfg = O.PUNetConfig(1, 1, nf, latent, 3, 1.0, consensus_masking=True, rl_swap=False)
+    Po = O.to_torch(O.synth_params(cfg.spec(), 1))
+    yo, zo = O.sample_consensus(Po, cfg, x1.cpu(), eps_n, 0.9, 0.1, True)
+    torch.cuda.synchronize()
+    assert float((yp.cpu() - yo).abs().max()) < 2e-5 and torch.equal(zp.cpu(), zo.float())
+    opt = FusedAdam(m, lr=1e-3)
+    before = m.flat_params.clone()
+    loss, ys, zs, _ = FU.fused_self_training_step(m, t, opt, x1, x2, n, True, eps_pl=eps_n.to(dev), eps_s=eps_s.to(dev))
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss)) and not torch.equal(before, m.flat_params)
+    assert torch.equal(ys, yp) and torch.equal(zs, zp)
 
 
 def test_joint_and_supervised_steps_native_equal_python(dev, monkeypatch):

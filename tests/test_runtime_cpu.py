@@ -46,3 +46,31 @@ def test_runtime_layout_is_the_param_layout(ic, nf, latent, nfc):
 def test_runtime_refuses_what_it_does_not_cover(ic, k, nf, latent, nfc):
     with pytest.raises(RuntimeError):
         _create(ic, k, nf, latent, nfc)
+
+
+def test_supported_mirrors_every_precondition_of_punet_rt_create():
+    """runtime.supported() decides whether the fused steps hand the graph walk to the native runtime; a layout it
+    accepts but punet_rt_create refuses would raise instead of taking the Python engine (latent_dim = 65 did)."""
+    from probabilistic_domain_adaptation_amd.runtime import supported
+    cases = []
+    for ic in (1, 3, 6):
+        for nf in ([64, 128, 256, 512], [32, 64], [32, 40, 72], [16, 32], [128, 256], [64, 128, 256, 512, 512, 512, 512, 512]):
+            for latent in (1, 6, 64, 65, 200):
+                for nfc in (2, 3, 4):
+                    cases.append((ic, nf, latent, nfc))
+    assert any(lat == 65 for _, _, lat, _ in cases)
+    n_ok = 0
+    for ic, nf, latent, nfc in cases:
+        try:
+            lay = ParamLayout(ic, 1, nf, latent, nfc)
+        except ValueError:
+            continue  # outside the whole HIP path's constructor space
+        try:
+            h = _create(ic, 1, nf, latent, nfc)
+            _lib.call("punet_rt_destroy", h)
+            created = True
+        except RuntimeError:
+            created = False
+        assert supported(lay) == created, (ic, nf, latent, nfc, supported(lay), created)
+        n_ok += created
+    assert n_ok > 10
