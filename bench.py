@@ -109,6 +109,43 @@ def cpu_baseline(workload, n_samples, H, W, min_iters=3):
                       f"{', '.join(f'{t:.2f}' for t in times)} s; parallel_info: {pinfo}"}
 
 
+def plain_unet_forward_config(dev, cpu=True, iters=20):
+    """BASELINE.json configs[0]: the plain `Unet` (unet.py:6-69, apply_last_layer=True) forward on one 256x256x1 patch - the
+    reference's own CPU-runnable case.  GPU: the HIP path behind this package's `Unet` (20 forwards between two
+    synchronisations); CPU beside it: the oracle's restatement with the same weights (the `cpu_baseline` leg of this
+    config), which also checks the GPU logits (max abs difference reported, bar 1e-3)."""
+    from probabilistic_domain_adaptation_amd.my_models import Unet
+    net = Unet(1, 1, NF, apply_last_layer=True, device=dev, seed=1)
+    x = synth(1, 256, 256, 11, dev, 1)[0]
+    for _ in range(3):
+        y = net(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        y = net(x)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / iters
+    gf = 118.46  # SURVEY.md 8d: unet forward at 256x256x1 (the 1x1 last layer adds 8 MFLOP)
+    out = {"workload": "plain Unet forward (BASELINE.json configs[0]): one 256x256x1 patch, nf=[64, 128, 256, 512], eager launches "
+                       "from Python (no graph)", "ms_per_step": round(ms, 3), "patches_per_s": round(1e3 / ms, 2),
+           "model_tflops": round(gf / ms, 2)}
+    if cpu:
+        from oracle import punet_oracle as O
+        torch.set_num_threads(host_cores())
+        P = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        xc = x.cpu()
+        with torch.no_grad():
+            ref = O.plain_unet_forward(P, xc, len(NF))
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ref = O.plain_unet_forward(P, xc, len(NF))
+            cms = 1e3 * (time.perf_counter() - t0) / 3
+        out["cpu_oracle_ms"] = round(cms, 1)
+        out["cpu_oracle_threads"] = torch.get_num_threads()
+        out["max_abs_logit_difference_to_cpu_oracle"] = float((y.cpu() - ref).abs().max())
+    return out
+
+
 class Runner:
     """One workload on one rank: the fused step on static synthetic tensors, launched eagerly from Python or replayed from a
     hipGraph (FU.GraphedStep); fresh latent draws every step either way."""
@@ -273,7 +310,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
-                    help="skip the short runs of BASELINE.json configs[2] (AdaMT) and configs[3] (AdaMatch 704x704x3) after the headline")
+                    help="skip the short runs of the other BASELINE.json configs (plain Unet forward, PUNet-source, AdaMT, AdaMatch 704x704x3, "
+                         "inference 1024x1024 N=16) and of the f16x3 fast mode after the headline")
     ap.add_argument("--kernel-timing", default="roofline", choices=["roofline", "all"],
                     help="HIP-event brackets in the instrumented region: only the roofline kernel's launches (default; 73 per "
                          "step) or every MFMA launch (adds ~1 ms of bubbles per step)")
@@ -554,8 +592,10 @@ def main():
             others = []
             del run
             torch.cuda.empty_cache()
-            for wl, ch, size in (("adamt", 1, 512), ("adamatch", 3, 704)):
-                r2 = Runner(wl, a, dev, rank, B, size, size, N, ch, a.conv_mode)
+            # (configs[1] PUNet-source and configs[4] inference since round 4: every BASELINE.json config is driver-timed)
+            for idx, wl, ch, size, b2, n2 in ((1, "punet_source", 1, 512, B, N), (2, "adamt", 1, 512, B, N),
+                                              (3, "adamatch", 3, 704, B, N), (4, "inference", 1, 1024, 1, 16)):
+                r2 = Runner(wl, a, dev, rank, b2, size, size, n2, ch, a.conv_mode)
                 g2ok = use_graph
                 if g2ok:
                     try:
@@ -565,14 +605,23 @@ def main():
                 for _ in range(2):
                     r2.step(g2ok)
                 d2, e2, each2 = timed_region(r2, 5, g2ok, sync, dp, dev)
-                g2 = gflop_per_patch(wl, N, size, size, ch)
-                others.append({"workload": f"{wl} (BASELINE.json configs[{2 if wl == 'adamt' else 3}], per GPU): {B} source + {B} target "
-                                           f"patches {size}x{size}x{ch} per step, N={N}",
-                               "ms_per_step": round(1e3 * d2 / 5, 3), "pairs_per_s": round(B * 5 / d2, 3),
-                               "model_tflops": round(g2 * B * 5 / d2 / 1e3, 2), "host_enqueue_ms_per_step": round(1e3 * e2 / 5, 2),
+                g2 = gflop_per_patch(wl, n2, size, size, ch)
+                what = {"punet_source": f"{b2} labelled patches {size}x{size}x{ch} per step (supervised ELBO step, punet_trainer.py:19-50)",
+                        "adamt": f"{b2} source + {b2} target patches {size}x{size}x{ch} per step, N={n2}",
+                        "adamatch": f"{b2} source + {b2} target patches {size}x{size}x{ch} per step, N={n2}",
+                        "inference": f"one {size}x{size}x{ch} tile per step, N={n2} MC samples, mean + consensus mask "
+                                     f"(punet_predictions.py:29-33 / :114-124)"}[wl]
+                unit = {"punet_source": "patches_per_s", "inference": "tiles_per_s"}.get(wl, "pairs_per_s")
+                others.append({"workload": f"{wl} (BASELINE.json configs[{idx}], per GPU): {what}",
+                               "ms_per_step": round(1e3 * d2 / 5, 3), unit: round(b2 * 5 / d2, 3),
+                               "model_tflops": round(g2 * b2 * 5 / d2 / 1e3, 2), "host_enqueue_ms_per_step": round(1e3 * e2 / 5, 2),
                                "ms_each_step": each2})
                 del r2
                 torch.cuda.empty_cache()
+            try:  # configs[0]: the plain Unet forward on one 256x256x1 patch - the reference's CPU-runnable case, here on the GPU
+                others.insert(0, plain_unet_forward_config(dev, cpu=not a.no_cpu_baseline))
+            except Exception as ex:  # never lose the headline to an extra
+                others.insert(0, {"workload": "plain Unet forward (BASELINE.json configs[0])", "error": f"{type(ex).__name__}: {ex}"})
             out["config"]["other_configs"] = others
             # the fast mode the trainers' mixed_precision=True selects (f16x3: logits within 1e-4 of the reference's), same headline
             # workload, same process: 2 warm-up + 5 steps (NOT the headline: reduced precision, its own roofline denominator)
