@@ -153,6 +153,23 @@ int punet_pool2x2_bwd_gated(const float* dy, const float* xmask, const void* xbi
 int punet_upsample2x_bwd_gated(const float* dy, const float* xmask, const void* xbits, float* dx, int B, int H, int W, int C,
                                void* stream);
 
+/* ---- K5x: the first convolution of an UpConvBlock, y = ReLU(conv3x3(cat[up(x), bridge]) + b) (unet_blocks.py:51-57), with
+ *      the `up` source contracted at LOW resolution: bilinear interpolation (per channel) and the convolution's channel
+ *      contraction (per pixel) commute, W_t . up(x) = up(W_t . x), so
+ *          conv3x3(up(x))[p] = sum_t up(z_t)[p + t - 1],   z = 1x1 convolution of x with the [cup][9 cout] matrix w9
+ *      - a quarter of the multiply-adds of that half of the layer, and the up-sampled tensor is never materialised.
+ *      punet_upconv_relayout: the slab w[3][3][cup + cb][cout] -> w9[cup][9 cout] (w9[ci][t cout + co] = w[t][ci][co]) and the
+ *        bridge rows as a contiguous slab wb[3][3][cb][cout] (both then go through punet_split_weights_x6).
+ *      punet_upconv_gather_fwd: y <- act(y + sum_t up(z_t)[. + t - 1]) in place, y [B][2h][2w][cout] holding the bridge half's
+ *        convolution incl. bias, z [B][h][w][9][cout]; zero padding at the high resolution as in the reference; gate_out
+ *        (nullable, cout % 64 == 0) receives (y > 0) in the punet_gate_dwords layout.
+ *      punet_upconv_gather_bwd: the adjoint, dzt[b][j][t][c] = sum_q up_weight(q, j) dz[b][q - t + 1][c] with dz [B][2h][2w][cout],
+ *        dzt [B][h][w][9][cout] (gather form, deterministic); the input gradient w.r.t. x is then ONE 1x1 input gradient of dzt
+ *        with w9.  Interpolation weights are K5's. */
+int punet_upconv_relayout(const float* w, int cup, int cb, int cout, float* w9, float* wb, void* stream);
+int punet_upconv_gather_fwd(const float* z, float* y, void* gate_out, int relu, int B, int h, int w, int cout, void* stream);
+int punet_upconv_gather_bwd(const float* dz, float* dzt, int B, int h, int w, int cout, void* stream);
+
 /* ---- K6: latent head (probabilistic_unet.py:126-137): mean over H, W then 1x1 conv C -> J = 2*latent_dim.
  *      muls[b][:L] = mu, muls[b][L:] = log_sigma.  mean[b][C] is kept for the backward. */
 size_t punet_chan_sum_workspace_floats(int B, int P, int C);
@@ -406,6 +423,10 @@ int punet_rt_set_arithmetic(PunetRt* rt, int products);
 /* criterion of every later punet_rt_elbo_fwd_bwd: 0 = BCEWithLogits (rl_swap=False), 1 = Dice (rl_swap=True; recalled torch_em
  * definition, parity unpinned) */
 int punet_rt_set_criterion(PunetRt* rt, int dice);
+/* K5x for every later call on this handle: 1 (default) = the up-blocks' entry convolutions contract their `up` source at low
+ * resolution (punet_upconv_* above; the six-product parity arithmetic only), 0 = as written, on the materialised up-sampled
+ * tensor (an A/B switch; results differ by summation order only). */
+int punet_rt_set_upconv(PunetRt* rt, int on);
 long punet_rt_param_floats(const PunetRt* rt);
 long punet_rt_unet_floats(const PunetRt* rt); /* [0, this) of the flat buffers = the U-Net's tensors (final first in the backward) */
 int punet_rt_num_entries(const PunetRt* rt);

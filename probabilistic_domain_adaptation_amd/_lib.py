@@ -52,6 +52,9 @@ _SIGS = {
     "punet_upsample2x_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "punet_pool2x2_bwd_gated": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "punet_upsample2x_bwd_gated": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "punet_upconv_relayout": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "punet_upconv_gather_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "punet_upconv_gather_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "punet_chan_sum_workspace_floats": (_sz, [_i, _i, _i]),
     "punet_chan_sum": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
     "punet_latent_head_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
@@ -125,6 +128,7 @@ _SIGS.update({
     "punet_rt_destroy": (None, [_p]),
     "punet_rt_set_arithmetic": (_i, [_p, _i]),
     "punet_rt_set_criterion": (_i, [_p, _i]),
+    "punet_rt_set_upconv": (_i, [_p, _i]),
     "punet_rt_param_floats": (_l, [_p]),
     "punet_rt_unet_floats": (_l, [_p]),
     "punet_rt_num_entries": (_i, [_p]),

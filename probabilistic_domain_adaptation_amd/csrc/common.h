@@ -68,6 +68,30 @@ __device__ __forceinline__ unsigned punet_gate_nibble(const unsigned* __restrict
     return (bits[idx] >> (16 * ((c & 63) >> 5) + 4 * ((c & 31) >> 3))) & 0xFu;
 }
 
+// Bilinear x2 interpolation with align_corners=True (unet_blocks.py:51): source index of output index o along one axis as ATen
+// computes it - scale = (in - 1) / (out - 1) in fp32, src = scale * o ROUNDED (a contracted fma(scale, o, -i0) is more exact but
+// moves the interpolation weight by ulp(src) ~ 2e-6, which the cancellation src - i0 exposes).  i0 = left / upper neighbour,
+// ip = 1 when the second neighbour exists, l1 = its weight (the first neighbour's is 1 - l1).  Shared by K5 (pointwise.hip) and the
+// low-resolution form of the up-blocks' first convolution (upconv.hip) so that both interpolate with the same weights.
+__device__ __forceinline__ void punet_up_src(int o, float scale, int in_size, int& i0, int& ip, float& l1) {
+#pragma clang fp contract(off)
+    const float src = __fmul_rn(scale, (float)o);
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    ip = (i0 < in_size - 1) ? 1 : 0;
+    l1 = src - (float)i0;
+}
+// weight with which output index o reads input index i along one axis
+__device__ __forceinline__ float punet_up_weight(int o, int i, float scale, int in_size) {
+    int i0, ip;
+    float l1;
+    punet_up_src(o, scale, in_size, i0, ip, l1);
+    float w = 0.f;
+    if (i0 == i) w += 1.f - l1;
+    if (i0 + ip == i) w += l1;
+    return w;
+}
+
 // fp32 -> bf16 planes h + m + l (round to nearest each, exact residuals) for a PAIR of values in packed arithmetic:
 // v_cvt_pk_bf16_f32 converts both, the packed dword IS the LDS image's element pair, its halves shifted / masked back to
 // fp32 feed one v_pk_add_f32 per level - 9 vector instructions per pair instead of ~12 for two scalar splits, bit-identical.

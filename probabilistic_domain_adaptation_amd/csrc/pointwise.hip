@@ -149,14 +149,7 @@ __global__ __launch_bounds__(256) void pool2x2_bwd_kernel(const float4* __restri
 // source index as ATen computes it: scale = (in - 1) / (out - 1) in fp32, src = scale * dst.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void up_src(int o, float scale, int in_size, int& i0, int& ip, float& l1) {
-#pragma clang fp contract(off)
-    // __fmul_rn: keep the product ROUNDED like ATen's CPU kernel does; a contracted fma(scale, o, -i0) is more
-    // exact but moves the interpolation weight by ulp(src) ~ 2e-6, which the cancellation src - i0 exposes
-    const float src = __fmul_rn(scale, (float)o);
-    i0 = (int)src;
-    if (i0 > in_size - 1) i0 = in_size - 1;
-    ip = (i0 < in_size - 1) ? 1 : 0;
-    l1 = src - (float)i0;
+    punet_up_src(o, scale, in_size, i0, ip, l1);  // (common.h: shared with upconv.hip)
 }
 
 // grid = (ceil(OW * C4 / 256), B * OH): the source row, its neighbour and the row weight are block-uniform
@@ -229,16 +222,7 @@ __global__ __launch_bounds__(256) void upsample2x_fwd16_kernel(const void* __res
     }
 }
 
-// weight with which output index o reads input index i along one axis
-__device__ __forceinline__ float up_weight(int o, int i, float scale, int in_size) {
-    int i0, ip;
-    float l1;
-    up_src(o, scale, in_size, i0, ip, l1);
-    float w = 0.f;
-    if (i0 == i) w += 1.f - l1;
-    if (i0 + ip == i) w += l1;
-    return w;
-}
+__device__ __forceinline__ float up_weight(int o, int i, float scale, int in_size) { return punet_up_weight(o, i, scale, in_size); }
 
 #ifndef PUNET_UPBWD_BATCH
 #define PUNET_UPBWD_BATCH 1  // 0: round 2's form (per-tap divergent loads), for same-box A/B (tools/ab_variants.sh)

@@ -50,11 +50,13 @@ struct Act {
     float* grad = nullptr;  // gradient buffer once one exists (the "gm" map of engine.py)
     float* amax = nullptr;   // fp16-operand arithmetics: amax slot of t (common.h); gamax: of grad
     float* gamax = nullptr;
+    Act* up_of = nullptr;        // this tensor is the bilinear x2 of that one (an as-written up-block: K5x's input gradient applies)
+    bool up_bwd_done = false;    // ... and its consumer's backward has already produced that tensor's gradient in the low-resolution form
     size_t numel() const { return (size_t)B * H * W * C; }
 };
 
 struct Op {
-    int kind;  // 0 conv, 1 pool, 2 up
+    int kind;  // 0 conv, 1 pool, 2 up, 3 up-block entry conv in the low-resolution form (K5x: x0 = the LOW-resolution source, x1 = bridge)
     int conv;
     Act *x0, *x1, *y;
 };
@@ -94,6 +96,7 @@ struct PunetRt {
     long* d_l2 = nullptr;
     int f16_planes = 0;  // 0: six-product bf16 parity arithmetic; 2: "f16x3"; 1: "f16" (punet_rt_set_arithmetic)
     int dice = 0;        // criterion of punet_rt_elbo_fwd_bwd: 0 BCE, 1 Dice (punet_rt_set_criterion)
+    int upconv = 1;      // K5x: up-block entry convs with the `up` source contracted at low resolution (punet_rt_set_upconv; x6 only)
     // per-call state
     size_t last_arena_used = 0;
     std::vector<Act*> acts;
@@ -159,6 +162,82 @@ struct Pass {  // one forward / backward walk
     float* wamax = nullptr;   // [nconv] amax slots of the weight slabs
     float* slots = nullptr;   // zeroed pool of activation / gradient amax slots
     int nslots = 0, next_slot = 0;
+
+    // K5x (csrc/upconv.hip; engine.py upconv_fwd / _upconv_dgrad): per up-block the re-laid-out entry slab and its planes
+    struct UpW {
+        float *w9 = nullptr, *wb = nullptr;
+        __bf16 *p9 = nullptr, *pb = nullptr, *p9d = nullptr;
+    };
+    std::vector<UpW> upw;
+    static constexpr int UPCONV_MIN_CUP_GRAD = 256;  // (engine.py: PUNetEngine.UPCONV_MIN_CUP_GRAD)
+    bool up_eligible(const Conv& c, int cup) const {  // the same rule as engine.py's _upconv_ok: the two walkers agree bit for bit
+        const int cb = c.cin - cup;
+        return rt->upconv && !f16 && c.k == 3 && cup % 8 == 0 && cb % 8 == 0 && cup > SMALL_CIN && cb > SMALL_CIN && c.cout % 64 == 0;
+    }
+    int up_index(int ci) const {  // up-block of conv ci (its entry conv), -1 otherwise
+        for (size_t j = 0; j < rt->unet_up.size(); ++j)
+            if (rt->unet_up[j][0] == ci) return (int)j;
+        return -1;
+    }
+    int split_up(int mode) {
+        const int n = rt->cfg.levels;
+        upw.resize(rt->unet_up.size());
+        for (size_t j = 0; j < rt->unet_up.size(); ++j) {
+            const Conv& c = rt->convs[rt->unet_up[j][0]];
+            const int cb = rt->cfg.num_filters[n - 2 - (int)j], cup = c.cin - cb;
+            if (!up_eligible(c, cup)) continue;
+            UpW& u = upw[j];
+            const size_t n9 = (size_t)cup * 9 * c.cout, nb = (size_t)9 * cb * c.cout;
+            if (!u.w9) {
+                u.w9 = ar->floats(n9);
+                u.wb = ar->floats(nb);
+            }
+            RT_LAUNCH(punet_upconv_relayout(w(c), cup, cb, c.cout, u.w9, u.wb, stream));
+            if (mode == 0) {
+                u.p9 = (__bf16*)ar->take(3 * n9 * 2);
+                u.pb = (__bf16*)ar->take(3 * nb * 2);
+                RT_LAUNCH(punet_split_weights_x6(u.w9, u.p9, (long)n9, cup, 9 * c.cout, 1, 0, stream));
+                RT_LAUNCH(punet_split_weights_x6(u.wb, u.pb, (long)nb, cb, c.cout, 3, 0, stream));
+            } else {
+                u.p9d = (__bf16*)ar->take(3 * n9 * 2);
+                RT_LAUNCH(punet_split_weights_x6(u.w9, u.p9d, (long)n9, cup, 9 * c.cout, 1, 1, stream));
+            }
+        }
+        return PUNET_OK;
+    }
+    // ReLU(conv3x3(cat[up(x), bridge]) + b): 1x1 conv of x with w9 at the low resolution, 3x3 conv of the bridge, gather
+    int upconv_fwd(int j, Act* x, Act* bridge, std::vector<Op>* tape, Act** out) {
+        const int ci = rt->unet_up[j][0];
+        const Conv& c = rt->convs[ci];
+        const UpW& u = upw[j];
+        const int B = x->B, h = x->H, wd = x->W, cup = x->C, cb = bridge->C;
+        float* z = ar->floats((size_t)B * h * wd * 9 * c.cout);
+        RT_LAUNCH(punet_conv1x1_x6_gated(x->t, cup, nullptr, 0, u.p9, (long)cup * 9 * c.cout, 9 * c.cout, 0, nullptr, 0, z, 9 * c.cout, nullptr,
+                                         nullptr, nullptr, 0, 0, B, h, wd, stream));
+        Act* y = rt->new_act(ar->floats((size_t)B * 4 * h * wd * c.cout), B, 2 * h, 2 * wd, c.cout, true);
+        RT_LAUNCH(punet_conv3x3_x6_gated(bridge->t, cb, nullptr, 0, u.pb, (long)9 * cb * c.cout, c.cout, 0, b(c), 0, y->t, c.cout, nullptr,
+                                         nullptr, nullptr, 0, 0, B, 2 * h, 2 * wd, X6_OPTS, stream));
+        if (tape) y->bits = (unsigned*)ar->take(punet_gate_dwords(B, 2 * h, 2 * wd, c.cout) * 4);
+        RT_LAUNCH(punet_upconv_gather_fwd(z, y->t, y->bits, 1, B, h, wd, c.cout, stream));
+        if (tape) tape->push_back(Op{3, ci, x, bridge, y});
+        *out = y;
+        return PUNET_OK;
+    }
+    // d loss / d x of the layer above given dz: nine adjoint-interpolated maps of dz, one 1x1 input gradient with w9, x's ReLU gate
+    int upconv_dgrad(int j, Act* x, const float* dz) {
+        const Conv& c = rt->convs[rt->unet_up[j][0]];
+        const UpW& u = upw[j];
+        const int B = x->B, h = x->H, wd = x->W, cup = x->C;
+        float* dzt = ar->floats((size_t)B * h * wd * 9 * c.cout);
+        RT_LAUNCH(punet_upconv_gather_bwd(dz, dzt, B, h, wd, c.cout, stream));
+        int acc = 0;
+        float* g = grad_into(x, &acc);
+        const bool use_bits = x->bits && x->relu_out;
+        RT_LAUNCH(punet_conv1x1_x6_gated(dzt, 9 * c.cout, nullptr, 0, u.p9d, (long)cup * 9 * c.cout, cup, 0, nullptr, 0, g, cup,
+                                         (x->relu_out && !use_bits) ? x->t : nullptr, use_bits ? x->bits : nullptr, nullptr, acc, 0, B, h, wd,
+                                         stream));
+        return PUNET_OK;
+    }
 
     int begin_slots(int n) {  // (fp16-operand arithmetics) a zeroed pool for this pass
         if (!f16) return PUNET_OK;
@@ -290,12 +369,18 @@ struct Pass {  // one forward / backward walk
         std::vector<Act*> outs;
         RT_CALL(encoder_stack(rt->unet_down, x, tape, &outs, &x));
         for (size_t j = 0; j < rt->unet_up.size(); ++j) {
-            Act* up = rt->new_act(ar->floats((size_t)x->B * 4 * x->H * x->W * x->C), x->B, 2 * x->H, 2 * x->W, x->C, false);
-            up->amax = x->amax;  // a bound: bilinear interpolation is a convex combination
-            RT_LAUNCH(punet_upsample2x_fwd(x->t, up->t, x->B, x->H, x->W, x->C, stream));
-            if (tape) tape->push_back(Op{2, -1, x, nullptr, up});
             Act* bridge = outs[outs.size() - 2 - j];
-            RT_CALL(conv(rt->unet_up[j][0], up, bridge, true, tape, nullptr, &x));  // concat order [up, bridge] (unet_blocks.py:56)
+            const bool elig = up_eligible(rt->convs[rt->unet_up[j][0]], x->C) && x->C + bridge->C == rt->convs[rt->unet_up[j][0]].cin;
+            if (elig && (!tape || x->C >= UPCONV_MIN_CUP_GRAD)) {
+                RT_CALL(upconv_fwd((int)j, x, bridge, tape, &x));
+            } else {
+                Act* up = rt->new_act(ar->floats((size_t)x->B * 4 * x->H * x->W * x->C), x->B, 2 * x->H, 2 * x->W, x->C, false);
+                up->amax = x->amax;  // a bound: bilinear interpolation is a convex combination
+                if (elig) up->up_of = x;
+                RT_LAUNCH(punet_upsample2x_fwd(x->t, up->t, x->B, x->H, x->W, x->C, stream));
+                if (tape) tape->push_back(Op{2, -1, x, nullptr, up});
+                RT_CALL(conv(rt->unet_up[j][0], up, bridge, true, tape, nullptr, &x));  // concat order [up, bridge] (unet_blocks.py:56)
+            }
             RT_CALL(conv(rt->unet_up[j][1], x, nullptr, true, tape, nullptr, &x));
             RT_CALL(conv(rt->unet_up[j][2], x, nullptr, true, tape, nullptr, &x));
         }
@@ -353,7 +438,10 @@ struct Pass {  // one forward / backward walk
                 int off = 0;
                 for (Act* src : {op.x0, op.x1}) {
                     if (!src) continue;
-                    if (src->needs_grad) {
+                    if (src == op.x0 && op.x1 && src->up_of) {  // x0 = up(low-res tensor): K5x's input gradient, the `up` op's backward is skipped
+                        if (src->up_of->needs_grad) RT_CALL(upconv_dgrad(up_index(op.conv), src->up_of, dz));
+                        src->up_bwd_done = true;
+                    } else if (src->needs_grad) {
                         int acc = 0;
                         float* g = grad_into(src, &acc);
                         const float* mask = src->relu_out ? src->t : nullptr;
@@ -372,6 +460,28 @@ struct Pass {  // one forward / backward walk
                     }
                     off += src->C;
                 }
+            } else if (op.kind == 3) {  // K5x forward: weight gradient as written (on the up-sampled tensor, materialised here), the bridge's
+                const Conv& c = rt->convs[op.conv];  // input gradient by the ordinary kernel, the low-resolution source's in the new form
+                const float* dz = op.y->grad;
+                if (!dz && !dry) {
+                    punet_set_error("punet_rt: no gradient reached %s", c.name.c_str());
+                    return PUNET_ERR_ARG;
+                }
+                Act *x = op.x0, *bridge = op.x1;
+                Act* up = rt->new_act(ar->floats((size_t)x->B * 4 * x->H * x->W * x->C), x->B, 2 * x->H, 2 * x->W, x->C, false);
+                RT_LAUNCH(punet_upsample2x_fwd(x->t, up->t, x->B, x->H, x->W, x->C, stream));
+                RT_CALL(wgrad(c, up, 0, dz, op.y->gamax, true, accumulate));
+                RT_CALL(wgrad(c, bridge, x->C, dz, op.y->gamax, false, accumulate));
+                if (bridge->needs_grad) {
+                    int acc = 0;
+                    float* g = grad_into(bridge, &acc);
+                    const float* mask = bridge->relu_out ? bridge->t : nullptr;
+                    const bool use_bits = bridge->bits && mask;
+                    RT_LAUNCH(punet_conv3x3_x6_gated(dz, c.cout, nullptr, 0, planes1 + 3 * c.w_off, c.w_numel(), c.cin, x->C, nullptr, 0, g,
+                                                   bridge->C, use_bits ? nullptr : mask, use_bits ? bridge->bits : nullptr, nullptr, acc, 0,
+                                                   bridge->B, bridge->H, bridge->W, X6_OPTS, stream));
+                }
+                if (x->needs_grad) RT_CALL(upconv_dgrad(up_index(op.conv), x, dz));
             } else if (op.kind == 1) {
                 int acc = 0;
                 float* g = grad_into(op.x0, &acc);
@@ -385,6 +495,7 @@ struct Pass {  // one forward / backward walk
                     op.x0->gamax = sl;
                 }
             } else {
+                if (op.y->up_bwd_done) continue;  // (the consumer's backward produced op.x0's gradient in the low-resolution form)
                 int acc = 0;
                 float* g = grad_into(op.x0, &acc);
                 const void* bits = (op.x0->relu_out && op.x0->bits) ? op.x0->bits : nullptr;
@@ -547,6 +658,14 @@ extern "C" int punet_rt_set_criterion(PunetRt* rt, int dice) {
     return PUNET_OK;
 }
 
+// K5x for every later call on this handle: 1 (default) = up-block entry convs with the `up` source contracted at low resolution
+// (csrc/upconv.hip; the parity arithmetic only), 0 = the layer as written, on the materialised up-sampled tensor (an A/B switch)
+extern "C" int punet_rt_set_upconv(PunetRt* rt, int on) {
+    PUNET_CHECK_ARG(rt && (on == 0 || on == 1), "punet_rt_set_upconv: 0 or 1");
+    rt->upconv = on;
+    return PUNET_OK;
+}
+
 extern "C" void punet_rt_destroy(PunetRt* rt) {
     if (!rt) return;
     rt->clear_acts();
@@ -600,6 +719,7 @@ static int pseudo_labels_body(PunetRt* rt, const float* flat, const float* x, in
     float* zs = ar.floats((size_t)N * B * L);
     float* zb = ar.floats((size_t)N * B * CH);
     RT_CALL(p.split(0, &p.planes0));
+    RT_CALL(p.split_up(0));
     float *muls = nullptr, *mean = nullptr;
     Act *enc = nullptr, *feat = nullptr;
     RT_CALL(p.latent(rt->enc_prior, rt->head_prior, xin, nullptr, &muls, &mean, &enc));
@@ -653,6 +773,7 @@ static int elbo_body(PunetRt* rt, const float* flat, float* gflat, const float* 
     p.ws_wgrad = ar.floats(max_wgrad_ws_floats(rt, B, H, W));
     // ---- forward: posterior on [patch, segm], prior, U-Net (tapes recorded)
     RT_CALL(p.split(0, &p.planes0));
+    RT_CALL(p.split_up(0));
     Act* xin = rt->new_act(const_cast<float*>(x), B, H, W, C, false, false);
     Act* xq = rt->new_act(ar.floats((size_t)B * H * W * (C + 1)), B, H, W, C + 1, false, false);
     if (!dry) RT_CALL(punet_concat_nhwc(x, C, target, 1, xq->t, (long)B * H * W, stream));
@@ -686,6 +807,7 @@ static int elbo_body(PunetRt* rt, const float* flat, float* gflat, const float* 
     }
     // ---- backward
     RT_CALL(p.split(1, &p.planes1));
+    RT_CALL(p.split_up(1));
     if (!dry) {
         RT_CALL(punet_fcomb_train_reduce(ws_f, gflat + c1.w_off, c1.cin, gflat + c1.b_off, cm ? gflat + cm->w_off : nullptr,
                                          cm ? gflat + cm->b_off : nullptr, gflat + c3.w_off, gflat + c3.b_off, S, p.ws_chan, B, H * W, CH,

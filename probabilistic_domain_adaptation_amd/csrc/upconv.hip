@@ -1,0 +1,280 @@
+// K5x: the first convolution of an UpConvBlock with its `up` source contracted at LOW resolution.
+//
+// The reference computes  y = ReLU(conv3x3(cat[up(x), bridge]) + b)  with up = bilinear x2, align_corners=True
+// (unet_blocks.py:51-57).  Interpolation acts per channel, the convolution's channel contraction per pixel, so they commute:
+//     W_t . up(x)[q] = up(W_t . x)[q]      for every tap t and every high-resolution position q,
+// hence, with zero padding at the HIGH resolution as in the reference,
+//     conv3x3(up(x))[p] = sum_t [q = p + t - 1 inside the image] up(z_t)[q],      z_t = W_t . x .
+// The nine z_t are ONE 1x1 convolution of the low-resolution tensor with 9 cout output channels (a quarter of the multiply-adds
+// of the `up` half of the layer, which is two thirds of it), and the up-sampled tensor never exists.  What is left at the high
+// resolution is a gather: 9 taps x 4 bilinear neighbours of [cout]-vectors per output pixel, added to the bridge half's
+// convolution (the ordinary 3x3 kernel on the bridge alone), then bias (already in the bridge half), ReLU and the gate bits.
+// The same algebra turns the input gradient w.r.t. x into nine ADJOINT-interpolated maps of dz followed by one 1x1 input gradient
+//     dz_t[j] = sum_q up_weight(q, j) . dz[q - t + 1],        dx = gate(x) . sum_t W_t^T . dz_t .
+// Interpolation weights are K5's (punet_up_src in common.h: ATen's rounding of the source index).
+//
+// Entry points (include/punet_hip.h): punet_upconv_relayout (the weight slab's `up` rows as the [cup][9 cout] matrix of that 1x1
+// convolution, its bridge rows as a contiguous 3x3 slab), punet_upconv_gather_fwd, punet_upconv_gather_bwd.
+#include "common.h"
+#include "punet_hip.h"
+
+namespace {
+
+#define STREAM ((hipStream_t)stream)
+#ifndef PUNET_UPCONV_NX
+#define PUNET_UPCONV_NX 4  // output columns per thread of the forward gather (4 or 8; same-box A/B)
+#endif
+
+// w[t][ci][co] (ci < cup + cb) -> w9[ci][t * cout + co] for ci < cup ; wb[t][ci - cup][co] for the others (float4 units)
+__global__ __launch_bounds__(256) void upconv_relayout_kernel(const float4* __restrict__ w, float4* __restrict__ w9, float4* __restrict__ wb,
+                                                              int cup, int cb, int co4) {
+    const int ctot = cup + cb;
+    const size_t n = (size_t)9 * ctot * co4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % co4);
+        const int ci = (int)((i / co4) % ctot);
+        const int t = (int)(i / ((size_t)co4 * ctot));
+        const float4 v = w[i];
+        if (ci < cup)
+            w9[((size_t)ci * 9 + t) * co4 + c] = v;
+        else
+            wb[((size_t)t * cb + (ci - cup)) * co4 + c] = v;
+    }
+}
+
+// y[b][Y][X][c] = act(y[b][Y][X][c] + sum_{ky, kx} up(z_{ky,kx})[Y + ky - 1][X + kx - 1][c]),  z: [B][h][w][9][C], y: [B][2h][2w][C]
+// A thread owns NX consecutive output columns of one channel quad: per tap their 2 NX bilinear column neighbours fall into
+// NX / 2 + 2 consecutive low-resolution columns (the x2 scale is just below 1/2), so a tap costs 2 (NX / 2 + 2) loads for NX outputs
+// instead of 4 NX - the first version (one output per thread, 36 loads each) ran at the vector L1's rate, not at HBM's.  The two
+// source rows are interpolated first (per loaded column), then each output picks its two columns by select.
+// grid = (ceil(ceil(2w / NX) * C4 / 256), B * 2h rows): the three source-row pairs and their weights are block-uniform.
+// BITS: publish (y > 0) in the punet_gate_dwords layout (C a multiple of 64: the 16 float4 of a pixel's 64-channel block sit in 16
+// consecutive lanes; a dword's nibbles are joined by an OR over the lanes that differ in bits 1..3).
+template <bool BITS, int NX>
+__global__ __launch_bounds__(256, 3) void upconv_gather_fwd_kernel(const float4* __restrict__ z, float4* __restrict__ y,
+                                                                unsigned* __restrict__ bits, int B, int h, int w, int C4, int c4_shift,
+                                                                int relu) {
+    static_assert(NX == 4, "four outputs per thread: their neighbours fall into NX / 2 + 2 = 4 consecutive low-resolution columns");
+    const int H = 2 * h, W = 2 * w;
+    const int WG = (W + NX - 1) / NX;  // column groups per row
+    const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= (unsigned)(WG * C4)) return;  // (C4 is a multiple of 16 when BITS: the lane groups of the reduction leave together)
+    const int xg = c4_shift >= 0 ? (int)(e >> c4_shift) : (int)(e / (unsigned)C4);
+    const int c4 = (int)e - xg * C4;
+    const int X0 = xg * NX;
+    // per tap column kx: the first low-resolution column of the run, and per output its interpolation as WEIGHTS on the run's columns
+    // (at most two are non-zero; zero padding and a missing second neighbour are weights of zero).  Output i can only reach columns
+    // 0 .. NCOL[i] - 1 of the run: the scale is below 1/2, so its first neighbour lies at most (i + 1) / 2 columns behind output 0's.
+    // Weights instead of a select of the two columns: the kernel is bound by its vector instructions (the select form needed 590
+    // per output against ~210 here), not by its loads.
+    constexpr int NCOL[4] = {2, 3, 3, 4};
+    int cmin[3];
+    float wgt[3][4][4];  // [kx][output][column]: only the first NCOL[output] entries are used (the rest is never read)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int qx = X0 + i + kx - 1;
+            const bool ok = qx >= 0 && qx < W && X0 + i < W;
+            int c0, cp;
+            float l1;
+            punet_up_src(min(max(qx, 0), W - 1), sw, w, c0, cp, l1);
+            if (i == 0) cmin[kx] = c0;
+            const int d = c0 - cmin[kx];  // monotone in qx
+            const float w0 = ok ? (cp ? 1.f - l1 : 1.f) : 0.f, w1 = (ok && cp) ? l1 : 0.f;
+#pragma unroll
+            for (int j = 0; j < NCOL[i]; ++j) wgt[kx][i][j] = j == d ? w0 : (j == d + 1 ? w1 : 0.f);
+        }
+    }
+    const unsigned pix9 = 9u * (unsigned)C4;  // float4 units per low-resolution pixel of z
+    // ONE output row per block (grid.y x grid.z), no loop over rows: a grid-stride row loop made every per-thread address part a
+    // loop invariant that the optimiser hoisted in front of it - ~70 64-bit values, 250 registers, spills
+    {
+        const unsigned row = blockIdx.z * gridDim.y + blockIdx.y;
+        if (row >= (unsigned)(B * H)) return;
+        const unsigned b = row / (unsigned)H;
+        const int Y = (int)(row - b * (unsigned)H);
+        float4 a[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int qy = Y + ky - 1;
+            if (qy < 0 || qy >= H) continue;  // block-uniform
+            int r0, rp;
+            float hl1;
+            punet_up_src(qy, sh, h, r0, rp, hl1);
+            const float hl0 = 1.f - hl1;
+            // block-uniform 64-bit row bases + 32-bit per-thread offsets inside a low-resolution row
+            const float4* z0 = z + ((size_t)b * h + r0) * w * pix9 + (size_t)(3 * ky) * C4;
+            const float4* z1 = z0 + (size_t)rp * w * pix9;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                // both rows of the NC = 4 columns first, then their interpolation.  Four NAMED values, not an array: a select chain
+                // over array elements is turned into a dynamically indexed load by the optimiser - the array then lives in scratch
+                // memory (measured: 112 bytes of scratch per lane, 256 registers, 9x slower)
+                auto col = [&](int j) __attribute__((always_inline)) -> float4 {
+                    const unsigned o = (unsigned)min(cmin[kx] + j, w - 1) * pix9 + (unsigned)(kx * C4 + c4);
+                    const float4 t0 = z0[o], t1 = z1[o];
+                    return make_float4(hl0 * t0.x + hl1 * t1.x, hl0 * t0.y + hl1 * t1.y, hl0 * t0.z + hl1 * t1.z, hl0 * t0.w + hl1 * t1.w);
+                };
+                const float4 v0 = col(0), v1 = col(1), v2 = col(2), v3 = col(3);
+                const float4 vv[4] = {v0, v1, v2, v3};  // (indexed by compile-time constants only)
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+#pragma unroll
+                    for (int j = 0; j < NCOL[i]; ++j) {
+                        const float g = wgt[kx][i][j];
+                        a[i].x += g * vv[j].x; a[i].y += g * vv[j].y; a[i].z += g * vv[j].z; a[i].w += g * vv[j].w;
+                    }
+                }
+                // one tap's loads in flight per wave, not all nine (the scheduler otherwise hoists every load of the row to the top:
+                // 256 registers, one wave per SIMD - latency is hidden by the resident waves instead)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int X = X0 + i;
+            if (X >= W) continue;  // (W is even; with NX = 4 the last group of a row may be half empty)
+            const size_t idx4 = ((size_t)row * W + X) * C4 + c4;
+            float4 o = y[idx4];
+            o.x += a[i].x; o.y += a[i].y; o.z += a[i].z; o.w += a[i].w;
+            if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            y[idx4] = o;
+            if constexpr (BITS) {
+                const int cl = (4 * c4) & 63;  // first channel of this float4 inside its 64-channel block
+                unsigned g = ((o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u))
+                             << (16 * (cl >> 5) + 4 * ((cl >> 3) & 3));
+                g |= __shfl_xor(g, 2, 64);
+                g |= __shfl_xor(g, 4, 64);
+                g |= __shfl_xor(g, 8, 64);
+                if ((c4 & 14) == 0) {  // lanes c4 % 16 == 0 / 1 write the dwords of half 0 / 1
+                    const int tiles = (W + 31) >> 5, cbs = (4 * C4 + 63) >> 6;
+                    const size_t idx = (((((size_t)b * H + Y) * tiles + (X >> 5)) * cbs + (c4 >> 4)) << 6) + (X & 31) + 32 * (c4 & 1);
+                    bits[idx] = g;
+                }
+            }
+        }
+    }
+}
+
+// dzt[b][jy][jx][t][c] = sum_{oy, ox} wy(oy, jy) wx(ox, jx) dz[b][oy - ky + 1][ox - kx + 1][c]   (t = 3 ky + kx; positions outside
+// the image contribute nothing: the forward's zero padding)  - gather form, deterministic.
+// A thread owns ALL NINE taps of one low-resolution pixel and channel quad: their windows into dz overlap almost completely (rows
+// oy0 - 1 .. oy1 + 1, columns ox0 - 1 .. ox0 + 7), so the window is loaded once - 9 columns per row for 9 outputs - instead of once
+// per tap (the first version: one tap per thread, ~25 loads per output, ran at a third of the forward's rate).
+// grid = (ceil(w * C4 / 256), B * h rows): the (up to 7) row weights are block-uniform (as in K5's backward).
+__global__ __launch_bounds__(256) void upconv_gather_bwd_kernel(const float4* __restrict__ dz, float4* __restrict__ dzt, int B, int h,
+                                                                int w, int C4, int c4_shift) {
+    const int H = 2 * h, W = 2 * w;
+    const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= (unsigned)(w * C4)) return;
+    const int jx = c4_shift >= 0 ? (int)(e >> c4_shift) : (int)(e / (unsigned)C4);
+    const int c4 = (int)e - jx * C4;
+    const int ox0 = max(0, 2 * jx - 2), ox1 = min(W - 1, 2 * jx + 4);
+    float wx[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) wx[k] = ox0 + k <= ox1 ? punet_up_weight(ox0 + k, jx, sw, w) : 0.f;
+    // the nine window columns ox0 - 1 .. ox0 + 7: clamped address, zero outside the image
+    int pcol[9];
+    bool pin[9];
+#pragma unroll
+    for (int m = 0; m < 9; ++m) {
+        const int p = ox0 - 1 + m;
+        pin[m] = p >= 0 && p < W;
+        pcol[m] = min(max(p, 0), W - 1) * C4;
+    }
+    for (unsigned row = blockIdx.y; row < (unsigned)(B * h); row += gridDim.y) {
+        const unsigned b = row / (unsigned)h;
+        const int jy = (int)(row - b * (unsigned)h);
+        const int oy0 = max(0, 2 * jy - 2), oy1 = min(H - 1, 2 * jy + 4);
+        float wy[7];  // block-uniform
+#pragma unroll
+        for (int k = 0; k < 7; ++k) wy[k] = oy0 + k <= oy1 ? punet_up_weight(oy0 + k, jy, sh, h) : 0.f;
+        float4 acc[3][3];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t / 3][t % 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int pi = 0; pi < 9; ++pi) {  // window row p = oy0 - 1 + pi of dz; tap row ky reads it for oy = p + ky - 1 = oy0 + pi + ky - 2
+            const int p = oy0 - 1 + pi;
+            float wk[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) wk[ky] = (pi + ky - 2 >= 0 && pi + ky - 2 < 7) ? wy[pi + ky - 2] : 0.f;
+            if ((wk[0] == 0.f && wk[1] == 0.f && wk[2] == 0.f) || p < 0 || p >= H) continue;  // block-uniform
+            const float4* drow = dz + (((size_t)b * H + p) * W) * C4 + c4;
+            float4 g[9];
+#pragma unroll
+            for (int m = 0; m < 9; ++m) g[m] = drow[pcol[m]];
+#pragma unroll
+            for (int m = 0; m < 9; ++m)
+                if (!pin[m]) g[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {  // tap column kx reads dz column ox - kx + 1 = window index k - kx + 2 for ox = ox0 + k
+                float4 hsum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    const float4 v = g[k - kx + 2];
+                    hsum.x += wx[k] * v.x; hsum.y += wx[k] * v.y; hsum.z += wx[k] * v.z; hsum.w += wx[k] * v.w;
+                }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    acc[ky][kx].x += wk[ky] * hsum.x; acc[ky][kx].y += wk[ky] * hsum.y;
+                    acc[ky][kx].z += wk[ky] * hsum.z; acc[ky][kx].w += wk[ky] * hsum.w;
+                }
+            }
+        }
+        float4* out = dzt + ((size_t)row * w + jx) * 9 * C4 + c4;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) out[(size_t)t * C4] = acc[t / 3][t % 3];
+    }
+}
+
+int shift_of(int c4) {  // log2 when a power of two, else -1
+    for (int s = 0; s < 16; ++s)
+        if ((1 << s) == c4) return s;
+    return -1;
+}
+
+}  // namespace
+
+extern "C" int punet_upconv_relayout(const float* w, int cup, int cb, int cout, float* w9, float* wb, void* stream) {
+    PUNET_CHECK_ARG(w && w9 && wb && cup > 0 && cb > 0 && cout > 0 && cout % 4 == 0, "punet_upconv_relayout: bad args (cup=%d cb=%d cout=%d)",
+                    cup, cb, cout);
+    const size_t n = (size_t)9 * (cup + cb) * (cout / 4);
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    upconv_relayout_kernel<<<grid, 256, 0, STREAM>>>((const float4*)w, (float4*)w9, (float4*)wb, cup, cb, cout / 4);
+    PUNET_LAUNCH_CHECK("upconv_relayout");
+    return PUNET_OK;
+}
+
+extern "C" int punet_upconv_gather_fwd(const float* z, float* y, void* gate_out, int relu, int B, int h, int w, int cout, void* stream) {
+    PUNET_CHECK_ARG(z && y && B > 0 && h > 0 && w > 0 && cout > 0 && cout % 4 == 0, "punet_upconv_gather_fwd: bad args (cout=%d)", cout);
+    PUNET_CHECK_ARG(!gate_out || cout % 64 == 0, "punet_upconv_gather_fwd: gate bits need cout %% 64 == 0 (got %d)", cout);
+    const int C4 = cout / 4, W = 2 * w;
+    PUNET_CHECK_ARG((size_t)w * 9 * C4 < (1ull << 31) && (size_t)W * C4 < (1ull << 31), "punet_upconv_gather_fwd: a row exceeds 2^31 float4 elements");
+    constexpr int NX = PUNET_UPCONV_NX;
+    const int rows = B * 2 * h, gy = rows < 65535 ? rows : 65535;
+    const dim3 grid(ceil_div(ceil_div(W, NX) * C4, 256), gy, ceil_div(rows, gy));
+    if (gate_out)
+        upconv_gather_fwd_kernel<true, NX><<<grid, 256, 0, STREAM>>>((const float4*)z, (float4*)y, (unsigned*)gate_out, B, h, w, C4, shift_of(C4), relu);
+    else
+        upconv_gather_fwd_kernel<false, NX><<<grid, 256, 0, STREAM>>>((const float4*)z, (float4*)y, nullptr, B, h, w, C4, shift_of(C4), relu);
+    PUNET_LAUNCH_CHECK("upconv_gather_fwd");
+    return PUNET_OK;
+}
+
+extern "C" int punet_upconv_gather_bwd(const float* dz, float* dzt, int B, int h, int w, int cout, void* stream) {
+    PUNET_CHECK_ARG(dz && dzt && B > 0 && h > 0 && w > 0 && cout > 0 && cout % 4 == 0, "punet_upconv_gather_bwd: bad args (cout=%d)", cout);
+    const int C4 = cout / 4;
+    PUNET_CHECK_ARG((size_t)B * 4 * h * w * C4 < (1ull << 31) && (size_t)B * h * w * 9 * C4 < (1ull << 31),
+                    "punet_upconv_gather_bwd: more than 2^31 float4 elements");
+    const dim3 grid(ceil_div(w * C4, 256), B * h < 65535 ? B * h : 65535);
+    upconv_gather_bwd_kernel<<<grid, 256, 0, STREAM>>>((const float4*)dz, (float4*)dzt, B, h, w, C4, shift_of(C4));
+    PUNET_LAUNCH_CHECK("upconv_gather_bwd");
+    return PUNET_OK;
+}

@@ -278,6 +278,10 @@ class PUNetEngine:
         self._x6 = {}  # (flat.data_ptr(), mode) -> bf16 planes buffer [3 * numel]
         self._x6_table = None  # (device int64 [nconv+1, 4], nconv, total_units) for punet_split_weights_x6_batch
         self._x6_1x1 = {}  # (flat.data_ptr(), mode) -> {conv name: bf16 planes} for the Fcomb 1x1 layers
+        # K5x (csrc/upconv.hip): the first conv of an up-block with its `up` source contracted at LOW resolution - the parity
+        # arithmetic only ($PUNET_UPCONV=0: the layer as written, on the materialised up-sampled tensor; an A/B switch)
+        self.upconv = self.conv_mode == "x6" and os.environ.get("PUNET_UPCONV", "1") != "0"
+        self._up = {}  # (flat.data_ptr(), conv name) -> dict(w9, wb fp32 re-layouts; p9, pb forward planes; p9d input-gradient planes)
         tab, self.l2_ntensors = layout.l2_chunk_table()
         self.l2_chunks = tab.to(self.device)
         self.l2_nchunks = tab.shape[0]
@@ -441,6 +445,70 @@ class PUNetEngine:
             taps["conv:" + name] = y
         return y
 
+    # ---------------------------------------------------------------- K5x: up-block entry conv at low resolution
+    UPCONV_MIN_CUP_GRAD = 256  # forward passes a backward follows keep the layer as written below this many `up` channels: their weight
+    # gradient needs the up-sampled tensor anyway, and the gather then costs what the saved matrix work is worth (tools/pushdown_probe.py)
+
+    def _upconv_ok(self, c: ConvP, x: Act, bridge: Act) -> bool:
+        """Shapes the low-resolution form serves (same rule as csrc/runtime.hip: the two graph walkers agree bit for bit)."""
+        return (self.upconv and c.k == 3 and x.C % 8 == 0 and bridge.C % 8 == 0 and x.C > SMALL_CIN and bridge.C > SMALL_CIN
+                and c.cout % 64 == 0 and x.t.dtype == torch.float32 and bridge.t.dtype == torch.float32)
+
+    def _up_weights(self, flat, c: ConvP, cup: int, mode: int):
+        """Re-layout + plane split of one up-block entry slab: w9 [cup][9 cout] (the 1x1 form of the `up` rows) and the bridge rows
+        as a 3x3 slab; mode 0: forward planes of both, mode 1: input-gradient planes of w9 (the bridge's input gradient takes the
+        ordinary planes of the whole slab)."""
+        key = (flat.data_ptr(), c.name)
+        d = self._up.get(key)
+        cb, n9, nb = c.cin - cup, cup * 9 * c.cout, 9 * (c.cin - cup) * c.cout
+        if d is None:
+            d = {"w9": self._empty(n9), "wb": self._empty(nb),
+                 "p9": torch.empty(3 * n9, dtype=torch.bfloat16, device=self.device),
+                 "pb": torch.empty(3 * nb, dtype=torch.bfloat16, device=self.device),
+                 "p9d": torch.empty(3 * n9, dtype=torch.bfloat16, device=self.device)}
+            self._up[key] = d
+        _lib.call("punet_upconv_relayout", self._wptr(flat, c), cup, cb, c.cout, d["w9"].data_ptr(), d["wb"].data_ptr(), _stream())
+        if mode == 0:
+            _lib.call("punet_split_weights_x6", d["w9"].data_ptr(), d["p9"].data_ptr(), n9, cup, 9 * c.cout, 1, 0, _stream())
+            _lib.call("punet_split_weights_x6", d["wb"].data_ptr(), d["pb"].data_ptr(), nb, cb, c.cout, 3, 0, _stream())
+        else:
+            _lib.call("punet_split_weights_x6", d["w9"].data_ptr(), d["p9d"].data_ptr(), n9, cup, 9 * c.cout, 1, 1, _stream())
+        return d
+
+    def _split_up(self, flat, mode: int):
+        if not self.upconv or self.L.kind not in ("punet", "unet"):
+            return
+        nf = self.L.nf
+        for j, names in enumerate(self.L.unet_up):
+            c = self.L.convs[names[0]]
+            cup = c.cin - nf[len(nf) - 2 - j]
+            if c.k == 3 and cup % 8 == 0 and (c.cin - cup) % 8 == 0 and cup > SMALL_CIN and c.cin - cup > SMALL_CIN and c.cout % 64 == 0:
+                self._up_weights(flat, c, cup, mode)
+
+    def upconv_fwd(self, flat, name: str, x: Act, bridge: Act, tape=None, taps=None) -> Act:
+        """ReLU(conv3x3(cat[up(x), bridge]) + b) (unet_blocks.py:51-57) as  1x1 conv of x with w9 at the low resolution, 3x3 conv of
+        the bridge, interpolating gather (csrc/upconv.hip).  The up-sampled tensor is not materialised."""
+        c = self.L.convs[name]
+        B, h, w, cup, cb = x.B, x.H, x.W, x.C, bridge.C
+        H, W = 2 * h, 2 * w
+        d = self._up[(flat.data_ptr(), name)]
+        z = self._empty(B, h, w, 9 * c.cout)
+        self._timed("conv1x1_fwd", 2.0 * B * h * w * cup * 9 * c.cout, "punet_conv1x1_x6_gated", x.ptr, cup, None, 0, d["p9"].data_ptr(),
+                    cup * 9 * c.cout, 9 * c.cout, 0, None, 0, z.data_ptr(), 9 * c.cout, None, None, None, 0, 0, B, h, w, _stream())
+        y = Act(self._empty(B, H, W, c.cout), B, H, W, c.cout, relu_out=True)
+        self._timed("conv3x3_fwd", 2.0 * B * H * W * cb * c.cout * 9, "punet_conv3x3_x6_gated", bridge.ptr, cb, None, 0,
+                    d["pb"].data_ptr(), 9 * cb * c.cout, c.cout, 0, self._bptr(flat, c), 0, y.ptr, c.cout, None, None, None, 0, 0,
+                    B, H, W, self.x6_opts, _stream())
+        if tape is not None:
+            y.bits = torch.empty(_lib.call("punet_gate_dwords", B, H, W, c.cout), dtype=torch.int32, device=self.device)
+        _lib.call("punet_upconv_gather_fwd", z.data_ptr(), y.ptr, y.bits.data_ptr() if y.bits is not None else None, 1, B, h, w,
+                  c.cout, _stream())
+        if tape is not None:
+            tape.append(("upconv", c, x, bridge, y))
+        if taps is not None:
+            taps["conv:" + name] = y
+        return y
+
     def pool(self, x: Act, tape=None) -> Act:
         OH, OW = (x.H + 1) // 2, (x.W + 1) // 2
         y = Act(self._empty(x.B, OH, OW, x.C), x.B, OH, OW, x.C)
@@ -492,10 +560,15 @@ class PUNetEngine:
             raise ValueError(f"H and W must be divisible by {1 << (len(self.L.nf) - 1)} (got {x.H}x{x.W})")
         x, outs = self.encoder_stack(flat, self.L.unet_down, x, tape, taps, "unet.down")
         for j, names in enumerate(self.L.unet_up):
-            up = self.upsample(x, tape)
             bridge = outs[-j - 2]
-            assert up.W == bridge.W and up.H == bridge.H  # unet_blocks.py:55
-            x = self.conv(flat, names[0], up, bridge, True, tape, taps)  # concat order [up, bridge] (unet_blocks.py:56)
+            c0 = self.L.convs[names[0]]
+            if self._upconv_ok(c0, x, bridge) and (tape is None or x.C >= self.UPCONV_MIN_CUP_GRAD):
+                assert 2 * x.W == bridge.W and 2 * x.H == bridge.H  # unet_blocks.py:55
+                x = self.upconv_fwd(flat, names[0], x, bridge, tape, taps)
+            else:
+                up = self.upsample(x, tape)
+                assert up.W == bridge.W and up.H == bridge.H  # unet_blocks.py:55
+                x = self.conv(flat, names[0], up, bridge, True, tape, taps)  # concat order [up, bridge] (unet_blocks.py:56)
             x = self.conv(flat, names[1], x, None, True, tape, taps)
             x = self.conv(flat, names[2], x, None, True, tape, taps)
             if taps is not None:
@@ -901,6 +974,7 @@ class PUNetEngine:
         if self.x6:
             self._split_x6(flat, 0)
             self._split_x6_1x1(flat, 0)
+            self._split_up(flat, 0)
 
     def prepare_dgrad_weights(self, flat):
         """Bring every conv weight slab into forward-kernel orientation for the input-gradient pass
@@ -908,6 +982,7 @@ class PUNetEngine:
         if self.x6:
             self._split_x6(flat, 1)
             self._split_x6_1x1(flat, 1)
+            self._split_up(flat, 1)
         if self.wT is None or self.wT.numel() != flat.numel():
             self.wT = torch.empty_like(flat)
         served = {c.name for c, _ in self._fcomb_1x1()} if self.x6 else set()
@@ -961,7 +1036,30 @@ class PUNetEngine:
             return g, 0
         return g, 1
 
+    def _upconv_dgrad(self, flat, c: ConvP, x: Act, dz: torch.Tensor, gm: dict):
+        """d loss / d x for y = conv3x3(cat[up(x), ...]) given dz = d loss / d (pre-activation of y): the nine adjoint-interpolated
+        maps of dz, then ONE 1x1 input gradient with w9, gated by x's ReLU (csrc/upconv.hip)."""
+        B, h, w, cup = x.B, x.H, x.W, x.C
+        d = self._up[(flat.data_ptr(), c.name)]
+        dzt = self._empty(B, h, w, 9 * c.cout)
+        _lib.call("punet_upconv_gather_bwd", dz.data_ptr(), dzt.data_ptr(), B, h, w, c.cout, _stream())
+        g, acc = self._grad_into(gm, x)
+        use_bits = x.bits is not None and x.relu_out
+        self._timed("conv1x1_dgrad", 2.0 * B * h * w * cup * 9 * c.cout, "punet_conv1x1_x6_gated", dzt.data_ptr(), 9 * c.cout, None, 0,
+                    d["p9d"].data_ptr(), cup * 9 * c.cout, cup, 0, None, 0, g.data_ptr(), cup,
+                    x.ptr if (x.relu_out and not use_bits) else None, x.bits.data_ptr() if use_bits else None, None, acc, 0, B, h, w,
+                    _stream())
+
     def _backward_tape(self, flat, gflat, tape, gm: dict, accumulate: bool):
+        # as-written up-block convs whose `up` source qualifies for K5x's input gradient: up-sampled tensor -> its low-res source
+        up_src, skip_up = {}, set()
+        if self.upconv:
+            for op in tape:
+                if op[0] == "up":
+                    up_src[id(op[2])] = op[1]
+            for op in tape:  # keep only those consumed by ONE eligible concat conv
+                if op[0] == "conv" and op[3] is not None and id(op[2]) in up_src and not self._upconv_ok(op[1], up_src[id(op[2])], op[3]):
+                    del up_src[id(op[2])]
         for op in reversed(tape):
             if op[0] == "conv":
                 _, c, x0, x1, y = op
@@ -970,14 +1068,33 @@ class PUNetEngine:
                 if x1 is not None:
                     self._wgrad(gflat, c, x1, x0.C, dz, False, accumulate)
                 off = 0
+                lowres = up_src.pop(id(x0), None) if x1 is not None else None  # x0 = up(lowres): K5x's input gradient (below)
                 for src in (x0, x1):
                     if src is None:
                         continue
-                    if src.needs_grad:
+                    if src is x0 and lowres is not None:
+                        if lowres.needs_grad:
+                            self._upconv_dgrad(flat, c, lowres, dz, gm)
+                        skip_up.add(id(x0))
+                    elif src.needs_grad:
                         g, acc = self._grad_into(gm, src)
                         self._dgrad(flat, c, dz, off, src.C, g, src.ptr if src.relu_out else None, acc, src.B, src.H, src.W,
                                     bits=src.bits)
                     off += src.C
+            elif op[0] == "upconv":  # K5x forward: weight gradient as written (on the up-sampled tensor, materialised here), the
+                _, c, x, bridge, y = op  # bridge's input gradient by the ordinary kernel, x's in the low-resolution form
+                dz = gm.pop(id(y))
+                up = Act(self._empty(x.B, 2 * x.H, 2 * x.W, x.C), x.B, 2 * x.H, 2 * x.W, x.C)
+                _lib.call("punet_upsample2x_fwd", x.ptr, up.ptr, x.B, x.H, x.W, x.C, _stream())
+                self._wgrad(gflat, c, up, 0, dz, True, accumulate)
+                self._wgrad(gflat, c, bridge, x.C, dz, False, accumulate)
+                del up
+                if bridge.needs_grad:
+                    g, acc = self._grad_into(gm, bridge)
+                    self._dgrad(flat, c, dz, x.C, bridge.C, g, bridge.ptr if bridge.relu_out else None, acc, bridge.B, bridge.H, bridge.W,
+                                bits=bridge.bits)
+                if x.needs_grad:
+                    self._upconv_dgrad(flat, c, x, dz, gm)
             elif op[0] == "pool":
                 _, x, y = op
                 dy = gm.pop(id(y))
@@ -992,6 +1109,8 @@ class PUNetEngine:
                     g.punet_amax = sl
             else:
                 _, x, y = op
+                if id(y) in skip_up:  # its consumer's backward has produced x's gradient in the low-resolution form already
+                    continue
                 dy = gm.pop(id(y))
                 assert id(x) not in gm
                 g, _ = self._grad_into(gm, x)

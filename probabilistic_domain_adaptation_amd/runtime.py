@@ -8,6 +8,7 @@ same bits (tests/test_gpu_runtime.py)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from typing import Optional
 
@@ -59,6 +60,8 @@ class NativeRuntime:
         _lib.call("punet_rt_set_arithmetic", h, self.ARITHMETICS[conv_mode])
         self.dice = bool(dice)
         _lib.call("punet_rt_set_criterion", h, int(self.dice))
+        # K5x (csrc/upconv.hip): the same switch the Python engine reads, so that the two graph walkers keep agreeing bit for bit
+        _lib.call("punet_rt_set_upconv", h, int(os.environ.get("PUNET_UPCONV", "1") != "0"))
         if _lib.call("punet_rt_param_floats", h) != layout.numel:
             raise RuntimeError("native runtime and ParamLayout disagree about the flat parameter layout")
         self.tables = torch.empty(_lib.call("punet_rt_tables_bytes", h), dtype=torch.uint8, device=self.device)
