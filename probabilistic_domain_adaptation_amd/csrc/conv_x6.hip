@@ -695,8 +695,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         xbase0 = a.x0 + (size_t)ti.b * ((size_t)(a.H * a.W) * a.c0);
         xbase1 = a.x1 + (size_t)ti.b * ((size_t)(a.H * a.W) * a.c1);
 #endif
-        wlane = (unsigned)((a.n_off + min(ti.n0 + lane, N - 1)) * 8);  // columns beyond N copy column N - 1 (never stored)
     };
+    // NOT part of retarget (round 4 bug fix): the weight rows of a tile's LAST chunk are DMA'd in the commit that FOLLOWS the
+    // re-targeting of the staging registers at the next tile, and that tile has another output-channel block whenever the grid is not
+    // a multiple of the channel-block count (cout = 192: three blocks, 512 workgroups) - the last chunk then contracted the next
+    // tile's weight columns (tests/test_gpu_x6.py, the 4 x 128 x 128, 64 -> 192 case).  wlane follows the TILE, at the end of a phase.
+    auto wlane_of = [&](const TileInfo& ti) { return (unsigned)((a.n_off + min(ti.n0 + lane, N - 1)) * 8); };  // columns beyond N copy column N - 1 (never stored)
     auto load_x = [&](int ch, int it) __attribute__((always_inline)) -> float4 {
         const int kbase = ch * CK;
         const int cs = kbase < a.c0 ? a.c0 : a.c1, coff = kbase < a.c0 ? kbase : kbase - a.c0;
@@ -1022,6 +1026,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     int ch = 0;
     TileInfo ti = decode(tile);
     retarget(ti);
+    wlane = wlane_of(ti);
     prefetch(0);
 #pragma unroll
     for (int it = 0; it < XITER; ++it) split_unit(it);
@@ -1079,6 +1084,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
             epilogue(ti);
             zero_acc();
         }
+        if (ph == 3 && ntile != tile) wlane = wlane_of(nti);  // the next tile's weight columns, from its first commit on
         tile = ntile;
         ch = nch;
         ti = nti;
@@ -1095,6 +1101,231 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
             __syncthreads();  // the slower waves' last fragment reads are done: the operand images are free
             punet_amax_publish_block256(a.amax_out, amax_run, reinterpret_cast<float*>(smem));
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// 1x1 convolution / its input gradient in the six-product arithmetic for WIDE contractions (one source, input channels a multiple
+// of 32): the GEMM of K5x (upconv.hip: [B h w] x cup -> 9 cout and back).  conv3x3_x6_kernel<3, ., 1> was built for the 64-channel
+// Fcomb layers: it stages 8 channels between two barriers and then issues 12 MFMAs per wave - 104-120 TFLOP/s on K = 512 ... 2304.
+// Here a phase stages 32 channels (four [plane][pixel][8 ch] sub-chunk images + their weight rows, 61,440 B: two workgroups per
+// CU) and issues two K-steps = 48 MFMAs per wave between the same two barriers; the fp32 -> 3 x bf16 split of the next phase's
+// activations runs in their shadow as in the 3x3 kernels, the weight rows go global -> LDS by LDS-DMA (no staging registers).
+// A thread stages the SAME pixel column and float4 of the 32 channels in every phase (unit = 8 rows x that column): lanes 0-7
+// read the 128 contiguous bytes of one pixel.  Tile, accumulator mapping, epilogue semantics and gate-bit layout are
+// conv3x3_x6_kernel's (weights as A, pixels as B: a lane holds one pixel and four consecutive channels per register quad).
+template <bool DGRAD>
+__global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
+    constexpr int NP = 3, NSUB = 4, CKP = 32, NPIX = TH * TW;
+    constexpr int XITER = TH;                     // one unit per tile row: pixel (row it, column tid / 8), float4 tid % 8 of the 32 channels
+    constexpr int SUBX = NP * NPIX, SUBW = NP * TN;  // uint4 units of one sub-chunk's activation image / weight block
+    __shared__ uint4 smem[NSUB * (SUBX + SUBW)];     // 61,440 B
+    uint4* sX = smem;
+    uint4* sW = smem + NSUB * SUBX;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int q = tid & 7, col = tid >> 3;  // this thread's float4 of the 32 channels and its pixel column inside the tile
+
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int ntn = (a.n_total + TN - 1) / TN;
+    const int N = a.n_total, K = a.c0;
+    const int nph = K / CKP;
+
+    auto decode = [&](int tile) {
+        TileInfo t;
+        t.n0 = (tile % ntn) * TN;
+        int sid = tile / ntn;
+        t.tx0 = (sid % tiles_x) * TW;
+        sid /= tiles_x;
+        t.ty0 = (sid % tiles_y) * TH;
+        t.b = sid / tiles_y;
+        return t;
+    };
+
+    f32x16 acc[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.f;
+    };
+    zero_acc();
+
+    float4 rx[XITER];
+    bf16x4 px[XITER][NP];
+    const float* xbase = a.x0;  // image of the tile the staging registers are loaded for (block-uniform)
+    unsigned xoff0 = 0u, xrow = 0u;  // element offset of (row 0, this column) inside the image; of one image row (0 beyond the last row)
+    unsigned inmask = 0u;        // bit it: pixel (row it, this column) lies inside the image
+    unsigned wlane = 0u;         // this lane's output-channel offset (elements) inside a weight row
+    auto retarget = [&](const TileInfo& ti) __attribute__((always_inline)) {
+        const int gx = ti.tx0 + col;
+        inmask = 0u;
+#pragma unroll
+        for (int it = 0; it < XITER; ++it) inmask |= (ti.ty0 + it < a.H && gx < a.W) ? (1u << it) : 0u;
+        xoff0 = (unsigned)((min(ti.ty0, a.H - 1) * a.W + min(gx, a.W - 1)) * K + q * 4);
+        xrow = (unsigned)(a.W * K);
+        xbase = a.x0 + (size_t)ti.b * ((size_t)(a.H * a.W) * K);
+    };
+    // (NOT part of retarget: the weight DMA of a tile's LAST phase is issued after the staging registers have been re-targeted at
+    // the next tile, and that tile has another channel block whenever the grid is not a multiple of the channel-block count)
+    auto wlane_of = [&](const TileInfo& ti) { return (unsigned)((a.n_off + min(ti.n0 + lane, N - 1)) * 8); };  // columns beyond N copy column N - 1
+    int ty_cur = 0;  // ty0 of the tile the staging registers belong to (rows beyond the image re-read the last row: never used)
+    auto load_x = [&](int ph, int it) __attribute__((always_inline)) -> float4 {
+        const int r = min(it, a.H - 1 - min(ty_cur, a.H - 1));  // clamped row
+        return *reinterpret_cast<const float4*>(xbase + (xoff0 + (unsigned)r * xrow + (unsigned)(ph * CKP)));
+    };
+    auto split_unit = [&](int it) __attribute__((always_inline)) {
+        const float4 r = (inmask >> it) & 1u ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        uint2 ph_, pm, pl;
+        split3_quad<NP>(r, ph_, pm, pl);
+        asm volatile("" : "+v"(ph_.x), "+v"(ph_.y), "+v"(pm.x), "+v"(pm.y), "+v"(pl.x), "+v"(pl.y));  // keep the split where it is written
+        px[it][0] = __builtin_bit_cast(bf16x4, ph_);
+        px[it][1] = __builtin_bit_cast(bf16x4, pm);
+        px[it][2] = __builtin_bit_cast(bf16x4, pl);
+    };
+    // phase `ph`: packed planes -> LDS images, this phase's 12 weight rows by LDS-DMA, staging registers re-loaded for phase nph_
+    auto commit = [&](int ph, int nph_) __attribute__((always_inline)) {
+        char* const dst = reinterpret_cast<char*>(sX + (q >> 1) * SUBX) + (q & 1) * 8 + col * 16;
+#pragma unroll
+        for (int it = 0; it < XITER; ++it)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(dst + (p * NPIX + it * TW) * 16) = px[it][p];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {  // wave = sub-chunk: one wave-instruction = one {sub-chunk, plane} row of 64 output channels
+            const __bf16* src = a.wp + ((size_t)p * a.plane_stride + (size_t)(ph * NSUB + wave) * a.n_row * 8) + wlane;
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(sW + wave * SUBW + p * TN), 16, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < XITER; ++it) rx[it] = load_x(nph_, it);
+    };
+    // one K-step = 16 channels: lanes 0-31 contract sub-chunk 2 ks, lanes 32-63 sub-chunk 2 ks + 1
+    auto kstep = [&](int ks) __attribute__((always_inline)) {
+        const int sub = 2 * ks + half;
+        U4 av[NP][2], bv[NP][2];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) av[p][m].u = sX[sub * SUBX + p * NPIX + (2 * wave + m) * TW + l31];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) bv[p][nb].u = sW[sub * SUBW + p * TN + nb * 32 + l31];
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                f32x16 c = acc[m][nb];
+                c = punet_mfma32<false>(bv[1][nb].u, av[1][m].u, c);  // mm
+                c = punet_mfma32<false>(bv[0][nb].u, av[2][m].u, c);  // lh
+                c = punet_mfma32<false>(bv[2][nb].u, av[0][m].u, c);  // hl
+                c = punet_mfma32<false>(bv[0][nb].u, av[1][m].u, c);  // mh
+                c = punet_mfma32<false>(bv[1][nb].u, av[0][m].u, c);  // hm
+                c = punet_mfma32<false>(bv[0][nb].u, av[0][m].u, c);  // hh
+                acc[m][nb] = c;
+            }
+    };
+    // epilogue straight from the accumulators (mapping and gate-bit layout: conv3x3_x6_kernel)
+    auto epilogue = [&](const TileInfo& ti) __attribute__((always_inline)) {
+        const int gx = ti.tx0 + l31;
+        const size_t img = (size_t)ti.b * ((size_t)(a.H * a.W) * N);
+        float* const yb = a.y + img;
+        const float* const mb = a.mask ? a.mask + img : nullptr;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int gy = ti.ty0 + 2 * wave + m;
+            const bool pix_in = gy < a.H && gx < a.W;
+            const unsigned gd = (unsigned)(((((ti.b * a.H + gy) * tiles_x + (ti.tx0 / TW)) * ntn + (ti.n0 / TN)) << 6) + lane);
+            const unsigned pbase = (unsigned)((gy * a.W + gx) * N + ti.n0 + 4 * half);
+            unsigned gin = 0u, gout = 0u;
+            if (DGRAD && a.gate_bits && pix_in) gin = a.gate_bits[gd];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int ch = nb * 32 + rg * 8;  // + 4 * half + e
+                    const bool ok = pix_in && ti.n0 + ch + 4 * half < N;  // N is a multiple of 4
+                    float4 v = make_float4(acc[m][nb][4 * rg + 0], acc[m][nb][4 * rg + 1], acc[m][nb][4 * rg + 2], acc[m][nb][4 * rg + 3]);
+                    if (!DGRAD) {
+                        if (a.bias && ok) {
+                            const float4 bq = *reinterpret_cast<const float4*>(a.bias + (size_t)ti.b * a.bias_img_stride + ti.n0 + ch + 4 * half);
+                            v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+                        }
+                        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    } else if (a.gate_bits) {
+                        const unsigned g4 = gin >> (16 * nb + 4 * rg);
+                        v.x = g4 & 1u ? v.x : 0.f; v.y = g4 & 2u ? v.y : 0.f; v.z = g4 & 4u ? v.z : 0.f; v.w = g4 & 8u ? v.w : 0.f;
+                    } else if (a.mask) {
+                        if (ok) {
+                            const float4 g = *reinterpret_cast<const float4*>(mb + pbase + ch);
+                            v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f;
+                            v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
+                        }
+                    }
+                    if (ok) {
+                        if (DGRAD && a.accumulate) {
+                            const float4 o = *reinterpret_cast<const float4*>(yb + pbase + ch);
+                            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                        }
+                        *reinterpret_cast<float4*>(yb + pbase + ch) = v;
+                        if (!DGRAD)
+                            gout |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u))
+                                    << (16 * nb + 4 * rg);
+                    }
+                }
+            if (!DGRAD && a.gate_out && pix_in) a.gate_out[gd] = gout;
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    int ph = 0;
+    TileInfo ti = decode(tile);
+    retarget(ti);
+    wlane = wlane_of(ti);
+    ty_cur = ti.ty0;
+#pragma unroll
+    for (int it = 0; it < XITER; ++it) rx[it] = load_x(0, it);
+#pragma unroll
+    for (int it = 0; it < XITER; ++it) split_unit(it);
+    while (true) {
+        int nph_ = ph + 1, ntile = tile;
+        TileInfo nti = ti;
+        if (nph_ == nph) {
+            nph_ = 0;
+            ntile = tile + (int)gridDim.x;
+            if (ntile < a.ntiles) nti = decode(ntile);
+        }
+        const bool has_next = ntile < a.ntiles;
+        if (!has_next) nph_ = ph;  // nothing follows: the (branch-free) reloads re-fetch this phase and are dropped
+        if (has_next && nph_ == 0) {
+            retarget(nti);
+            ty_cur = nti.ty0;
+        }
+        __syncthreads();  // every wave has read the previous phase's fragments
+        __builtin_amdgcn_s_setprio(3);
+        commit(ph, nph_);
+        __builtin_amdgcn_s_setprio(0);
+        // the weight DMAs (older) must have landed, the XITER activation loads issued after them may stay in flight
+        __builtin_amdgcn_s_waitcnt(XITER | (7 << 4) | (0 << 8));  // vmcnt(XITER) expcnt(7) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        kstep(0);
+#pragma unroll
+        for (int it = 0; it < XITER / 2; ++it) split_unit(it);  // the next phase's split in the shadow of the MFMAs
+        kstep(1);
+#pragma unroll
+        for (int it = XITER / 2; it < XITER; ++it) split_unit(it);
+        if (ph == nph - 1) {  // no barrier: the epilogue touches no LDS
+            epilogue(ti);
+            zero_acc();
+        }
+        if (ntile != tile) wlane = wlane_of(nti);
+        tile = ntile;
+        ph = nph_;
+        ti = nti;
+        if (!has_next) break;
     }
 }
 
@@ -1357,6 +1588,16 @@ extern "C" int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1
                                   nullptr, nullptr, accumulate, relu, B, H, W, opts, stream);
 }
 
+// $PUNET_CONV1X1_WIDE=0: 1x1 convolutions with wide contractions through the 8-channel-chunk kernel as before (same-box A/B);
+// read once per process (a build-time choice in effect, not per-call state: both give the same products, summed in another order)
+static bool punet_conv1x1_wide() {
+    static const bool on = [] {
+        const char* e = getenv("PUNET_CONV1X1_WIDE");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 struct F16Scales {  // fp16-operand arithmetic (planes = 2 or 1; 0 = the bf16 split-plane arithmetic): amax slots, see ConvX6Args
     int planes = 0;
     const float* amax_x0 = nullptr;
@@ -1534,7 +1775,9 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
     } else if (f16.planes == 1) {  // "f16": one fp16 product
         if (dgrad) conv3x3_x6_kernel<1, true, 3, false, true><<<grid, 256, 0, st>>>(a);
         else conv3x3_x6_kernel<1, false, 3, false, true><<<grid, 256, 0, st>>>(a);
-    } else if (ksize == 1) {  // the two Fcomb layers: always the parity arithmetic (they are a rounding error of the step time)
+    } else if (ksize == 1 && c1 == 0 && c0 % 32 == 0 && punet_conv1x1_wide()) {  // wide contractions (K5x's GEMMs): 32-channel phases
+        if (dgrad) conv1x1_x6w_kernel<true><<<grid, 256, 0, st>>>(a); else conv1x1_x6w_kernel<false><<<grid, 256, 0, st>>>(a);
+    } else if (ksize == 1) {  // the Fcomb layers: always the parity arithmetic (they are a rounding error of the step time)
         if (dgrad) conv3x3_x6_kernel<3, true, 1><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<3, false, 1><<<grid, 256, 0, st>>>(a);
     } else if (shape == 16 && (c0 + c1) % 32 == 0 && planes >= 2) {
         // 16 x 16 x 32 MFMAs: four {tap, 8 channels} blocks per instruction.  (Not for the one-plane fast mode: that one is

@@ -153,3 +153,58 @@ def test_composite_forward_and_input_gradient_against_the_layer_as_written(L, B,
     torch.cuda.synchronize()
     ref = x.grad * (x.detach() > 0)  # x is the leaf (a post-ReLU tensor): the kernel applies ITS gate, as the producing layer's backward needs
     assert rel_err(nchw(DX), ref) < 4e-6
+
+
+@pytest.mark.parametrize("wide", ["1", "0"], ids=["32-channel-phases", "8-channel-chunks"])
+def test_wide_1x1_kernel_over_many_tiles(L, wide):
+    """The 1x1 x6 kernel for wide contractions (conv1x1_x6w_kernel) on a problem with more tiles than the persistent grid and a
+    channel-block count (9) that does not divide it - a workgroup's successive tiles differ in their output-channel block - forward
+    (bias, ReLU, gate bits) and input gradient (gate by bits, accumulate), against PyTorch CPU fp32.  $PUNET_CONV1X1_WIDE is read once
+    per process, so each setting runs in a child process."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np, torch, torch.nn.functional as F
+from probabilistic_domain_adaptation_amd import _lib as L
+L.load()
+S = torch.cuda.current_stream().cuda_stream
+g = torch.Generator().manual_seed(9)
+B, H, W, cin, cout = 4, 64, 128, 128, 576
+x = torch.relu(torch.randn(B, cin, H, W, generator=g)).requires_grad_(True)
+w = (torch.randn(cout, cin, 1, 1, generator=g) / np.sqrt(cin)).requires_grad_(True)
+b = torch.randn(cout, generator=g)
+y = F.relu(F.conv2d(x, w, b))
+dz = torch.randn(B, cout, H, W, generator=g)
+y.backward(dz)
+Wp = w.detach().permute(2, 3, 1, 0).contiguous().cuda()
+nw = cin * cout
+pf = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda"); pd = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+L.call("punet_split_weights_x6", Wp.data_ptr(), pf.data_ptr(), nw, cin, cout, 1, 0, S)
+L.call("punet_split_weights_x6", Wp.data_ptr(), pd.data_ptr(), nw, cin, cout, 1, 1, S)
+X = x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+Y = torch.full((B, H, W, cout), float("nan"), device="cuda")
+bits = torch.zeros(L.call("punet_gate_dwords", B, H, W, cout), dtype=torch.int32, device="cuda")
+L.call("punet_conv1x1_x6_gated", X.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, b.cuda().data_ptr(), 0, Y.data_ptr(), cout,
+       None, None, bits.data_ptr(), 0, 1, B, H, W, S)
+torch.cuda.synchronize()
+rel = lambda a, r: (a - r).abs().max().item() / r.abs().max().item()
+e1 = rel(Y.permute(0, 3, 1, 2).cpu(), y.detach())
+# input gradient w.r.t. x: dz gated by (y > 0), contracted with W^T, gated by x's own ReLU (as bits of a tensor shaped like x), accumulated
+DZ = (dz * (y.detach() > 0)).permute(0, 2, 3, 1).contiguous().cuda()
+xb = torch.zeros(L.call("punet_gate_dwords", B, H, W, cin), dtype=torch.int32, device="cuda")
+L.call("punet_gate_bits_f16", X.half().data_ptr(), xb.data_ptr(), B, H, W, cin, S)
+prev = torch.randn(B, H, W, cin, generator=g)
+DX = prev.cuda()
+L.call("punet_conv1x1_x6_gated", DZ.data_ptr(), cout, None, 0, pd.data_ptr(), nw, cin, 0, None, 0, DX.data_ptr(), cin,
+       None, xb.data_ptr(), None, 1, 0, B, H, W, S)
+torch.cuda.synchronize()
+ref = prev.permute(0, 3, 1, 2) + x.grad * (x.detach().half() > 0)
+e2 = rel(DX.permute(0, 3, 1, 2).cpu(), ref)
+print("ERR", e1, e2)
+assert e1 < 2e-6 and e2 < 3e-6, (e1, e2)
+"""
+    env = dict(os.environ, PUNET_CONV1X1_WIDE=wide)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
