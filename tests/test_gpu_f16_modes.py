@@ -378,3 +378,28 @@ def test_fast_modes_at_512_against_the_oracle():
         del m
     assert err["x6"] < 1e-3 and err["f16x3"] < 2e-4 and err["f16x3"] < 2.0 * err["x6"] + 2e-5, err
     assert 1e-4 < err["f16"] < 0.2 and 1e-4 < err["f16s"] < 0.3, err
+
+
+@pytest.mark.parametrize("planes", [2, 1], ids=["f16x3", "f16"])
+def test_many_tiles_with_three_channel_blocks(L, planes):
+    """More tiles than the persistent grid and an output-channel-block count (3) that does not divide it: a workgroup's successive
+    tiles differ in their channel block (round 4: the 16x16x32 kernel contracted the next tile's weight columns in a tile's last
+    chunk there - all arithmetics share that kernel)."""
+    S = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(13)
+    B, H, W, cin, cout = 4, 128, 128, 64, 192
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    ref = F.conv2d(x, w, None, padding=1)
+    Wp = w.permute(2, 3, 1, 0).contiguous().cuda()
+    nw = 9 * cin * cout
+    pf = torch.zeros(3 * nw, dtype=torch.bfloat16, device="cuda")
+    aw, ay = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    L.call("punet_split_weights_f16", Wp.data_ptr(), pf.data_ptr(), nw, cin, cout, 0, aw.data_ptr(), S)
+    X = x.permute(0, 2, 3, 1).contiguous().cuda()
+    ax = _amax_slot(L, X, S)
+    Y = torch.empty(B, H, W, cout, device="cuda")
+    L.call("punet_conv3x3_f16", X.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, None, 0, Y.data_ptr(), cout, None, None, None, None,
+           0, 0, B, H, W, planes, ax.data_ptr(), None, aw.data_ptr(), ay.data_ptr(), S)
+    torch.cuda.synchronize()
+    assert rel(Y.permute(0, 3, 1, 2).cpu(), ref) < (2e-6 if planes == 2 else 4e-3)

@@ -57,6 +57,8 @@ CONV_CASES = [
     (1, 64, 64, 96, 64, 64, 3),
     (2, 16, 32, 64, 0, 64, 1),     # 1x1
     (1, 4, 4, 192, 0, 160, 3),
+    (4, 128, 128, 64, 0, 192, 3),  # more tiles than a persistent grid, three output-channel blocks (not a divisor of the grid)
+    (3, 96, 160, 96, 64, 160, 3),
 ]
 
 

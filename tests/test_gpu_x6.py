@@ -14,7 +14,7 @@ CASES = [(1, 8, 32, 8, 0, 32), (2, 16, 16, 64, 0, 64), (1, 24, 40, 32, 0, 96), (
          (1, 16, 32, 64, 32, 32), (1, 64, 64, 96, 64, 64), (1, 4, 4, 192, 0, 160),
          # more tiles than the persistent grid (2 x 256 workgroups) AND a channel-block count (3) that does not divide it: a
          # workgroup's successive tiles have different output-channel blocks (the reference's default filters [32, 64, 128, 192])
-         (4, 128, 128, 64, 0, 192)]
+         (4, 128, 128, 64, 0, 192), (4, 128, 128, 192, 0, 64), (3, 96, 160, 96, 64, 160)]
 
 
 def _random_cases(count, seed):

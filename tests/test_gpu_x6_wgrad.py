@@ -10,7 +10,10 @@ import os
 import random
 
 CASES = [(1, 8, 32, 8, 32), (2, 16, 16, 64, 64), (1, 24, 40, 32, 96), (2, 8, 8, 128, 128), (1, 64, 64, 96, 64), (1, 4, 4, 192, 160),
-         (2, 32, 64, 64, 32)]
+         (2, 32, 64, 64, 32),
+         # large against the persistent grid, channel counts that are not powers of two (round 4: the 16x16x32 forward kernel had a
+         # tile-switch bug that only such shapes reach; the seeded draws above are all small)
+         (3, 96, 160, 96, 160), (4, 128, 128, 192, 64)]
 _r = random.Random(9)  # seeded draws: any image size from one pixel up, channel counts multiples of 8 (PUNET_FUZZ_X6=count widens)
 CASES += [(_r.randint(1, 3), _r.randint(1, 50), _r.randint(1, 70), 8 * _r.randint(1, 20), 8 * _r.randint(1, 24))
           for _ in range(int(os.environ.get("PUNET_FUZZ_X6", "8:5").split(":")[0]))]
