@@ -16,7 +16,8 @@ reduced-precision fast modes (the reference scripts' mixed_precision=True analog
 and are NOT the headline number.
 
 The timed steps are replays of the step captured once into a hipGraph (`--no-graph`: launched eagerly from Python; under
-torch.distributed eager launches are the default and `--graph` selects the segmented replay).
+torch.distributed the capture is cut at the gradient all-reduces and replayed in segments behind a one-step bit-equality self-check).
+After the headline the default command also times every other BASELINE.json config for a few steps (`config.other_configs`).
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel = the 3x3 MFMA
 convolution, algorithmic FLOPs / HIP-event duration measured live in this run - in K eagerly launched steps right after
 the timed region, because events cannot sit inside a captured graph - against the matrix peak of the arithmetic in use)
