@@ -1111,9 +1111,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 // Here a phase stages 32 channels (four [plane][pixel][8 ch] sub-chunk images + their weight rows, 61,440 B: two workgroups per
 // CU) and issues two K-steps = 48 MFMAs per wave between the same two barriers; the fp32 -> 3 x bf16 split of the next phase's
 // activations runs in their shadow as in the 3x3 kernels, the weight rows go global -> LDS by LDS-DMA (no staging registers).
+// What bounds it (timing-only builds, -DX6W_TIMING=..., tools/ab_variants.sh; batch 4, K5x's GEMMs): with NO matrix instructions the
+// kernel still takes 192 / 235 / 306 us, with matrix instructions but without loads, splits and stores 275 / 247 / 247 us - against a
+// matrix-pipe floor of ~93 us.  Per workgroup and phase 49 KB of staging writes + 12 KB of weight rows + 98 KB of fragment reads
+// cross the LDS for 1,536 cycles of MFMAs per SIMD: 81 % of the LDS's 128 bytes per clock with two workgroups per CU, where the
+// 3x3 kernels (whose staging is amortised over nine taps) need 58 %.  A 64 x 64 wave tile in three planes cannot go faster as a
+// GEMM; the remedy is a larger wave tile (fewer fragment reads per MFMA) with pre-split operands by LDS-DMA (no staging registers
+// to pay for the accumulators) - DESIGN.md section 8.  Rejected on the way (all +-0): staging two phases ahead, sub-chunk images
+// 128 bytes apart mod 256, weight units through registers, an XCD-aware tile order.
 // A thread stages the SAME pixel column and float4 of the 32 channels in every phase (unit = 8 rows x that column): lanes 0-7
 // read the 128 contiguous bytes of one pixel.  Tile, accumulator mapping, epilogue semantics and gate-bit layout are
 // conv3x3_x6_kernel's (weights as A, pixels as B: a lane holds one pixel and four consecutive channels per register quad).
+#ifndef X6W_TIMING  // timing-only builds of conv1x1_x6w_kernel (WRONG results): 1 = no epilogue, 2 = no split arithmetic, 4 = no activation
+#define X6W_TIMING 0  // loads, 8 = no MFMAs (tools/ab_variants.sh conv_x6.hip ...)
+#endif
 template <bool DGRAD>
 __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
     constexpr int NP = 3, NSUB = 4, CKP = 32, NPIX = TH * TW;
@@ -1175,13 +1186,22 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
     auto wlane_of = [&](const TileInfo& ti) { return (unsigned)((a.n_off + min(ti.n0 + lane, N - 1)) * 8); };  // columns beyond N copy column N - 1
     int ty_cur = 0;  // ty0 of the tile the staging registers belong to (rows beyond the image re-read the last row: never used)
     auto load_x = [&](int ph, int it) __attribute__((always_inline)) -> float4 {
+#if X6W_TIMING & 4
+        return make_float4((float)(ph + it), 1.f, (float)q, 0.5f);
+#endif
         const int r = min(it, a.H - 1 - min(ty_cur, a.H - 1));  // clamped row
         return *reinterpret_cast<const float4*>(xbase + (xoff0 + (unsigned)r * xrow + (unsigned)(ph * CKP)));
     };
     auto split_unit = [&](int it) __attribute__((always_inline)) {
         const float4 r = (inmask >> it) & 1u ? rx[it] : make_float4(0.f, 0.f, 0.f, 0.f);
         uint2 ph_, pm, pl;
+#if X6W_TIMING & 2
+        ph_ = make_uint2(__builtin_bit_cast(unsigned, r.x), __builtin_bit_cast(unsigned, r.y));
+        pm = make_uint2(__builtin_bit_cast(unsigned, r.z), __builtin_bit_cast(unsigned, r.w));
+        pl = ph_;
+#else
         split3_quad<NP>(r, ph_, pm, pl);
+#endif
         asm volatile("" : "+v"(ph_.x), "+v"(ph_.y), "+v"(pm.x), "+v"(pm.y), "+v"(pl.x), "+v"(pl.y));  // keep the split where it is written
         px[it][0] = __builtin_bit_cast(bf16x4, ph_);
         px[it][1] = __builtin_bit_cast(bf16x4, pm);
@@ -1229,6 +1249,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
     };
     // epilogue straight from the accumulators (mapping and gate-bit layout: conv3x3_x6_kernel)
     auto epilogue = [&](const TileInfo& ti) __attribute__((always_inline)) {
+#if X6W_TIMING & 1
+        if (acc[0][0][0] != 1.2345e-30f) return;
+#endif
         const int gx = ti.tx0 + l31;
         const size_t img = (size_t)ti.b * ((size_t)(a.H * a.W) * N);
         float* const yb = a.y + img;
@@ -1279,6 +1302,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
         }
     };
 
+    // (no XCD-aware tile order here: measured +-: 277 -> 301 / 306 -> 307 / 381 -> 373 us on K5x's three forward GEMMs - the kernel is
+    // bound by its LDS traffic, not by what it fetches; see the header comment)
     int tile = blockIdx.x;
     if (tile >= a.ntiles) return;
     int ph = 0;
@@ -1311,10 +1336,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
         // the weight DMAs (older) must have landed, the XITER activation loads issued after them may stay in flight
         __builtin_amdgcn_s_waitcnt(XITER | (7 << 4) | (0 << 8));  // vmcnt(XITER) expcnt(7) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
+#if !(X6W_TIMING & 8)
         kstep(0);
+#endif
 #pragma unroll
         for (int it = 0; it < XITER / 2; ++it) split_unit(it);  // the next phase's split in the shadow of the MFMAs
+#if !(X6W_TIMING & 8)
         kstep(1);
+#endif
 #pragma unroll
         for (int it = XITER / 2; it < XITER; ++it) split_unit(it);
         if (ph == nph - 1) {  // no barrier: the epilogue touches no LDS

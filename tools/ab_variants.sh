@@ -13,7 +13,7 @@ while [ $# -gt 0 ]; do
   OBJ=$PKG/csrc/build/${SRC%.hip}_$NAME.o
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -I $PKG/csrc -I include $FLAGS -c $PKG/csrc/$SRC -o $OBJ
   OBJS=""
-  for f in capi conv_mfma conv_x6 wgrad_mfma wgrad_x6 conv_small pointwise fcomb_sampler fcomb_train augment runtime; do
+  for f in capi conv_mfma conv_x6 wgrad_mfma wgrad_x6 conv_small pointwise fcomb_sampler fcomb_train augment upconv runtime; do
     if [ "$f.hip" == "$SRC" ]; then OBJS="$OBJS $OBJ"; else OBJS="$OBJS $PKG/csrc/build/$f.o"; fi
   done
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -no-hip-rt -o $PKG/libpunet_hip_$NAME.so $OBJS -L$TLIB -lamdhip64 -Wl,-rpath,$TLIB
