@@ -316,3 +316,84 @@ def test_pseudo_prediction_livecell_image_size_against_oracle(dev):
     mism = int((mask != ref_mask).sum())
     print(f"\n520x704 pseudo-prediction: {mism} mask pixels differ ({int(unsafe.sum())} within 1e-5 of a threshold)")
     assert mism <= int(unsafe.sum()) and 0.01 < ref_mask.mean() < 0.99
+
+
+DEFAULT_NF = [32, 64, 128, 192]  # the reference's class default (probabilistic_unet.py:231): filter counts that are NOT powers of two
+
+
+def _default_model(dev, seed=1):
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    m = ProbabilisticUnet(1, 1, DEFAULT_NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=0)
+    cfg = O.PUNetConfig(1, 1, DEFAULT_NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in O.synth_params(cfg.spec(), seed).items()})
+    return m, cfg
+
+
+def test_default_filters_large_batch_inference_against_oracle(dev):
+    """The reference's DEFAULT filters [32, 64, 128, 192] on a batch of four 1024 x 1024 patches: the 192-channel level then has
+    768 tiles in three output-channel blocks - more than the persistent grid of 512 workgroups, and a block count that does not
+    divide it, so a workgroup's successive tiles differ in their channel block.  That combination (never reached by the scripts'
+    power-of-two filters, the fixtures or the seeded draws) hid a tile-switch bug of the 16x16x32 convolution kernel for three
+    rounds; this is the model-level guard, next to the kernel-level cases of test_gpu_x6.py."""
+    m, cfg = _default_model(dev)
+    P = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    B, size, n = 4, 1024, 2
+    x, x1, x2, y = O.synth_batch(B, 1, size, size, 0)
+    eps = torch.randn(n, B, 6, generator=torch.Generator().manual_seed(2))
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        st = O.punet_forward(P, cfg, x1, None, False)
+        logits = torch.stack([O.punet_sample(P, cfg, st, eps[i]) for i in range(n)])
+    eng = m.engine
+    with torch.no_grad():
+        out = eng.forward_features(m.flat_params, eng.to_nhwc(x1))
+        z = eng.reparam(out["prior_muls"], eps.to(dev))
+        ym, cz, lg = eng.sample(m.flat_params, out["features"], z, 0.9, 0.1, True, want_logits=True)
+    torch.cuda.synchronize()
+    err = (lg.cpu() - logits).abs().max().item()
+    print(f"\ndefault filters, batch {B} x {size}x{size}: logits max abs err vs oracle {err:.3e}")
+    assert err < 1e-3
+    # and through the native runtime (the other graph walker): bit-identical pseudo-labels
+    from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
+    if FU.native_ok(m):
+        y2, z2 = FU.pseudo_labels(m, x1.to(dev), n, True, eps.to(dev))
+        torch.cuda.synchronize()
+        assert torch.equal(y2.reshape(-1), ym.reshape(-1)) and torch.equal(z2.float().reshape(-1), cz.float().reshape(-1))
+
+
+def test_default_filters_training_step_against_oracle(dev):
+    """All gradients of one consensus-masked ELBO step at the reference's default filters, batch 2 x 512 x 512, against the CPU
+    oracle's autograd (same structure and bar as test_training_step_fullsize_against_oracle): the 192- and 320-channel layers
+    (channel counts that are multiples of 32 but not powers of two) in forward, input gradient and weight gradient."""
+    m, cfg = _default_model(dev)
+    eng, lay, flat = m.engine, m.layout, m.flat_params
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    B, size = 2, 512
+    x, x1, x2, y = O.synth_batch(B, 1, size, size, 0)
+    g = torch.Generator().manual_seed(4)
+    eps_s = torch.randn(B, 6, generator=g)
+    y_soft = (0.8 * y + 0.1 * torch.rand(y.shape, generator=g)).clamp(0, 1)
+    consm = (torch.rand(y.shape, generator=g) > 0.3).float()
+    taps = {}
+    st = eng.elbo_forward(flat, eng.to_nhwc(x2.to(dev)), y_soft.to(dev), consm.to(dev), eps_s.to(dev), "bce", 1.0, 1.0, True, taps)
+    gflat = torch.full((lay.numel,), float("nan"), device=dev)
+    eng.elbo_backward(flat, gflat, st, accumulate=False)
+    torch.cuda.synchronize()
+    gates = {k[5:]: (v.t > 0).permute(0, 3, 1, 2).cpu() for k, v in taps.items() if k.startswith("conv:")}
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    O.RELU_GATES = gates
+    try:
+        lo, aux = O.training_loss(P, cfg, x2, y_soft, consm, eps_s, reg_weight=0.0)
+        go = O.grads_of(lo, P)
+    finally:
+        O.RELU_GATES = None
+    np.testing.assert_allclose([st["rec"].item(), st["kl"].item()], [aux["reconstruction_loss"].item(), aux["kl"].item()], rtol=2e-4)
+    gv = lay.views(gflat)
+    worst = 0.0
+    for k, ref in go.items():
+        got = gv[k].cpu()
+        assert torch.isfinite(got).all(), k
+        e = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-8)
+        worst = max(worst, e)
+        assert e <= 5e-4, (k, e)
+    print(f"\ndefault filters, batch {B} x {size}x{size} training step: worst gradient error {worst:.2e} of the tensor max over {len(go)} tensors")

@@ -60,6 +60,10 @@ int main(int argc, char** argv) {
     PUNET(punet_rt_create(&cfg, &rt));
     PUNET(punet_rt_set_arithmetic(rt, products));
     PUNET(punet_rt_set_criterion(rt, dice));
+    {   /* the same implementation switch the Python side reads: K5x on (default) or the up-blocks as written */
+        const char* e = getenv("PUNET_UPCONV");
+        PUNET(punet_rt_set_upconv(rt, !(e && e[0] == '0')));
+    }
     const size_t P = (size_t)punet_rt_param_floats(rt), px = (size_t)B * H * W, L = (size_t)cfg.latent_dim;
 
     float *student = upload(f, P), *x1 = upload(f, px * cfg.input_channels), *x2 = upload(f, px * cfg.input_channels);
