@@ -542,7 +542,7 @@ def main():
                 if a.workload == "mean_teacher" and (B, H, W, N) == (4, 512, 512, 8) and eng.conv_mode in ("x6", "f32"):
                     fn, key = {"x6": ("pmc_hbm_traffic_x6.json", "conv3x3_x6b_kernel<3, false>"),
                                "f32": ("pmc_hbm_traffic.json", "conv_mfma_kernel<3, false>")}[eng.conv_mode]
-                    rdir = next(r for r in ("r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", r, fn)))
+                    rdir = next(r for r in ("r04", "r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", r, fn)))
                     pm = json.load(open(os.path.join(ROOT, "profiles", rdir, fn)))
                     if key not in pm["kernels"]:  # (round 3 added a template argument to the kernels' names)
                         key = key.replace("<3, false>", "<3, false, false>")
@@ -556,9 +556,10 @@ def main():
                                     f"kernel sources unchanged since that collection: {same if 'kernel_sources_sha16' in pm else 'unknown (pre-r03 file)'}; "
                                     "= rocprofv3 --pmc FETCH_SIZE (x2, gfx950 "
                                     "correction) + WRITE_SIZE in separate passes of this same command, bytes per launch, mean over the "
-                                    "launches of the forward instantiation (algorithmic mean over the forward launches: 265 MB = 144 MB "
-                                    "activations in + weight planes, 121 MB out); FETCH_SIZE includes the 1.33x halo re-reads of the "
-                                    "8x32-pixel tiles")
+                                    "launches of the forward instantiation (algorithmic mean over the 73 forward launches of a step: "
+                                    + ("250 MB with the up-blocks' entry convolutions in their low-resolution form, K5x" if rdir >= "r04"
+                                       else "265 MB = 144 MB activations in + weight planes, 121 MB out")
+                                    + "); FETCH_SIZE includes the 1.33x halo re-reads of the 8x32-pixel tiles")
             except Exception:
                 pass
             if k3:
