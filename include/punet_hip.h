@@ -169,6 +169,14 @@ int punet_upsample2x_bwd_gated(const float* dy, const float* xmask, const void* 
 int punet_upconv_relayout(const float* w, int cup, int cb, int cout, float* w9, float* wb, void* stream);
 int punet_upconv_gather_fwd(const float* z, float* y, void* gate_out, int relu, int B, int h, int w, int cout, void* stream);
 int punet_upconv_gather_bwd(const float* dz, float* dzt, int B, int h, int w, int cout, void* stream);
+/*      punet_upconv_wgrad_x6: the weight gradient of the `up` rows in the same form, dw[t][ci][co] (+)= scale * sum_j x[j][ci]
+ *        dzt[j][t][co] for ci < cup (rows [0, cup) of every tap's [cin_total][cout] block; six-product arithmetic, deterministic
+ *        split-K: nslices from punet_upconv_wgrad_slices, workspace of punet_upconv_wgrad_workspace_floats floats) - a quarter
+ *        of the 3x3 weight gradient's multiply-adds, and the up-sampled tensor is needed by nothing any more. */
+int punet_upconv_wgrad_slices(int cup, int cout, int B, int h, int w);
+size_t punet_upconv_wgrad_workspace_floats(int cup, int cout, int nslices);
+int punet_upconv_wgrad_x6(const float* x, int cup, const float* dzt, int cout, float* dw, int cin_total, float* workspace,
+                          int nslices, int B, int h, int w, int accumulate, float scale, void* stream);
 
 /* ---- K6: latent head (probabilistic_unet.py:126-137): mean over H, W then 1x1 conv C -> J = 2*latent_dim.
  *      muls[b][:L] = mu, muls[b][L:] = log_sigma.  mean[b][C] is kept for the backward. */

@@ -55,6 +55,9 @@ _SIGS = {
     "punet_upconv_relayout": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "punet_upconv_gather_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "punet_upconv_gather_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "punet_upconv_wgrad_slices": (_i, [_i, _i, _i, _i, _i]),
+    "punet_upconv_wgrad_workspace_floats": (_sz, [_i, _i, _i]),
+    "punet_upconv_wgrad_x6": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _f, _p]),
     "punet_chan_sum_workspace_floats": (_sz, [_i, _i, _i]),
     "punet_chan_sum": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
     "punet_latent_head_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
@@ -149,7 +152,7 @@ _SIGS.update({
 
 _NO_WRAP = {"punet_rt_destroy", "punet_rt_param_floats", "punet_rt_unet_floats", "punet_rt_num_entries", "punet_rt_tables_bytes",
             "punet_rt_arena_bytes", "punet_rt_last_arena_used", "punet_last_error", "punet_build_info", "punet_device_ok", "punet_compute_units", "punet_wgrad_workspace_floats", "punet_gate_dwords",
-            "punet_wgrad_slices", "punet_wgrad_x6_slices", "punet_small_wgrad_workspace_floats", "punet_chan_sum_workspace_floats",
+            "punet_wgrad_slices", "punet_wgrad_x6_slices", "punet_upconv_wgrad_slices", "punet_upconv_wgrad_workspace_floats", "punet_small_wgrad_workspace_floats", "punet_chan_sum_workspace_floats",
             "punet_dot_bwd_workspace_floats", "punet_loss_workspace_floats", "punet_fcomb_train_supported",
             "punet_fcomb_train_workspace_floats", "punet_standardize_workspace_doubles"}
 

@@ -163,7 +163,7 @@ struct Pass {  // one forward / backward walk
     float* slots = nullptr;   // zeroed pool of activation / gradient amax slots
     int nslots = 0, next_slot = 0;
 
-    // K5x (csrc/upconv.hip; engine.py upconv_fwd / _upconv_dgrad): per up-block the re-laid-out entry slab and its planes
+    // K5x (csrc/upconv.hip; engine.py upconv_fwd / _upconv_backward): per up-block the re-laid-out entry slab and its planes
     struct UpW {
         float *w9 = nullptr, *wb = nullptr;
         __bf16 *p9 = nullptr, *pb = nullptr, *p9d = nullptr;
@@ -223,13 +223,17 @@ struct Pass {  // one forward / backward walk
         *out = y;
         return PUNET_OK;
     }
-    // d loss / d x of the layer above given dz: nine adjoint-interpolated maps of dz, one 1x1 input gradient with w9, x's ReLU gate
-    int upconv_dgrad(int j, Act* x, const float* dz) {
+    // everything the `up` source receives from dz in the low-resolution form: the nine adjoint-interpolated maps of dz ONCE, the weight
+    // gradient of the `up` rows (x^T . maps), d loss / d x (one 1x1 input gradient with w9, x's ReLU gate) - engine.py _upconv_backward
+    int upconv_backward(int j, Act* x, const float* dz, int accumulate) {
         const Conv& c = rt->convs[rt->unet_up[j][0]];
         const UpW& u = upw[j];
         const int B = x->B, h = x->H, wd = x->W, cup = x->C;
         float* dzt = ar->floats((size_t)B * h * wd * 9 * c.cout);
         RT_LAUNCH(punet_upconv_gather_bwd(dz, dzt, B, h, wd, c.cout, stream));
+        const int ns = punet_upconv_wgrad_slices(cup, c.cout, B, h, wd);
+        RT_LAUNCH(punet_upconv_wgrad_x6(x->t, cup, dzt, c.cout, gflat + c.w_off, c.cin, ws_wgrad, ns, B, h, wd, accumulate, 1.f, stream));
+        if (!x->needs_grad) return PUNET_OK;
         int acc = 0;
         float* g = grad_into(x, &acc);
         const bool use_bits = x->bits && x->relu_out;
@@ -433,14 +437,20 @@ struct Pass {  // one forward / backward walk
                     punet_set_error("punet_rt: no gradient reached %s", c.name.c_str());
                     return PUNET_ERR_ARG;
                 }
-                RT_CALL(wgrad(c, op.x0, 0, dz, op.y->gamax, true, accumulate));
-                if (op.x1) RT_CALL(wgrad(c, op.x1, op.x0->C, dz, op.y->gamax, false, accumulate));
+                const bool lowres = op.x1 && op.x0->up_of;  // x0 = up(low-res tensor): K5x's backward of the `up` rows
+                if (lowres) {
+                    RT_CALL(upconv_backward(up_index(op.conv), op.x0->up_of, dz, accumulate));
+                    RT_CALL(wgrad(c, op.x1, op.x0->C, dz, op.y->gamax, true, accumulate));
+                    op.x0->up_bwd_done = true;  // the `up` op's own backward is skipped
+                } else {
+                    RT_CALL(wgrad(c, op.x0, 0, dz, op.y->gamax, true, accumulate));
+                    if (op.x1) RT_CALL(wgrad(c, op.x1, op.x0->C, dz, op.y->gamax, false, accumulate));
+                }
                 int off = 0;
                 for (Act* src : {op.x0, op.x1}) {
                     if (!src) continue;
-                    if (src == op.x0 && op.x1 && src->up_of) {  // x0 = up(low-res tensor): K5x's input gradient, the `up` op's backward is skipped
-                        if (src->up_of->needs_grad) RT_CALL(upconv_dgrad(up_index(op.conv), src->up_of, dz));
-                        src->up_bwd_done = true;
+                    if (src == op.x0 && lowres) {
+                        // (done above)
                     } else if (src->needs_grad) {
                         int acc = 0;
                         float* g = grad_into(src, &acc);
@@ -460,18 +470,16 @@ struct Pass {  // one forward / backward walk
                     }
                     off += src->C;
                 }
-            } else if (op.kind == 3) {  // K5x forward: weight gradient as written (on the up-sampled tensor, materialised here), the bridge's
-                const Conv& c = rt->convs[op.conv];  // input gradient by the ordinary kernel, the low-resolution source's in the new form
+            } else if (op.kind == 3) {  // K5x forward: everything that concerns the `up` source in the low-resolution form (the up-sampled
+                const Conv& c = rt->convs[op.conv];  // tensor never exists), the bridge's gradients by the ordinary kernels
                 const float* dz = op.y->grad;
                 if (!dz && !dry) {
                     punet_set_error("punet_rt: no gradient reached %s", c.name.c_str());
                     return PUNET_ERR_ARG;
                 }
                 Act *x = op.x0, *bridge = op.x1;
-                Act* up = rt->new_act(ar->floats((size_t)x->B * 4 * x->H * x->W * x->C), x->B, 2 * x->H, 2 * x->W, x->C, false);
-                RT_LAUNCH(punet_upsample2x_fwd(x->t, up->t, x->B, x->H, x->W, x->C, stream));
-                RT_CALL(wgrad(c, up, 0, dz, op.y->gamax, true, accumulate));
-                RT_CALL(wgrad(c, bridge, x->C, dz, op.y->gamax, false, accumulate));
+                RT_CALL(upconv_backward(up_index(op.conv), x, dz, accumulate));
+                RT_CALL(wgrad(c, bridge, x->C, dz, op.y->gamax, true, accumulate));
                 if (bridge->needs_grad) {
                     int acc = 0;
                     float* g = grad_into(bridge, &acc);
@@ -481,7 +489,6 @@ struct Pass {  // one forward / backward walk
                                                    bridge->C, use_bits ? nullptr : mask, use_bits ? bridge->bits : nullptr, nullptr, acc, 0,
                                                    bridge->B, bridge->H, bridge->W, X6_OPTS, stream));
                 }
-                if (x->needs_grad) RT_CALL(upconv_dgrad(up_index(op.conv), x, dz));
             } else if (op.kind == 1) {
                 int acc = 0;
                 float* g = grad_into(op.x0, &acc);
@@ -536,6 +543,11 @@ size_t max_wgrad_ws_floats(const PunetRt* rt, int B, int H, int W) {
         const int bridge = rt->cfg.num_filters[lv];
         one(c0, c0.cin - bridge, lv);  // the up-sampled source
         one(c0, bridge, lv);           // the bridge
+        {   // K5x: the `up` rows' weight gradient at the low resolution (two slabs per slice)
+            const int cup = c0.cin - bridge, h = H >> (lv + 1), w = W >> (lv + 1);
+            const size_t v = punet_upconv_wgrad_workspace_floats(cup, c0.cout, punet_upconv_wgrad_slices(cup, c0.cout, B, h, w));
+            m = v > m ? v : m;
+        }
         one(rt->convs[rt->unet_up[j][1]], rt->convs[rt->unet_up[j][1]].cin, lv);
         one(rt->convs[rt->unet_up[j][2]], rt->convs[rt->unet_up[j][2]].cin, lv);
     }

@@ -234,6 +234,180 @@ __global__ __launch_bounds__(256) void upconv_gather_bwd_kernel(const float4* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The weight gradient of the `up` rows in the low-resolution form:   dW[t][ci][co] = sum_j x[j][ci] * dzt[j][t][co]
+// (j over ALL low-resolution pixels of the batch; dzt = the nine adjoint-interpolated maps of upconv_gather_bwd_kernel) - a
+// quarter of the multiply-adds of the 3x3 weight gradient on the up-sampled tensor, which then no longer has to exist at all.
+// Structure of wgrad3x3_x6_kernel (wgrad_x6.hip): six-product bf16 arithmetic, [pixel][32 ch] LDS images read with the
+// transposing ds_read_b64_tr_b16, deterministic split-K (slabs summed in fixed order by reduce_slabs) - with the operands' roles
+// swapped: there ONE dz image serves nine shifted views of x, here ONE x image serves the nine channel blocks of dzt.  A
+// workgroup owns a 64 x 64 (ci, co) tile, THREE taps (their dzt images are 72 KB of LDS; all nine would be 216 KB) and a slice of
+// the pixels; its 8 waves = 4 (ci block, co block) pairs x 2 halves of the 64-pixel tile (the halves are two more split-K slabs).
+// Single-buffered (96 KB): the next tile's global loads are in flight during the MFMAs and split in their shadow.
+typedef __bf16 up_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 up_bf16x4 __attribute__((ext_vector_type(4)));
+typedef short up_s16x4 __attribute__((ext_vector_type(4)));
+union UpFrag {
+    up_bf16x8 v;
+    up_s16x4 half4[2];
+};
+__device__ __forceinline__ up_s16x4 up_tr_read(const char* lds_base, int byte_off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) up_s16x4*)(lds_base + byte_off));
+}
+constexpr int UWC = 64, UNPD = 64, UROWB = 64, UIMG = UNPD * UROWB, UTAPS = 3;  // 64 x 64 channel tile, 64 pixels per tile, 4 KB images
+
+struct UpWgradArgs {
+    const float* x;    // [M][cs]      low-resolution source, M = B h w pixels
+    const float* dzt;  // [M][9][cout]
+    float* partial;    // [2 nslices][9][cs][cout]
+    int cs, cout, nslices;
+    long M;
+};
+
+__global__ __launch_bounds__(512, 2) void upconv_wgrad_x6_kernel(UpWgradArgs a) {
+    constexpr int NP = 3;
+    constexpr int XIT = UNPD * (UWC / 4) / 512, DIT = UTAPS * UNPD * (UWC / 4) / 512;  // 2 and 6 float4 units per thread and tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sX = smem;                     // [plane][ci block][64 px][32 ch]
+    char* const sD = smem + NP * 2 * UIMG;     // [tap][plane][co block][64 px][32 ch]
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int pair = wave & 3, group = wave >> 2;  // group = half of the pixel tile (pixel groups 2 group, 2 group + 1)
+    const int cib = pair >> 1, cob = pair & 1;
+    const int co_tiles = (a.cout + UWC - 1) / UWC;
+    const int tg = blockIdx.y % 3;                         // taps 3 tg .. 3 tg + 2
+    const int co_tile = (blockIdx.y / 3) % co_tiles, ci_tile = blockIdx.y / (3 * co_tiles);
+    const int ci0 = ci_tile * UWC, co0 = co_tile * UWC;
+    const int slice = blockIdx.x;
+    const long ntiles = (a.M + UNPD - 1) / UNPD;
+
+    f32x16 acc[UTAPS];
+#pragma unroll
+    for (int t = 0; t < UTAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int l16 = lane & 15, q = l16 >> 2, p4 = l16 & 3, cb = (lane >> 4) & 1;
+    const int lane_off = (8 * half + q) * UROWB + (16 * cb + 4 * p4) * 2;  // (wgrad_x6.hip: the transposing read's lane mapping)
+
+    float4 rx[XIT], rd[DIT];
+    unsigned inmask = 0u;
+    auto prefetch = [&](long tile) __attribute__((always_inline)) {
+        const long p0 = tile * UNPD;
+        inmask = 0u;
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int u = tid + it * 512;
+            const int c4 = u % (UWC / 4), pix = u / (UWC / 4);
+            const int c = ci0 + c4 * 4;
+            const bool in = p0 + pix < a.M && c < a.cs;
+            const long pp = p0 + pix < a.M ? p0 + pix : a.M - 1;
+            rx[it] = *reinterpret_cast<const float4*>(a.x + (size_t)pp * a.cs + min(c, a.cs - 4));
+            inmask = in ? inmask | (1u << it) : inmask;
+        }
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const int u = tid + it * 512;
+            const int c4 = u % (UWC / 4), tap = (u / (UWC / 4)) % UTAPS, pix = u / ((UWC / 4) * UTAPS);
+            const int c = co0 + c4 * 4;
+            const bool in = p0 + pix < a.M && c < a.cout;
+            const long pp = p0 + pix < a.M ? p0 + pix : a.M - 1;
+            rd[it] = *reinterpret_cast<const float4*>(a.dzt + ((size_t)pp * 9 + (3 * tg + tap)) * a.cout + min(c, a.cout - 4));
+            inmask = in ? inmask | (1u << (XIT + it)) : inmask;
+        }
+    };
+    up_bf16x4 px[XIT + DIT][NP];
+    auto split_unit = [&](int i) __attribute__((always_inline)) {  // i < XIT: x unit, else dzt unit
+        const float4 v = i < XIT ? rx[i < XIT ? i : 0] : rd[i >= XIT ? i - XIT : 0];
+        const float4 r = (inmask >> i) & 1u ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        uint2 ph, pm, pl;
+        split3_quad<NP>(r, ph, pm, pl);
+        px[i][0] = __builtin_bit_cast(up_bf16x4, ph);
+        px[i][1] = __builtin_bit_cast(up_bf16x4, pm);
+        px[i][2] = __builtin_bit_cast(up_bf16x4, pl);
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int u = tid + it * 512;
+            const int c4 = u % (UWC / 4), pix = u / (UWC / 4);
+            const int off = (c4 >> 3) * UIMG + pix * UROWB + (c4 & 7) * 8;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<up_bf16x4*>(sX + p * 2 * UIMG + off) = px[it][p];
+        }
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const int u = tid + it * 512;
+            const int c4 = u % (UWC / 4), tap = (u / (UWC / 4)) % UTAPS, pix = u / ((UWC / 4) * UTAPS);
+            const int off = (c4 >> 3) * UIMG + pix * UROWB + (c4 & 7) * 8;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<up_bf16x4*>(sD + (tap * NP + p) * 2 * UIMG + off) = px[XIT + it][p];
+        }
+    };
+
+    if (slice < ntiles) {
+        prefetch(slice);
+#pragma unroll
+        for (int i = 0; i < XIT + DIT; ++i) split_unit(i);
+    }
+    for (long tile = slice; tile < ntiles; tile += a.nslices) {
+        const long next = tile + a.nslices;
+        const bool has_next = next < ntiles;  // block-uniform
+        __syncthreads();                      // the previous tile's fragment reads are done
+        commit();
+        prefetch(has_next ? next : tile);     // unconditional (a re-fetch is dropped); in flight during the MFMAs below
+        __syncthreads();
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+            const int s = 2 * group + sg;  // this wave's pixel groups of 16
+            UpFrag fa[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) fa[p].half4[r] = up_tr_read(sX, (p * 2 + cib) * UIMG + (16 * s + 4 * r) * UROWB + lane_off);
+#pragma unroll
+            for (int t = 0; t < UTAPS; ++t) {
+                UpFrag fb[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+                        fb[p].half4[r] = up_tr_read(sD, ((t * NP + p) * 2 + cob) * UIMG + (16 * s + 4 * r) * UROWB + lane_off);
+                f32x16 c = acc[t];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1].v, fb[1].v, c, 0, 0, 0);  // mm
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2].v, fb[0].v, c, 0, 0, 0);  // lh
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0].v, fb[2].v, c, 0, 0, 0);  // hl
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1].v, fb[0].v, c, 0, 0, 0);  // mh
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0].v, fb[1].v, c, 0, 0, 0);  // hm
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0].v, fb[0].v, c, 0, 0, 0);  // hh
+                acc[t] = c;
+            }
+            // the next tile's split in the shadow of these MFMAs (its loads were issued before them)
+            if (sg == 0) {
+#pragma unroll
+                for (int i = 0; i < (XIT + DIT) / 2; ++i) split_unit(i);
+            } else {
+#pragma unroll
+                for (int i = (XIT + DIT) / 2; i < XIT + DIT; ++i) split_unit(i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // slab (2 slice + group): rows [tap][ci], columns co - the layout of wgrad3x3_x6_kernel's slabs (reduce_slabs sums them)
+    const int co = co0 + cob * 32 + l31;
+    if (co < a.cout) {
+#pragma unroll
+        for (int t = 0; t < UTAPS; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + cib * 32 + mfma32_row(r, half);
+                if (ci < a.cs) a.partial[((((size_t)(2 * slice + group)) * 9 + 3 * tg + t) * a.cs + ci) * a.cout + co] = acc[t][r];
+            }
+    }
+}
+
 int shift_of(int c4) {  // log2 when a power of two, else -1
     for (int s = 0; s < 16; ++s)
         if ((1 << s) == c4) return s;
@@ -277,4 +451,34 @@ extern "C" int punet_upconv_gather_bwd(const float* dz, float* dzt, int B, int h
     upconv_gather_bwd_kernel<<<grid, 256, 0, STREAM>>>((const float4*)dz, (float4*)dzt, B, h, w, C4, shift_of(C4));
     PUNET_LAUNCH_CHECK("upconv_gather_bwd");
     return PUNET_OK;
+}
+
+// split-K slices of punet_upconv_wgrad_x6 (about one resident workgroup per CU) and its workspace (2 slabs per slice)
+extern "C" int punet_upconv_wgrad_slices(int cup, int cout, int B, int h, int w) {
+    const long ntiles = ((long)B * h * w + UNPD - 1) / UNPD;
+    const int groups = 3 * ceil_div(cup, UWC) * ceil_div(cout, UWC);
+    if (groups < 1 || ntiles < 1) return 1;
+    long ns = punet_num_cus() / groups;
+    if (ns > ntiles) ns = ntiles;
+    return ns < 1 ? 1 : (int)ns;
+}
+extern "C" size_t punet_upconv_wgrad_workspace_floats(int cup, int cout, int nslices) { return (size_t)2 * nslices * 9 * cup * cout; }
+
+extern "C" int punet_upconv_wgrad_x6(const float* x, int cup, const float* dzt, int cout, float* dw, int cin_total, float* workspace,
+                                     int nslices, int B, int h, int w, int accumulate, float scale, void* stream) {
+    PUNET_CHECK_ARG(x && dzt && dw && workspace, "punet_upconv_wgrad_x6: null pointer");
+    PUNET_CHECK_ARG(cup > 0 && cup % 4 == 0 && cout > 0 && cout % 4 == 0 && cup <= cin_total && nslices >= 1 && B > 0 && h > 0 && w > 0,
+                    "punet_upconv_wgrad_x6: bad args (cup=%d cout=%d cin_total=%d nslices=%d)", cup, cout, cin_total, nslices);
+    UpWgradArgs a{};
+    a.x = x; a.dzt = dzt; a.partial = workspace; a.cs = cup; a.cout = cout; a.nslices = nslices; a.M = (long)B * h * w;
+    constexpr int SMEM = 3 * 2 * UIMG + UTAPS * 3 * 2 * UIMG;  // 98,304 B
+    if (hipFuncSetAttribute((const void*)upconv_wgrad_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
+        punet_set_error("punet_upconv_wgrad_x6: cannot reserve %d bytes of LDS", SMEM);
+        return PUNET_ERR_HIP;
+    }
+    const dim3 grid(nslices, 3 * ceil_div(cup, UWC) * ceil_div(cout, UWC));
+    upconv_wgrad_x6_kernel<<<grid, 512, SMEM, STREAM>>>(a);
+    PUNET_LAUNCH_CHECK("upconv_wgrad_x6");
+    // rows [tap][ci] of the slabs -> rows [0, cup) of every tap's [cin_total][cout] block of dw (deterministic: slabs in slice order)
+    return punet_launch_reduce_slabs(workspace, 2 * nslices, (size_t)9 * cup * cout, 9 * cup, cout, cup, cin_total, 0, dw, accumulate, scale, STREAM);
 }

@@ -1036,13 +1036,20 @@ class PUNetEngine:
             return g, 0
         return g, 1
 
-    def _upconv_dgrad(self, flat, c: ConvP, x: Act, dz: torch.Tensor, gm: dict):
-        """d loss / d x for y = conv3x3(cat[up(x), ...]) given dz = d loss / d (pre-activation of y): the nine adjoint-interpolated
-        maps of dz, then ONE 1x1 input gradient with w9, gated by x's ReLU (csrc/upconv.hip)."""
+    def _upconv_backward(self, flat, gflat, c: ConvP, x: Act, dz: torch.Tensor, gm: dict, accumulate: bool):
+        """Everything the `up` source of y = conv3x3(cat[up(x), bridge]) receives from dz = d loss / d (pre-activation of y), in the
+        low-resolution form (csrc/upconv.hip): the nine adjoint-interpolated maps of dz ONCE, then the weight gradient of the `up`
+        rows (x^T . maps, rows [0, cup) of every tap) and d loss / d x (one 1x1 input gradient with w9, gated by x's ReLU)."""
         B, h, w, cup = x.B, x.H, x.W, x.C
         d = self._up[(flat.data_ptr(), c.name)]
         dzt = self._empty(B, h, w, 9 * c.cout)
         _lib.call("punet_upconv_gather_bwd", dz.data_ptr(), dzt.data_ptr(), B, h, w, c.cout, _stream())
+        ns = _lib.call("punet_upconv_wgrad_slices", cup, c.cout, B, h, w)
+        ws = self.ws.get("wgrad", _lib.call("punet_upconv_wgrad_workspace_floats", cup, c.cout, ns))
+        self._timed("conv1x1_wgrad", 2.0 * B * h * w * cup * 9 * c.cout, "punet_upconv_wgrad_x6", x.ptr, cup, dzt.data_ptr(), c.cout,
+                    gflat.data_ptr() + 4 * c.w_off, c.cin, ws.data_ptr(), ns, B, h, w, int(accumulate), 1.0, _stream())
+        if not x.needs_grad:
+            return
         g, acc = self._grad_into(gm, x)
         use_bits = x.bits is not None and x.relu_out
         self._timed("conv1x1_dgrad", 2.0 * B * h * w * cup * 9 * c.cout, "punet_conv1x1_x6_gated", dzt.data_ptr(), 9 * c.cout, None, 0,
@@ -1064,37 +1071,35 @@ class PUNetEngine:
             if op[0] == "conv":
                 _, c, x0, x1, y = op
                 dz = gm.pop(id(y))
-                self._wgrad(gflat, c, x0, 0, dz, True, accumulate)
-                if x1 is not None:
-                    self._wgrad(gflat, c, x1, x0.C, dz, False, accumulate)
+                lowres = up_src.pop(id(x0), None) if x1 is not None else None  # x0 = up(lowres): K5x's backward of the `up` rows
+                if lowres is not None:
+                    self._upconv_backward(flat, gflat, c, lowres, dz, gm, accumulate)
+                    self._wgrad(gflat, c, x1, x0.C, dz, True, accumulate)
+                    skip_up.add(id(x0))
+                else:
+                    self._wgrad(gflat, c, x0, 0, dz, True, accumulate)
+                    if x1 is not None:
+                        self._wgrad(gflat, c, x1, x0.C, dz, False, accumulate)
                 off = 0
-                lowres = up_src.pop(id(x0), None) if x1 is not None else None  # x0 = up(lowres): K5x's input gradient (below)
                 for src in (x0, x1):
                     if src is None:
                         continue
                     if src is x0 and lowres is not None:
-                        if lowres.needs_grad:
-                            self._upconv_dgrad(flat, c, lowres, dz, gm)
-                        skip_up.add(id(x0))
+                        pass  # (done above: gradient of the low-resolution source, the `up` op's backward is skipped)
                     elif src.needs_grad:
                         g, acc = self._grad_into(gm, src)
                         self._dgrad(flat, c, dz, off, src.C, g, src.ptr if src.relu_out else None, acc, src.B, src.H, src.W,
                                     bits=src.bits)
                     off += src.C
-            elif op[0] == "upconv":  # K5x forward: weight gradient as written (on the up-sampled tensor, materialised here), the
-                _, c, x, bridge, y = op  # bridge's input gradient by the ordinary kernel, x's in the low-resolution form
+            elif op[0] == "upconv":  # K5x forward: everything that concerns the `up` source in the low-resolution form (the up-sampled
+                _, c, x, bridge, y = op  # tensor never exists), the bridge's gradients by the ordinary kernels
                 dz = gm.pop(id(y))
-                up = Act(self._empty(x.B, 2 * x.H, 2 * x.W, x.C), x.B, 2 * x.H, 2 * x.W, x.C)
-                _lib.call("punet_upsample2x_fwd", x.ptr, up.ptr, x.B, x.H, x.W, x.C, _stream())
-                self._wgrad(gflat, c, up, 0, dz, True, accumulate)
-                self._wgrad(gflat, c, bridge, x.C, dz, False, accumulate)
-                del up
+                self._upconv_backward(flat, gflat, c, x, dz, gm, accumulate)
+                self._wgrad(gflat, c, bridge, x.C, dz, True, accumulate)
                 if bridge.needs_grad:
                     g, acc = self._grad_into(gm, bridge)
                     self._dgrad(flat, c, dz, x.C, bridge.C, g, bridge.ptr if bridge.relu_out else None, acc, bridge.B, bridge.H, bridge.W,
                                 bits=bridge.bits)
-                if x.needs_grad:
-                    self._upconv_dgrad(flat, c, x, dz, gm)
             elif op[0] == "pool":
                 _, x, y = op
                 dy = gm.pop(id(y))

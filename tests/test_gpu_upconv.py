@@ -106,7 +106,7 @@ def test_gather_backward_is_the_adjoint(L, B, h, w, cout):
 
 
 @pytest.mark.parametrize("B,h,w,cup,cb,cout", [(2, 8, 16, 64, 32, 64), (1, 16, 8, 128, 64, 64), (1, 4, 4, 256, 128, 128),
-                                               (2, 6, 10, 40, 24, 64)])
+                                               (2, 6, 10, 40, 24, 64), (3, 40, 56, 192, 96, 128)])
 def test_composite_forward_and_input_gradient_against_the_layer_as_written(L, B, h, w, cup, cb, cout):
     """y = ReLU(conv3x3(cat[up(x), bridge]) + b): 1x1 x6 convolution of x with w9, 3x3 x6 convolution of the bridge, gather - and the
     gradient w.r.t. x: adjoint gather of the gated dz, one 1x1 x6 input gradient."""
@@ -115,12 +115,12 @@ def test_composite_forward_and_input_gradient_against_the_layer_as_written(L, B,
     g = torch.Generator().manual_seed(4)
     x = torch.relu(torch.randn(B, cup, h, w, generator=g)).requires_grad_(True)
     bridge = torch.relu(torch.randn(B, cb, 2 * h, 2 * w, generator=g))
-    wt = (torch.randn(cout, cup + cb, 3, 3, generator=g) * np.sqrt(2.0 / (9 * (cup + cb))))
+    wt = (torch.randn(cout, cup + cb, 3, 3, generator=g) * np.sqrt(2.0 / (9 * (cup + cb)))).requires_grad_(True)
     bias = 0.1 * torch.randn(cout, generator=g)
     y = F.relu(F.conv2d(torch.cat([up(x), bridge], 1), wt, bias, padding=1))
     dy = torch.randn(B, cout, 2 * h, 2 * w, generator=g)
     y.backward(dy)
-    Wp = wt.permute(2, 3, 1, 0).contiguous().cuda()  # [3][3][cin][cout]
+    Wp = wt.detach().permute(2, 3, 1, 0).contiguous().cuda()  # [3][3][cin][cout]
     w9 = torch.empty(cup, 9 * cout, device="cuda")
     wb = torch.empty(3, 3, cb, cout, device="cuda")
     L.call("punet_upconv_relayout", Wp.data_ptr(), cup, cb, cout, w9.data_ptr(), wb.data_ptr(), S())
@@ -153,6 +153,20 @@ def test_composite_forward_and_input_gradient_against_the_layer_as_written(L, B,
     torch.cuda.synchronize()
     ref = x.grad * (x.detach() > 0)  # x is the leaf (a post-ReLU tensor): the kernel applies ITS gate, as the producing layer's backward needs
     assert rel_err(nchw(DX), ref) < 4e-6
+    # weight gradient of the `up` rows in the same form: dW[t][ci][co] = sum_j x[j][ci] dzt[j][t][co]; the bridge rows stay untouched
+    ctot = cup + cb
+    dw = torch.full((3, 3, ctot, cout), float("nan"), device="cuda")
+    dw[:, :, :cup] = 0.25  # (written, not accumulated)
+    ns = L.call("punet_upconv_wgrad_slices", cup, cout, B, h, w)
+    ws = torch.empty(L.call("punet_upconv_wgrad_workspace_floats", cup, cout, ns), device="cuda")
+    L.call("punet_upconv_wgrad_x6", X.data_ptr(), cup, DZT.data_ptr(), cout, dw.data_ptr(), ctot, ws.data_ptr(), ns, B, h, w, 0, 1.0, S())
+    torch.cuda.synchronize()
+    wref = wt.grad.permute(2, 3, 1, 0)  # [3][3][cin][cout]
+    assert rel_err(dw[:, :, :cup].cpu(), wref[:, :, :cup]) < 5e-6
+    assert torch.isnan(dw[:, :, cup:]).all()
+    L.call("punet_upconv_wgrad_x6", X.data_ptr(), cup, DZT.data_ptr(), cout, dw.data_ptr(), ctot, ws.data_ptr(), ns, B, h, w, 1, 0.5, S())
+    torch.cuda.synchronize()
+    assert rel_err(dw[:, :, :cup].cpu(), 1.5 * wref[:, :, :cup]) < 5e-6
 
 
 @pytest.mark.parametrize("wide", ["1", "0"], ids=["32-channel-phases", "8-channel-chunks"])

@@ -106,6 +106,10 @@ def main():
         new["gather bwd (adjoint)"] = timeit(lambda: L.call("punet_upconv_gather_bwd", dz.data_ptr(), dzt.data_ptr(), B, h, h, cout, S))
         new["x6 1x1 dgrad GEMM"] = timeit(lambda: L.call("punet_conv1x1_x6_gated", dzt.data_ptr(), n9, None, 0, p1d.data_ptr(), cup * n9, cup, 0,
                                                           None, 0, dx.data_ptr(), cup, x.data_ptr(), None, None, 0, 0, B, h, h, S))
+        nsu = L.call("punet_upconv_wgrad_slices", cup, cout, B, h, h)
+        wsu = torch.empty(L.call("punet_upconv_wgrad_workspace_floats", cup, cout, nsu), device=dev)
+        new["x6 low-res wgrad (GEMM-TN)"] = timeit(lambda: L.call("punet_upconv_wgrad_x6", x.data_ptr(), cup, dzt.data_ptr(), cout, dw.data_ptr(), cup,
+                                                                    wsu.data_ptr(), nsu, B, h, h, 0, 1.0, S))
         gb_f = (z.numel() + 2 * y.numel()) * 4 / 1e9
         gb_b = (dz.numel() + dzt.numel()) * 4 / 1e9
         print(f"   gather traffic: forward {gb_f:.2f} GB = {gb_f / new['gather fwd (relu + gate bits)'] * 1e3:.2f} TB/s, "
