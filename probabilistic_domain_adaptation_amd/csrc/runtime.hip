@@ -169,7 +169,7 @@ struct Pass {  // one forward / backward walk
         __bf16 *p9 = nullptr, *pb = nullptr, *p9d = nullptr;
     };
     std::vector<UpW> upw;
-    static constexpr int UPCONV_MIN_CUP_GRAD = 256;  // (engine.py: PUNetEngine.UPCONV_MIN_CUP_GRAD)
+    static constexpr int UPCONV_MIN_CUP_GRAD = 128;  // (engine.py: PUNetEngine.UPCONV_MIN_CUP_GRAD)
     bool up_eligible(const Conv& c, int cup) const {  // the same rule as engine.py's _upconv_ok: the two walkers agree bit for bit
         const int cb = c.cin - cup;
         return rt->upconv && !f16 && c.k == 3 && cup % 8 == 0 && cb % 8 == 0 && cup > SMALL_CIN && cb > SMALL_CIN && c.cout % 64 == 0;

@@ -355,10 +355,15 @@ __global__ __launch_bounds__(512, 2) void upconv_wgrad_x6_kernel(UpWgradArgs a) 
     for (long tile = slice; tile < ntiles; tile += a.nslices) {
         const long next = tile + a.nslices;
         const bool has_next = next < ntiles;  // block-uniform
-        __syncthreads();                      // the previous tile's fragment reads are done
+        // the next tile's loads FIRST (their staging registers were consumed by the previous iteration's split): issued behind the
+        // commit they had only half an MFMA phase to arrive before the split needed them
+        prefetch(has_next ? next : tile);     // unconditional (a re-fetch is dropped); in flight during the commit and the MFMAs
+        // raw barriers + an LDS-only wait: __syncthreads() fences with s_waitcnt vmcnt(0), i.e. it would wait right here for the
+        // loads just issued - a full memory round trip exposed per tile (that form ran at 93-107 TFLOP/s)
+        __builtin_amdgcn_s_barrier();         // the previous tile's fragment reads are done (every wave waited for its own)
         commit();
-        prefetch(has_next ? next : tile);     // unconditional (a re-fetch is dropped); in flight during the MFMAs below
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // vmcnt(63) expcnt(7) lgkmcnt(0): this wave's LDS writes have landed
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int sg = 0; sg < 2; ++sg) {
             const int s = 2 * group + sg;  // this wave's pixel groups of 16

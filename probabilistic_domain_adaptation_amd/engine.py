@@ -446,8 +446,9 @@ class PUNetEngine:
         return y
 
     # ---------------------------------------------------------------- K5x: up-block entry conv at low resolution
-    UPCONV_MIN_CUP_GRAD = 256  # forward passes a backward follows keep the layer as written below this many `up` channels: their weight
-    # gradient needs the up-sampled tensor anyway, and the gather then costs what the saved matrix work is worth (tools/pushdown_probe.py)
+    UPCONV_MIN_CUP_GRAD = 128  # forward passes a backward follows keep the layer as written below this many `up` channels (untested
+    # territory: the gather's cost is per output channel, the saved matrix work per `up` channel; at 128 the form still wins by ~0.1 ms
+    # per launch at 512 x 512 - tools/pushdown_probe.py; it was 256 while the weight gradient still needed the up-sampled tensor)
 
     def _upconv_ok(self, c: ConvP, x: Act, bridge: Act) -> bool:
         """Shapes the low-resolution form serves (same rule as csrc/runtime.hip: the two graph walkers agree bit for bit)."""

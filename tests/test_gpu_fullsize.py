@@ -176,12 +176,16 @@ def test_mean_teacher_soak_no_memory_growth(dev):
     losses, mem = [], []
     for i in range(60):
         loss, ys, zs, _ = FU.fused_self_training_step(m, t, opt, x1, x2, 8, True, None, None, 0.99, 1e-4)
+        losses.append(loss)
         if i % 10 == 9:
             torch.cuda.synchronize()
-            losses.append(float(loss))
             mem.append(torch.cuda.memory_allocated(dev))
+    losses = [float(v) for v in losses]
     assert all(np.isfinite(v) for v in losses), losses
-    assert losses[-1] < losses[0], losses
+    # the per-step loss scatters by a factor of five with the latent draws (3.7e3 ... 2.0e4): compare averages, not two single steps
+    # (round 4: "last < first" of six samples had held by luck; two arithmetically equivalent forward forms - PUNET_UPCONV=0 / 1 -
+    # track each other within 3 % for all 60 steps and landed on either side of it)
+    assert np.mean(losses[-20:]) < np.mean(losses[:20]), (np.mean(losses[:20]), np.mean(losses[-20:]))
     assert max(mem[1:]) - min(mem[1:]) < (1 << 20), mem  # flat from step 20 on (a few KB of scalars come and go)
     assert not torch.equal(t.flat_params, w0) and torch.isfinite(t.flat_params).all()
 
