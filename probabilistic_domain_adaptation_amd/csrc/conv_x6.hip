@@ -1125,28 +1125,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 #ifndef X6W_TIMING  // timing-only builds of conv1x1_x6w_kernel (WRONG results): 1 = no epilogue, 2 = no split arithmetic, 4 = no activation
 #define X6W_TIMING 0  // loads, 8 = no MFMAs (tools/ab_variants.sh conv_x6.hip ...)
 #endif
-template <bool DGRAD>
+// NB = 32-channel output blocks per wave: 2 = a 64-channel tile and 32-channel phases (above); 4 = a 128-channel tile and 16-channel
+// phases - the same 48 MFMAs per wave and phase, but every staged activation value and every pixel fragment serves twice the output
+// channels: the LDS traffic per MFMA cycle drops from 81 % to 55 % of the LDS's rate (the accumulators take 128 registers, which
+// is why the phases stage 16 channels instead of 32).  Used when the layer has at least 128 output channels.
+template <bool DGRAD, int NB>
 __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
-    constexpr int NP = 3, NSUB = 4, CKP = 32, NPIX = TH * TW;
-    constexpr int XITER = TH;                     // one unit per tile row: pixel (row it, column tid / 8), float4 tid % 8 of the 32 channels
-    constexpr int SUBX = NP * NPIX, SUBW = NP * TN;  // uint4 units of one sub-chunk's activation image / weight block
-    __shared__ uint4 smem[NSUB * (SUBX + SUBW)];     // 61,440 B
+    constexpr int NP = 3, NSUB = NB == 2 ? 4 : 2, CKP = 8 * NSUB, NPIX = TH * TW, TNW = 32 * NB;
+    constexpr int QN = CKP / 4;                   // float4 units per pixel and phase
+    constexpr int RSTEP = 256 / (QN * TW);        // tile rows the 256 threads cover at once (1 or 2)
+    constexpr int XITER = TH / RSTEP;             // units per thread: pixel (row rsub + it * RSTEP, column col), float4 q of the CKP channels
+    constexpr int SUBX = NP * NPIX, SUBW = NP * TNW;  // uint4 units of one sub-chunk's activation image / weight block
+    __shared__ uint4 smem[NSUB * (SUBX + SUBW)];      // 61,440 B (NB = 2) / 36,864 B (NB = 4)
     uint4* sX = smem;
     uint4* sW = smem + NSUB * SUBX;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
-    const int q = tid & 7, col = tid >> 3;  // this thread's float4 of the 32 channels and its pixel column inside the tile
+    const int q = tid % QN, col = (tid / QN) % TW, rsub = tid / (QN * TW);  // this thread's float4 of the phase's channels, its pixel column and first row
 
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
-    const int ntn = (a.n_total + TN - 1) / TN;
+    const int ntn = (a.n_total + TNW - 1) / TNW, ntn64 = (a.n_total + TN - 1) / TN;  // tiles / gate-dword blocks along the channels
     const int N = a.n_total, K = a.c0;
     const int nph = K / CKP;
 
     auto decode = [&](int tile) {
         TileInfo t;
-        t.n0 = (tile % ntn) * TN;
+        t.n0 = (tile % ntn) * TNW;
         int sid = tile / ntn;
         t.tx0 = (sid % tiles_x) * TW;
         sid /= tiles_x;
@@ -1155,12 +1161,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
         return t;
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NB];
     auto zero_acc = [&]() {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.f;
     };
@@ -1176,20 +1182,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
         const int gx = ti.tx0 + col;
         inmask = 0u;
 #pragma unroll
-        for (int it = 0; it < XITER; ++it) inmask |= (ti.ty0 + it < a.H && gx < a.W) ? (1u << it) : 0u;
+        for (int it = 0; it < XITER; ++it) inmask |= (ti.ty0 + rsub + it * RSTEP < a.H && gx < a.W) ? (1u << it) : 0u;
         xoff0 = (unsigned)((min(ti.ty0, a.H - 1) * a.W + min(gx, a.W - 1)) * K + q * 4);
         xrow = (unsigned)(a.W * K);
         xbase = a.x0 + (size_t)ti.b * ((size_t)(a.H * a.W) * K);
     };
     // (NOT part of retarget: the weight DMA of a tile's LAST phase is issued after the staging registers have been re-targeted at
     // the next tile, and that tile has another channel block whenever the grid is not a multiple of the channel-block count)
-    auto wlane_of = [&](const TileInfo& ti) { return (unsigned)((a.n_off + min(ti.n0 + lane, N - 1)) * 8); };  // columns beyond N copy column N - 1
+    // (NB = 4: a wave stages the 64-column half `wave & 1` of sub-chunk `wave >> 1`)
+    auto wlane_of = [&](const TileInfo& ti) {  // columns beyond N copy column N - 1
+        return (unsigned)((a.n_off + min(ti.n0 + (NB == 4 ? 64 * (wave & 1) : 0) + lane, N - 1)) * 8);
+    };
     int ty_cur = 0;  // ty0 of the tile the staging registers belong to (rows beyond the image re-read the last row: never used)
     auto load_x = [&](int ph, int it) __attribute__((always_inline)) -> float4 {
 #if X6W_TIMING & 4
         return make_float4((float)(ph + it), 1.f, (float)q, 0.5f);
 #endif
-        const int r = min(it, a.H - 1 - min(ty_cur, a.H - 1));  // clamped row
+        const int r = min(rsub + it * RSTEP, a.H - 1 - min(ty_cur, a.H - 1));  // clamped row
         return *reinterpret_cast<const float4*>(xbase + (xoff0 + (unsigned)r * xrow + (unsigned)(ph * CKP)));
     };
     auto split_unit = [&](int it) __attribute__((always_inline)) {
@@ -1209,15 +1218,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
     };
     // phase `ph`: packed planes -> LDS images, this phase's 12 weight rows by LDS-DMA, staging registers re-loaded for phase nph_
     auto commit = [&](int ph, int nph_) __attribute__((always_inline)) {
-        char* const dst = reinterpret_cast<char*>(sX + (q >> 1) * SUBX) + (q & 1) * 8 + col * 16;
+        char* const dst = reinterpret_cast<char*>(sX + (q >> 1) * SUBX) + (q & 1) * 8 + (rsub * TW + col) * 16;
 #pragma unroll
         for (int it = 0; it < XITER; ++it)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(dst + (p * NPIX + it * TW) * 16) = px[it][p];
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(dst + (p * NPIX + it * RSTEP * TW) * 16) = px[it][p];
+        // one wave-instruction = one {sub-chunk, plane} row of 64 output channels; NB = 2: wave = sub-chunk, NB = 4: wave = {sub-chunk,
+        // 64-column half}
+        const int wsub = NB == 2 ? wave : wave >> 1, wcol = NB == 2 ? 0 : 64 * (wave & 1);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {  // wave = sub-chunk: one wave-instruction = one {sub-chunk, plane} row of 64 output channels
-            const __bf16* src = a.wp + ((size_t)p * a.plane_stride + (size_t)(ph * NSUB + wave) * a.n_row * 8) + wlane;
-            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(sW + wave * SUBW + p * TN), 16, 0, 0);
+        for (int p = 0; p < NP; ++p) {
+            const __bf16* src = a.wp + ((size_t)p * a.plane_stride + (size_t)(ph * NSUB + wsub) * a.n_row * 8) + wlane;
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(sW + wsub * SUBW + p * TNW + wcol), 16, 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < XITER; ++it) rx[it] = load_x(nph_, it);
@@ -1225,27 +1237,32 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
     // one K-step = 16 channels: lanes 0-31 contract sub-chunk 2 ks, lanes 32-63 sub-chunk 2 ks + 1
     auto kstep = [&](int ks) __attribute__((always_inline)) {
         const int sub = 2 * ks + half;
-        U4 av[NP][2], bv[NP][2];
+        U4 av[NP][2];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int m = 0; m < 2; ++m) av[p][m].u = sX[sub * SUBX + p * NPIX + (2 * wave + m) * TW + l31];
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) bv[p][nb].u = sW[sub * SUBW + p * TN + nb * 32 + l31];
+        for (int nbp = 0; nbp < NB / 2; ++nbp) {  // the weight fragments of two channel blocks at a time (NB = 4: 24 registers, not 48)
+            U4 bv[NP][2];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) bv[p][nb].u = sW[sub * SUBW + p * TNW + (2 * nbp + nb) * 32 + l31];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    f32x16 c = acc[m][2 * nbp + nb];
+                    c = punet_mfma32<false>(bv[1][nb].u, av[1][m].u, c);  // mm
+                    c = punet_mfma32<false>(bv[0][nb].u, av[2][m].u, c);  // lh
+                    c = punet_mfma32<false>(bv[2][nb].u, av[0][m].u, c);  // hl
+                    c = punet_mfma32<false>(bv[0][nb].u, av[1][m].u, c);  // mh
+                    c = punet_mfma32<false>(bv[1][nb].u, av[0][m].u, c);  // hm
+                    c = punet_mfma32<false>(bv[0][nb].u, av[0][m].u, c);  // hh
+                    acc[m][2 * nbp + nb] = c;
+                }
         }
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                f32x16 c = acc[m][nb];
-                c = punet_mfma32<false>(bv[1][nb].u, av[1][m].u, c);  // mm
-                c = punet_mfma32<false>(bv[0][nb].u, av[2][m].u, c);  // lh
-                c = punet_mfma32<false>(bv[2][nb].u, av[0][m].u, c);  // hl
-                c = punet_mfma32<false>(bv[0][nb].u, av[1][m].u, c);  // mh
-                c = punet_mfma32<false>(bv[1][nb].u, av[0][m].u, c);  // hm
-                c = punet_mfma32<false>(bv[0][nb].u, av[0][m].u, c);  // hh
-                acc[m][nb] = c;
-            }
     };
     // epilogue straight from the accumulators (mapping and gate-bit layout: conv3x3_x6_kernel)
     auto epilogue = [&](const TileInfo& ti) __attribute__((always_inline)) {
@@ -1260,14 +1277,21 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
         for (int m = 0; m < 2; ++m) {
             const int gy = ti.ty0 + 2 * wave + m;
             const bool pix_in = gy < a.H && gx < a.W;
-            const unsigned gd = (unsigned)(((((ti.b * a.H + gy) * tiles_x + (ti.tx0 / TW)) * ntn + (ti.n0 / TN)) << 6) + lane);
+            // gate dwords are per 64-channel block: block ti.n0 / 64 + nb / 2, bits 16 (nb & 1) + 4 rg + e
+            const unsigned gd = (unsigned)(((((ti.b * a.H + gy) * tiles_x + (ti.tx0 / TW)) * ntn64 + (ti.n0 / TN)) << 6) + lane);
             const unsigned pbase = (unsigned)((gy * a.W + gx) * N + ti.n0 + 4 * half);
-            unsigned gin = 0u, gout = 0u;
-            if (DGRAD && a.gate_bits && pix_in) gin = a.gate_bits[gd];
+            unsigned gin2[NB / 2], gout2[NB / 2];
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int j = 0; j < NB / 2; ++j) {
+                gout2[j] = 0u;
+                gin2[j] = (DGRAD && a.gate_bits && pix_in && ti.n0 + 64 * j < N) ? a.gate_bits[gd + 64 * j] : 0u;
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
+                    const unsigned gin = gin2[nb >> 1];
+                    unsigned& gout = gout2[nb >> 1];
                     const int ch = nb * 32 + rg * 8;  // + 4 * half + e
                     const bool ok = pix_in && ti.n0 + ch + 4 * half < N;  // N is a multiple of 4
                     float4 v = make_float4(acc[m][nb][4 * rg + 0], acc[m][nb][4 * rg + 1], acc[m][nb][4 * rg + 2], acc[m][nb][4 * rg + 3]);
@@ -1278,7 +1302,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
                         }
                         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     } else if (a.gate_bits) {
-                        const unsigned g4 = gin >> (16 * nb + 4 * rg);
+                        const unsigned g4 = gin >> (16 * (nb & 1) + 4 * rg);
                         v.x = g4 & 1u ? v.x : 0.f; v.y = g4 & 2u ? v.y : 0.f; v.z = g4 & 4u ? v.z : 0.f; v.w = g4 & 8u ? v.w : 0.f;
                     } else if (a.mask) {
                         if (ok) {
@@ -1295,10 +1319,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
                         *reinterpret_cast<float4*>(yb + pbase + ch) = v;
                         if (!DGRAD)
                             gout |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u))
-                                    << (16 * nb + 4 * rg);
+                                    << (16 * (nb & 1) + 4 * rg);
                     }
                 }
-            if (!DGRAD && a.gate_out && pix_in) a.gate_out[gd] = gout;
+            if (!DGRAD && a.gate_out && pix_in) {
+#pragma unroll
+                for (int j = 0; j < NB / 2; ++j)
+                    if (ti.n0 + 64 * j < N) a.gate_out[gd + 64 * j] = gout2[j];
+            }
         }
     };
 
@@ -1342,7 +1370,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
 #pragma unroll
         for (int it = 0; it < XITER / 2; ++it) split_unit(it);  // the next phase's split in the shadow of the MFMAs
 #if !(X6W_TIMING & 8)
-        kstep(1);
+        if constexpr (NSUB == 4) kstep(1);
 #endif
 #pragma unroll
         for (int it = XITER / 2; it < XITER; ++it) split_unit(it);
@@ -1619,10 +1647,10 @@ extern "C" int punet_conv3x3_x6(const float* x0, int c0, const float* x1, int c1
 
 // $PUNET_CONV1X1_WIDE=0: 1x1 convolutions with wide contractions through the 8-channel-chunk kernel as before (same-box A/B);
 // read once per process (a build-time choice in effect, not per-call state: both give the same products, summed in another order)
-static bool punet_conv1x1_wide() {
-    static const bool on = [] {
+static int punet_conv1x1_wide() {  // 0: off; 1: 64-channel tiles only; 2 (default): 128-channel tiles where the layer has them
+    static const int on = [] {
         const char* e = getenv("PUNET_CONV1X1_WIDE");
-        return !(e && e[0] == '0');
+        return e && e[0] == '0' ? 0 : (e && e[0] == '1' ? 1 : 2);
     }();
     return on;
 }
@@ -1804,8 +1832,14 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
     } else if (f16.planes == 1) {  // "f16": one fp16 product
         if (dgrad) conv3x3_x6_kernel<1, true, 3, false, true><<<grid, 256, 0, st>>>(a);
         else conv3x3_x6_kernel<1, false, 3, false, true><<<grid, 256, 0, st>>>(a);
-    } else if (ksize == 1 && c1 == 0 && c0 % 32 == 0 && punet_conv1x1_wide()) {  // wide contractions (K5x's GEMMs): 32-channel phases
-        if (dgrad) conv1x1_x6w_kernel<true><<<grid, 256, 0, st>>>(a); else conv1x1_x6w_kernel<false><<<grid, 256, 0, st>>>(a);
+    } else if (ksize == 1 && c1 == 0 && c0 % 32 == 0 && punet_conv1x1_wide()) {  // wide contractions (K5x's GEMMs)
+        if (n_out >= 128 && punet_conv1x1_wide() == 2) {  // 128-channel tiles, 16-channel phases (fewer LDS bytes per MFMA)
+            a.ntiles = B * ceil_div(H, TH) * ceil_div(W, TW) * ceil_div(n_out, 128);
+            const int grid2 = a.ntiles < cap ? a.ntiles : cap;
+            if (dgrad) conv1x1_x6w_kernel<true, 4><<<grid2, 256, 0, st>>>(a); else conv1x1_x6w_kernel<false, 4><<<grid2, 256, 0, st>>>(a);
+        } else {
+            if (dgrad) conv1x1_x6w_kernel<true, 2><<<grid, 256, 0, st>>>(a); else conv1x1_x6w_kernel<false, 2><<<grid, 256, 0, st>>>(a);
+        }
     } else if (ksize == 1) {  // the Fcomb layers: always the parity arithmetic (they are a rounding error of the step time)
         if (dgrad) conv3x3_x6_kernel<3, true, 1><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<3, false, 1><<<grid, 256, 0, st>>>(a);
     } else if (shape == 16 && (c0 + c1) % 32 == 0 && planes >= 2) {

@@ -169,7 +169,7 @@ def test_composite_forward_and_input_gradient_against_the_layer_as_written(L, B,
     assert rel_err(dw[:, :, :cup].cpu(), 1.5 * wref[:, :, :cup]) < 5e-6
 
 
-@pytest.mark.parametrize("wide", ["1", "0"], ids=["32-channel-phases", "8-channel-chunks"])
+@pytest.mark.parametrize("wide", ["2", "1", "0"], ids=["128-channel-tiles", "64-channel-tiles", "8-channel-chunks"])
 def test_wide_1x1_kernel_over_many_tiles(L, wide):
     """The 1x1 x6 kernel for wide contractions (conv1x1_x6w_kernel) on a problem with more tiles than the persistent grid and a
     channel-block count (9) that does not divide it - a workgroup's successive tiles differ in their output-channel block - forward
