@@ -64,7 +64,8 @@ def test_relayout(L):
 
 
 @pytest.mark.parametrize("B,h,w,cout,bits", [(2, 5, 7, 64, True), (1, 8, 16, 128, True), (3, 1, 1, 64, True), (2, 6, 20, 24, False),
-                                            (1, 33, 18, 8, False)])
+                                            (1, 33, 18, 8, False),
+                                            (2, 16400, 1, 8, False)])  # more than 65,535 output rows: the grid's z dimension
 def test_gather_forward_and_gate_bits(L, B, h, w, cout, bits):
     g = torch.Generator().manual_seed(2)
     z = torch.randn(B, 9 * cout, h, w, generator=g)
@@ -92,7 +93,7 @@ def test_gather_forward_and_gate_bits(L, B, h, w, cout, bits):
     assert rel_err(nchw(Y2), ypre + gather_reference(z, cout)) < 2e-6
 
 
-@pytest.mark.parametrize("B,h,w,cout", [(2, 5, 7, 16), (1, 8, 16, 64), (2, 1, 1, 8), (1, 2, 33, 24)])
+@pytest.mark.parametrize("B,h,w,cout", [(2, 5, 7, 16), (1, 8, 16, 64), (2, 1, 1, 8), (1, 2, 33, 24), (2, 33000, 1, 8)])
 def test_gather_backward_is_the_adjoint(L, B, h, w, cout):
     g = torch.Generator().manual_seed(3)
     z = torch.randn(B, 9 * cout, h, w, generator=g, dtype=torch.float64).requires_grad_(True)
