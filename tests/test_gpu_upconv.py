@@ -93,7 +93,7 @@ def test_gather_forward_and_gate_bits(L, B, h, w, cout, bits):
     assert rel_err(nchw(Y2), ypre + gather_reference(z, cout)) < 2e-6
 
 
-@pytest.mark.parametrize("B,h,w,cout", [(2, 5, 7, 16), (1, 8, 16, 64), (2, 1, 1, 8), (1, 2, 33, 24), (2, 33000, 1, 8)])
+@pytest.mark.parametrize("B,h,w,cout", [(2, 5, 7, 16), (1, 8, 16, 64), (2, 1, 1, 8), (1, 2, 33, 24), (2100, 32, 1, 8)])  # the last one: more than 65,535 rows (the row loop); h stays small - the fp64 reference has exact weights, fp32 src = scale * o does not at h ~ 3e4
 def test_gather_backward_is_the_adjoint(L, B, h, w, cout):
     g = torch.Generator().manual_seed(3)
     z = torch.randn(B, 9 * cout, h, w, generator=g, dtype=torch.float64).requires_grad_(True)
