@@ -96,9 +96,14 @@ __global__ __launch_bounds__(256, 3) void upconv_gather_fwd_kernel(const float4*
         if (row >= (unsigned)(B * H)) return;
         const unsigned b = row / (unsigned)H;
         const int Y = (int)(row - b * (unsigned)H);
+        // the accumulators start from the bridge half's convolution: its four loads are the first in flight, not the last (issued
+        // behind the gather they stood exposed in front of the stores - the instantiation without gate bits ran 10-15 % slower)
         float4 a[NX];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < NX; ++i) {
+            const unsigned xo = (unsigned)((min(X0 + i, W - 1) * C4 + c4) * 16);
+            a[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(y + (size_t)row * W * C4) + xo);
+        }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int qy = Y + ky - 1;
@@ -116,8 +121,11 @@ __global__ __launch_bounds__(256, 3) void upconv_gather_fwd_kernel(const float4*
                 // over array elements is turned into a dynamically indexed load by the optimiser - the array then lives in scratch
                 // memory (measured: 112 bytes of scratch per lane, 256 registers, 9x slower)
                 auto col = [&](int j) __attribute__((always_inline)) -> float4 {
-                    const unsigned o = (unsigned)min(cmin[kx] + j, w - 1) * pix9 + (unsigned)(kx * C4 + c4);
-                    const float4 t0 = z0[o], t1 = z1[o];
+                    // 32-bit BYTE offset from a block-uniform base: the scalar-base + vector-offset addressing mode (a 64-bit vector
+                    // address per load cost two more vector instructions each, in a kernel that is bound by them)
+                    const unsigned ob = ((unsigned)min(cmin[kx] + j, w - 1) * pix9 + (unsigned)(kx * C4 + c4)) * 16u;
+                    const float4 t0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(z0) + ob);
+                    const float4 t1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(z1) + ob);
                     return make_float4(hl0 * t0.x + hl1 * t1.x, hl0 * t0.y + hl1 * t1.y, hl0 * t0.z + hl1 * t1.z, hl0 * t0.w + hl1 * t1.w);
                 };
                 const float4 v0 = col(0), v1 = col(1), v2 = col(2), v3 = col(3);
@@ -140,8 +148,7 @@ __global__ __launch_bounds__(256, 3) void upconv_gather_fwd_kernel(const float4*
             const int X = X0 + i;
             if (X >= W) continue;  // (W is even; with NX = 4 the last group of a row may be half empty)
             const size_t idx4 = ((size_t)row * W + X) * C4 + c4;
-            float4 o = y[idx4];
-            o.x += a[i].x; o.y += a[i].y; o.z += a[i].z; o.w += a[i].w;
+            float4 o = a[i];
             if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             y[idx4] = o;
             if constexpr (BITS) {
@@ -435,7 +442,7 @@ extern "C" int punet_upconv_gather_fwd(const float* z, float* y, void* gate_out,
     PUNET_CHECK_ARG(z && y && B > 0 && h > 0 && w > 0 && cout > 0 && cout % 4 == 0, "punet_upconv_gather_fwd: bad args (cout=%d)", cout);
     PUNET_CHECK_ARG(!gate_out || cout % 64 == 0, "punet_upconv_gather_fwd: gate bits need cout %% 64 == 0 (got %d)", cout);
     const int C4 = cout / 4, W = 2 * w;
-    PUNET_CHECK_ARG((size_t)w * 9 * C4 < (1ull << 31) && (size_t)W * C4 < (1ull << 31), "punet_upconv_gather_fwd: a row exceeds 2^31 float4 elements");
+    PUNET_CHECK_ARG((size_t)w * 9 * C4 * 16 < (1ull << 32) && (size_t)W * C4 < (1ull << 31), "punet_upconv_gather_fwd: a row of z exceeds 2^32 bytes");
     constexpr int NX = PUNET_UPCONV_NX;
     const int rows = B * 2 * h, gy = rows < 65535 ? rows : 65535;
     const dim3 grid(ceil_div(ceil_div(W, NX) * C4, 256), gy, ceil_div(rows, gy));
