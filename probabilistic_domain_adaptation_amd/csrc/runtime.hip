@@ -543,7 +543,7 @@ size_t max_wgrad_ws_floats(const PunetRt* rt, int B, int H, int W) {
         const int bridge = rt->cfg.num_filters[lv];
         one(c0, c0.cin - bridge, lv);  // the up-sampled source
         one(c0, bridge, lv);           // the bridge
-        {   // K5x: the `up` rows' weight gradient at the low resolution (two slabs per slice)
+        {   // K5x: the `up` rows' weight gradient at the low resolution (four slabs per slice)
             const int cup = c0.cin - bridge, h = H >> (lv + 1), w = W >> (lv + 1);
             const size_t v = punet_upconv_wgrad_workspace_floats(cup, c0.cout, punet_upconv_wgrad_slices(cup, c0.cout, B, h, w));
             m = v > m ? v : m;

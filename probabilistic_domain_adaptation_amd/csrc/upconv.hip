@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void upconv_gather_bwd_kernel(const float4* __
 // transposing ds_read_b64_tr_b16, deterministic split-K (slabs summed in fixed order by reduce_slabs) - with the operands' roles
 // swapped: there ONE dz image serves nine shifted views of x, here ONE x image serves the nine channel blocks of dzt.  A
 // workgroup owns a 64 x 64 (ci, co) tile, THREE taps (their dzt images are 72 KB of LDS; all nine would be 216 KB) and a slice of
-// the pixels; its 8 waves = 4 (ci block, co block) pairs x 2 halves of the 64-pixel tile (the halves are two more split-K slabs).
+// the pixels; its 8 waves = 2 co blocks x 4 quarters of the 64-pixel tile (the quarters are four split-K slabs), each wave both ci blocks.
 // Single-buffered (96 KB): the next tile's global loads are in flight during the MFMAs and split in their shadow.
 typedef __bf16 up_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 up_bf16x4 __attribute__((ext_vector_type(4)));
@@ -266,7 +266,7 @@ constexpr int UWC = 64, UNPD = 64, UROWB = 64, UIMG = UNPD * UROWB, UTAPS = 3;  
 struct UpWgradArgs {
     const float* x;    // [M][cs]      low-resolution source, M = B h w pixels
     const float* dzt;  // [M][9][cout]
-    float* partial;    // [2 nslices][9][cs][cout]
+    float* partial;    // [4 nslices][9][cs][cout]
     int cs, cout, nslices;
     long M;
 };
@@ -281,8 +281,9 @@ __global__ __launch_bounds__(512, 2) void upconv_wgrad_x6_kernel(UpWgradArgs a) 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
-    const int pair = wave & 3, group = wave >> 2;  // group = half of the pixel tile (pixel groups 2 group, 2 group + 1)
-    const int cib = pair >> 1, cob = pair & 1;
+    // a wave = one 32-channel co block x BOTH ci blocks x one 16-pixel quarter of the tile: its x fragments serve three taps and its
+    // dzt fragments two ci blocks - 30 fragment reads per 36 MFMAs (the first version - one ci block, two quarters - read 24 per 18)
+    const int cob = wave & 1, quarter = wave >> 1;
     const int co_tiles = (a.cout + UWC - 1) / UWC;
     const int tg = blockIdx.y % 3;                         // taps 3 tg .. 3 tg + 2
     const int co_tile = (blockIdx.y / 3) % co_tiles, ci_tile = blockIdx.y / (3 * co_tiles);
@@ -290,11 +291,11 @@ __global__ __launch_bounds__(512, 2) void upconv_wgrad_x6_kernel(UpWgradArgs a) 
     const int slice = blockIdx.x;
     const long ntiles = (a.M + UNPD - 1) / UNPD;
 
-    f32x16 acc[UTAPS];
+    f32x16 acc[2][UTAPS];
 #pragma unroll
-    for (int t = 0; t < UTAPS; ++t)
+    for (int i = 0; i < 2 * UTAPS; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i / UTAPS][i % UTAPS][r] = 0.f;
 
     const int l16 = lane & 15, q = l16 >> 2, p4 = l16 & 3, cb = (lane >> 4) & 1;
     const int lane_off = (8 * half + q) * UROWB + (16 * cb + 4 * p4) * 2;  // (wgrad_x6.hip: the transposing read's lane mapping)
@@ -371,14 +372,15 @@ __global__ __launch_bounds__(512, 2) void upconv_wgrad_x6_kernel(UpWgradArgs a) 
         commit();
         __builtin_amdgcn_s_waitcnt(0xC07F);   // vmcnt(63) expcnt(7) lgkmcnt(0): this wave's LDS writes have landed
         __builtin_amdgcn_s_barrier();
+        {
+            const int s = quarter;  // this wave's pixel group of 16
+            UpFrag fa[2][NP];
 #pragma unroll
-        for (int sg = 0; sg < 2; ++sg) {
-            const int s = 2 * group + sg;  // this wave's pixel groups of 16
-            UpFrag fa[NP];
+            for (int cib = 0; cib < 2; ++cib)
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
+                for (int p = 0; p < NP; ++p)
 #pragma unroll
-                for (int r = 0; r < 2; ++r) fa[p].half4[r] = up_tr_read(sX, (p * 2 + cib) * UIMG + (16 * s + 4 * r) * UROWB + lane_off);
+                    for (int r = 0; r < 2; ++r) fa[cib][p].half4[r] = up_tr_read(sX, (p * 2 + cib) * UIMG + (16 * s + 4 * r) * UROWB + lane_off);
 #pragma unroll
             for (int t = 0; t < UTAPS; ++t) {
                 UpFrag fb[NP];
@@ -387,36 +389,44 @@ __global__ __launch_bounds__(512, 2) void upconv_wgrad_x6_kernel(UpWgradArgs a) 
 #pragma unroll
                     for (int r = 0; r < 2; ++r)
                         fb[p].half4[r] = up_tr_read(sD, ((t * NP + p) * 2 + cob) * UIMG + (16 * s + 4 * r) * UROWB + lane_off);
-                f32x16 c = acc[t];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1].v, fb[1].v, c, 0, 0, 0);  // mm
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2].v, fb[0].v, c, 0, 0, 0);  // lh
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0].v, fb[2].v, c, 0, 0, 0);  // hl
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1].v, fb[0].v, c, 0, 0, 0);  // mh
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0].v, fb[1].v, c, 0, 0, 0);  // hm
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0].v, fb[0].v, c, 0, 0, 0);  // hh
-                acc[t] = c;
-            }
-            // the next tile's split in the shadow of these MFMAs (its loads were issued before them)
-            if (sg == 0) {
 #pragma unroll
-                for (int i = 0; i < (XIT + DIT) / 2; ++i) split_unit(i);
-            } else {
+                for (int cib = 0; cib < 2; ++cib) {
+                    f32x16 c = acc[cib][t];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cib][1].v, fb[1].v, c, 0, 0, 0);  // mm
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cib][2].v, fb[0].v, c, 0, 0, 0);  // lh
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cib][0].v, fb[2].v, c, 0, 0, 0);  // hl
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cib][1].v, fb[0].v, c, 0, 0, 0);  // mh
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cib][0].v, fb[1].v, c, 0, 0, 0);  // hm
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cib][0].v, fb[0].v, c, 0, 0, 0);  // hh
+                    acc[cib][t] = c;
+                }
+                // the next tile's split in the shadow of these MFMAs (its loads were issued before the commit)
+                if (t == 0) {
 #pragma unroll
-                for (int i = (XIT + DIT) / 2; i < XIT + DIT; ++i) split_unit(i);
+                    for (int i = 0; i < 3; ++i) split_unit(i);
+                } else if (t == 1) {
+#pragma unroll
+                    for (int i = 3; i < 6; ++i) split_unit(i);
+                } else {
+#pragma unroll
+                    for (int i = 6; i < XIT + DIT; ++i) split_unit(i);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // slab (2 slice + group): rows [tap][ci], columns co - the layout of wgrad3x3_x6_kernel's slabs (reduce_slabs sums them)
+    // slab (4 slice + quarter): rows [tap][ci], columns co - the layout of wgrad3x3_x6_kernel's slabs (reduce_slabs sums them)
     const int co = co0 + cob * 32 + l31;
     if (co < a.cout) {
 #pragma unroll
-        for (int t = 0; t < UTAPS; ++t)
+        for (int cib = 0; cib < 2; ++cib)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ci = ci0 + cib * 32 + mfma32_row(r, half);
-                if (ci < a.cs) a.partial[((((size_t)(2 * slice + group)) * 9 + 3 * tg + t) * a.cs + ci) * a.cout + co] = acc[t][r];
-            }
+            for (int t = 0; t < UTAPS; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = ci0 + cib * 32 + mfma32_row(r, half);
+                    if (ci < a.cs) a.partial[((((size_t)(4 * slice + quarter)) * 9 + 3 * tg + t) * a.cs + ci) * a.cout + co] = acc[cib][t][r];
+                }
     }
 }
 
@@ -465,7 +475,7 @@ extern "C" int punet_upconv_gather_bwd(const float* dz, float* dzt, int B, int h
     return PUNET_OK;
 }
 
-// split-K slices of punet_upconv_wgrad_x6 (about one resident workgroup per CU) and its workspace (2 slabs per slice)
+// split-K slices of punet_upconv_wgrad_x6 (about one resident workgroup per CU) and its workspace (4 slabs per slice)
 extern "C" int punet_upconv_wgrad_slices(int cup, int cout, int B, int h, int w) {
     const long ntiles = ((long)B * h * w + UNPD - 1) / UNPD;
     const int groups = 3 * ceil_div(cup, UWC) * ceil_div(cout, UWC);
@@ -474,7 +484,7 @@ extern "C" int punet_upconv_wgrad_slices(int cup, int cout, int B, int h, int w)
     if (ns > ntiles) ns = ntiles;
     return ns < 1 ? 1 : (int)ns;
 }
-extern "C" size_t punet_upconv_wgrad_workspace_floats(int cup, int cout, int nslices) { return (size_t)2 * nslices * 9 * cup * cout; }
+extern "C" size_t punet_upconv_wgrad_workspace_floats(int cup, int cout, int nslices) { return (size_t)4 * nslices * 9 * cup * cout; }
 
 extern "C" int punet_upconv_wgrad_x6(const float* x, int cup, const float* dzt, int cout, float* dw, int cin_total, float* workspace,
                                      int nslices, int B, int h, int w, int accumulate, float scale, void* stream) {
@@ -492,5 +502,5 @@ extern "C" int punet_upconv_wgrad_x6(const float* x, int cup, const float* dzt, 
     upconv_wgrad_x6_kernel<<<grid, 512, SMEM, STREAM>>>(a);
     PUNET_LAUNCH_CHECK("upconv_wgrad_x6");
     // rows [tap][ci] of the slabs -> rows [0, cup) of every tap's [cin_total][cout] block of dw (deterministic: slabs in slice order)
-    return punet_launch_reduce_slabs(workspace, 2 * nslices, (size_t)9 * cup * cout, 9 * cup, cout, cup, cin_total, 0, dw, accumulate, scale, STREAM);
+    return punet_launch_reduce_slabs(workspace, 4 * nslices, (size_t)9 * cup * cout, 9 * cup, cout, cup, cin_total, 0, dw, accumulate, scale, STREAM);
 }
