@@ -523,6 +523,10 @@ def main():
                    "fp16 MFMA per product, per-tensor power-of-two scaling from amax instead of a global loss scale, fp32 storage",
             "f16s": "REDUCED PRECISION fast mode: as f16, plus fp16 STORAGE of every activation (unscaled, saturating - as under "
                     "autocast); gradients fp32 in memory, scaled per tensor in the kernels' loaders"}[eng.conv_mode]
+        out["config"]["up_blocks"] = ("K5x: the up-blocks' entry convolutions contract their `up` source at low resolution (conv3x3(up(x)) = sum_t "
+                                      "up(W_t . x): forward, input gradient and weight gradient; the up-sampled tensor is not materialised) - FLOPs "
+                                      "above are counted for the layers as WRITTEN" if getattr(eng, "upconv", False)
+                                      else "as written (bilinear x2 materialised, 3x3 convolution on the concat)")
         if prof:
             out["config"]["instrumented_eager_region"] = {
                 "ms_per_step": round(1e3 * dt_eager / a.steps, 3), "host_enqueue_ms_per_step": round(1e3 * t_enq_eager / a.steps, 2),
