@@ -591,7 +591,12 @@ def main():
                                    "kernel": kname, "flops_per_launch_avg": k3[0] / k3[2],
                                    "avg_launch_ms": round(1e3 * k3[1] / k3[2], 4), "peak_note": pnote,
                                    "timing": "HIP events on the launch stream around every launch of the kernel, live in this run, "
-                                             "over the K eagerly launched steps of config.instrumented_eager_region"}
+                                             "over the K eagerly launched steps of config.instrumented_eager_region",
+                                   "population_note": ("since round 4 (K5x) the 768 / 384 / 192-channel concat convolutions of the up-blocks - "
+                                                       "the launches this kernel ran fastest - are replaced by their bridge halves plus 1x1 "
+                                                       "GEMMs and gathers: the mean rate over the remaining launches is ~0.02 lower than round "
+                                                       "3's population at equal kernel code, while the step is 5 % faster"
+                                                       if getattr(eng, "upconv", False) else None)}
             out["kernels"] = kernels
         if not a.no_other_configs and not dp and a.workload == "mean_teacher" and (B, H, W, a.channels) == (4, 512, 512, 1):
             # BASELINE.json configs[2] / configs[3] per GPU, timed in this same process (short: 2 warm-up + 5 steps each)
