@@ -10,11 +10,14 @@
 // resolution is a gather: 9 taps x 4 bilinear neighbours of [cout]-vectors per output pixel, added to the bridge half's
 // convolution (the ordinary 3x3 kernel on the bridge alone), then bias (already in the bridge half), ReLU and the gate bits.
 // The same algebra turns the input gradient w.r.t. x into nine ADJOINT-interpolated maps of dz followed by one 1x1 input gradient
-//     dz_t[j] = sum_q up_weight(q, j) . dz[q - t + 1],        dx = gate(x) . sum_t W_t^T . dz_t .
+//     dz_t[j] = sum_q up_weight(q, j) . dz[q - t + 1],        dx = gate(x) . sum_t W_t^T . dz_t ,
+// and the weight gradient of the `up` rows into  dW_t = x^T . dz_t  (contracted over the low-resolution pixels): with all three in
+// this form the up-sampled tensor is needed by nothing, forward or backward.
 // Interpolation weights are K5's (punet_up_src in common.h: ATen's rounding of the source index).
 //
 // Entry points (include/punet_hip.h): punet_upconv_relayout (the weight slab's `up` rows as the [cup][9 cout] matrix of that 1x1
-// convolution, its bridge rows as a contiguous 3x3 slab), punet_upconv_gather_fwd, punet_upconv_gather_bwd.
+// convolution, its bridge rows as a contiguous 3x3 slab), punet_upconv_gather_fwd, punet_upconv_gather_bwd, punet_upconv_wgrad_x6
+// (+ punet_upconv_wgrad_slices / _workspace_floats).  The 1x1 convolutions themselves are punet_conv1x1_x6_gated (conv_x6.hip).
 #include "common.h"
 #include "punet_hip.h"
 
@@ -22,7 +25,7 @@ namespace {
 
 #define STREAM ((hipStream_t)stream)
 #ifndef PUNET_UPCONV_NX
-#define PUNET_UPCONV_NX 4  // output columns per thread of the forward gather (4 or 8; same-box A/B)
+#define PUNET_UPCONV_NX 4  // output columns per thread of the forward gather (the kernel is written for 4)
 #endif
 
 // w[t][ci][co] (ci < cup + cb) -> w9[ci][t * cout + co] for ci < cup ; wb[t][ci - cup][co] for the others (float4 units)
