@@ -1119,16 +1119,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 // GEMM; the remedy is a larger wave tile (fewer fragment reads per MFMA) with pre-split operands by LDS-DMA (no staging registers
 // to pay for the accumulators) - DESIGN.md section 8.  Rejected on the way (all +-0): staging two phases ahead, sub-chunk images
 // 128 bytes apart mod 256, weight units through registers, an XCD-aware tile order.
+// Round 4, later (128-channel tiles, tools/trace_x6w.py + -DX6W_TIMING on them): a phase takes ~5,000 cycles for 1,536 of MFMAs per
+// wave; the split moved between the MFMA groups (+1-2 %); a double-buffered form with the whole staging inside the K-step and one
+// barrier per phase measured +-0 (251 / 255 / 339 vs 249 / 259 / 342 us) and was removed again.  Without its epilogue the kernel
+// takes 207 / 187 / 207 us: writing z (151 / 302 / 604 MB: 9 cout floats per low-resolution pixel) costs 12 / 25 / 39 % - the
+// 512 x 512 block's GEMM is bound by that write, not by anything inside the K loop.
 // A thread stages the SAME pixel column and float4 of the 32 channels in every phase (unit = 8 rows x that column): lanes 0-7
 // read the 128 contiguous bytes of one pixel.  Tile, accumulator mapping, epilogue semantics and gate-bit layout are
 // conv3x3_x6_kernel's (weights as A, pixels as B: a lane holds one pixel and four consecutive channels per register quad).
 #ifndef X6W_TIMING  // timing-only builds of conv1x1_x6w_kernel (WRONG results): 1 = no epilogue, 2 = no split arithmetic, 4 = no activation
-#define X6W_TIMING 0  // loads, 8 = no MFMAs (tools/ab_variants.sh conv_x6.hip ...)
+#define X6W_TIMING 0  // loads, 8 = no MFMAs, 16 = the epilogue's stores as whole 128-byte lines (tools/ab_variants.sh conv_x6.hip ...)
 #endif
 // NB = 32-channel output blocks per wave: 2 = a 64-channel tile and 32-channel phases (above); 4 = a 128-channel tile and 16-channel
 // phases - the same 48 MFMAs per wave and phase, but every staged activation value and every pixel fragment serves twice the output
 // channels: the LDS traffic per MFMA cycle drops from 81 % to 55 % of the LDS's rate (the accumulators take 128 registers, which
 // is why the phases stage 16 channels instead of 32).  Used when the layer has at least 128 output channels.
+#ifdef X6W_TRACE  // s_memtime stamps of workgroup 9's phases 8..11 (tools/trace_x6w.py): per wave and phase: top, first barrier passed,
+                  // commit issued, operand barrier passed, first K-step issued, splits done.  The buffer travels in ConvX6Args::pool_out
+                  // (unused by this kernel), handed in through $PUNET_X6W_TRACE_PTR by the launcher of a trace build.
+#define X6WT(id)                                                                                                        \
+    do {                                                                                                                \
+        if (a.pool_out && blockIdx.x == 9 && (threadIdx.x & 63) == 0 && trace_phase >= 8 && trace_phase < 12)           \
+            reinterpret_cast<unsigned long long*>(a.pool_out)[((threadIdx.x >> 6) * 4 + (trace_phase - 8)) * 8 + (id)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define X6WT(id)
+#endif
 template <bool DGRAD, int NB>
 __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
     constexpr int NP = 3, NSUB = NB == 2 ? 4 : 2, CKP = 8 * NSUB, NPIX = TH * TW, TNW = 32 * NB;
@@ -1234,8 +1250,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
 #pragma unroll
         for (int it = 0; it < XITER; ++it) rx[it] = load_x(nph_, it);
     };
-    // one K-step = 16 channels: lanes 0-31 contract sub-chunk 2 ks, lanes 32-63 sub-chunk 2 ks + 1
-    auto kstep = [&](int ks) __attribute__((always_inline)) {
+    // one K-step = 16 channels: lanes 0-31 contract sub-chunk 2 ks, lanes 32-63 sub-chunk 2 ks + 1.  `mid(g)` is called after MFMA
+    // group g (12 MFMAs each; NB groups per K-step): the next phase's split goes there, i.e. BETWEEN the MFMAs of this wave - a wave
+    // issues in order, so vector work placed behind the K-step only started once all 48 MFMAs had been issued and ran with the matrix
+    // pipe idle (s_memtime timeline, tools/trace_x6w.py: 1,900 of a phase's 5,600 cycles)
+    auto kstep = [&](int ks, auto&& mid) __attribute__((always_inline)) {
         const int sub = 2 * ks + half;
         U4 av[NP][2];
 #pragma unroll
@@ -1250,7 +1269,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) bv[p][nb].u = sW[sub * SUBW + p * TNW + (2 * nbp + nb) * 32 + l31];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 2; ++m) {
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
                     f32x16 c = acc[m][2 * nbp + nb];
@@ -1262,6 +1281,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
                     c = punet_mfma32<false>(bv[0][nb].u, av[0][m].u, c);  // hh
                     acc[m][2 * nbp + nb] = c;
                 }
+                mid(2 * nbp + m);
+                __builtin_amdgcn_sched_barrier(0);  // keep the groups (and the split between them) where they are written
+            }
         }
     };
     // epilogue straight from the accumulators (mapping and gate-bit layout: conv3x3_x6_kernel)
@@ -1316,7 +1338,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
                             const float4 o = *reinterpret_cast<const float4*>(yb + pbase + ch);
                             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                         }
+#if X6W_TIMING & 16  // the same bytes in whole 128-byte lines per 8 lanes (a permutation of the tile: WRONG results)
+                        *reinterpret_cast<float4*>(yb + (unsigned)((gy * a.W + ti.tx0 + rg * 8 + (lane >> 3)) * N + ti.n0 + nb * 32 + (lane & 7) * 4)) = v;
+#else
                         *reinterpret_cast<float4*>(yb + pbase + ch) = v;
+#endif
                         if (!DGRAD)
                             gout |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u))
                                     << (16 * (nb & 1) + 4 * rg);
@@ -1335,6 +1361,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
     int tile = blockIdx.x;
     if (tile >= a.ntiles) return;
     int ph = 0;
+#ifdef X6W_TRACE
+    int trace_phase = 0;
+#endif
     TileInfo ti = decode(tile);
     retarget(ti);
     wlane = wlane_of(ti);
@@ -1357,23 +1386,39 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
             retarget(nti);
             ty_cur = nti.ty0;
         }
+        X6WT(0);
         __syncthreads();  // every wave has read the previous phase's fragments
+        X6WT(1);
         __builtin_amdgcn_s_setprio(3);
         commit(ph, nph_);
         __builtin_amdgcn_s_setprio(0);
+        X6WT(2);
         // the weight DMAs (older) must have landed, the XITER activation loads issued after them may stay in flight
         __builtin_amdgcn_s_waitcnt(XITER | (7 << 4) | (0 << 8));  // vmcnt(XITER) expcnt(7) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
+        X6WT(3);
+        // the next phase's split between the MFMA groups: NB groups per K-step, NSUB / 2 K-steps, XITER units
+        constexpr int GROUPS = NB * (NSUB / 2), UPG = XITER / GROUPS;  // 4 groups: 2 units each (NB = 2) or 1 (NB = 4)
+        static_assert(UPG * GROUPS == XITER, "the staged units divide evenly over the MFMA groups");
 #if !(X6W_TIMING & 8)
-        kstep(0);
-#endif
+        kstep(0, [&](int g) __attribute__((always_inline)) {
 #pragma unroll
-        for (int it = 0; it < XITER / 2; ++it) split_unit(it);  // the next phase's split in the shadow of the MFMAs
-#if !(X6W_TIMING & 8)
-        if constexpr (NSUB == 4) kstep(1);
-#endif
+            for (int u = 0; u < UPG; ++u) split_unit(g * UPG + u);
+        });
+        X6WT(4);
+        if constexpr (NSUB == 4)
+            kstep(1, [&](int g) __attribute__((always_inline)) {
 #pragma unroll
-        for (int it = XITER / 2; it < XITER; ++it) split_unit(it);
+                for (int u = 0; u < UPG; ++u) split_unit((NB + g) * UPG + u);
+            });
+#else
+#pragma unroll
+        for (int it = 0; it < XITER; ++it) split_unit(it);
+#endif
+        X6WT(5);
+#ifdef X6W_TRACE
+        ++trace_phase;
+#endif
         if (ph == nph - 1) {  // no barrier: the epilogue touches no LDS
             epilogue(ti);
             zero_acc();
@@ -1833,7 +1878,10 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
         if (dgrad) conv3x3_x6_kernel<1, true, 3, false, true><<<grid, 256, 0, st>>>(a);
         else conv3x3_x6_kernel<1, false, 3, false, true><<<grid, 256, 0, st>>>(a);
     } else if (ksize == 1 && c1 == 0 && c0 % 32 == 0 && punet_conv1x1_wide()) {  // wide contractions (K5x's GEMMs)
-        if (n_out >= 128 && punet_conv1x1_wide() == 2) {  // 128-channel tiles, 16-channel phases (fewer LDS bytes per MFMA)
+#ifdef X6W_TRACE
+        if (const char* tp = getenv("PUNET_X6W_TRACE_PTR")) a.pool_out = reinterpret_cast<float*>(strtoull(tp, nullptr, 0));
+#endif
+        if (n_out >= 128 && punet_conv1x1_wide() >= 2) {  // 128-channel tiles, 16-channel phases (fewer LDS bytes per MFMA)
             a.ntiles = B * ceil_div(H, TH) * ceil_div(W, TW) * ceil_div(n_out, 128);
             const int grid2 = a.ntiles < cap ? a.ntiles : cap;
             if (dgrad) conv1x1_x6w_kernel<true, 4><<<grid2, 256, 0, st>>>(a); else conv1x1_x6w_kernel<false, 4><<<grid2, 256, 0, st>>>(a);
