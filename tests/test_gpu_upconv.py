@@ -174,7 +174,7 @@ def test_composite_forward_and_input_gradient_against_the_layer_as_written(L, B,
 def test_wide_1x1_kernel_over_many_tiles(L, wide):
     """The 1x1 x6 kernel for wide contractions (conv1x1_x6w_kernel) on a problem with more tiles than the persistent grid and a
     channel-block count (9) that does not divide it - a workgroup's successive tiles differ in their output-channel block - forward
-    (bias, ReLU, gate bits) and input gradient (gate by bits, accumulate), against PyTorch CPU fp32.  $PUNET_CONV1X1_WIDE is read once
+    (bias, ReLU, gate bits; and plain, as K5x's GEMM runs it) and input gradient (gate by bits, accumulate), against PyTorch CPU fp32.  $PUNET_CONV1X1_WIDE is read once
     per process, so each setting runs in a child process."""
     import os
     import subprocess
@@ -216,8 +216,20 @@ L.call("punet_conv1x1_x6_gated", DZ.data_ptr(), cout, None, 0, pd.data_ptr(), nw
 torch.cuda.synchronize()
 ref = prev.permute(0, 3, 1, 2) + x.grad * (x.detach().half() > 0)
 e2 = rel(DX.permute(0, 3, 1, 2).cpu(), ref)
-print("ERR", e1, e2)
-assert e1 < 2e-6 and e2 < 3e-6, (e1, e2)
+# the plain forward (no ReLU, no gate bits: K5x's z, which the 128-channel-tile form computes as the transposed tile and stores in
+# whole lines), with and without a bias, on an image whose width is not a multiple of the tile's and rows beyond the last tile row
+e3 = 0.0
+for (B2, H2, W2), bias2 in (((4, 64, 128), True), ((3, 13, 45), False), ((2, 9, 32), True)):
+    x2 = torch.relu(torch.randn(B2, cin, H2, W2, generator=g))
+    y2 = F.conv2d(x2, w.detach(), b if bias2 else None)
+    X2 = x2.permute(0, 2, 3, 1).contiguous().cuda()
+    Y2 = torch.full((B2, H2, W2, cout), float("nan"), device="cuda")
+    L.call("punet_conv1x1_x6_gated", X2.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, b.cuda().data_ptr() if bias2 else None, 0,
+           Y2.data_ptr(), cout, None, None, None, 0, 0, B2, H2, W2, S)
+    torch.cuda.synchronize()
+    e3 = max(e3, rel(Y2.permute(0, 3, 1, 2).cpu(), y2))
+print("ERR", e1, e2, e3)
+assert e1 < 2e-6 and e2 < 3e-6 and e3 < 2e-6, (e1, e2, e3)
 """
     env = dict(os.environ, PUNET_CONV1X1_WIDE=wide)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
