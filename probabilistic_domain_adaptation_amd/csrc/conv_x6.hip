@@ -1123,7 +1123,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 // wave; the split moved between the MFMA groups (+1-2 %); a double-buffered form with the whole staging inside the K-step and one
 // barrier per phase measured +-0 (251 / 255 / 339 vs 249 / 259 / 342 us) and was removed again.  Without its epilogue the kernel
 // takes 207 / 187 / 207 us: writing z (151 / 302 / 604 MB: 9 cout floats per low-resolution pixel) costs 12 / 25 / 39 % - the
-// 512 x 512 block's GEMM is bound by that write, not by anything inside the K loop.
+// 512 x 512 block's GEMM is bound by that write, not by anything inside the K loop.  The stores are 32-byte pieces of 32 pixels;
+// as a timing-only permutation into whole 128-byte lines (X6W_TIMING bit 16) they measure 239 -> 234 / 255 -> 235 / 337 -> 304 us.
+// The transposed tile (pixels as A: a lane holds one channel of 16 pixels, whole lines by dword stores) was built, passed its
+// tests and measured 254 / 266 / 348 us on a box where the input gradients ran 2 % slower - four times the store instructions
+// queue in front of the next tile's loads; the float4 form needs an LDS transposition for ~0.1 ms of the step: not built
+// (profiles/r04/conv1x1_x6w_store_pattern_variants.txt).
 // A thread stages the SAME pixel column and float4 of the 32 channels in every phase (unit = 8 rows x that column): lanes 0-7
 // read the 128 contiguous bytes of one pixel.  Tile, accumulator mapping, epilogue semantics and gate-bit layout are
 // conv3x3_x6_kernel's (weights as A, pixels as B: a lane holds one pixel and four consecutive channels per register quad).
