@@ -110,6 +110,25 @@ def main():
         wsu = torch.empty(L.call("punet_upconv_wgrad_workspace_floats", cup, cout, nsu), device=dev)
         new["x6 low-res wgrad (GEMM-TN)"] = timeit(lambda: L.call("punet_upconv_wgrad_x6", x.data_ptr(), cup, dzt.data_ptr(), cout, dw.data_ptr(), cup,
                                                                     wsu.data_ptr(), nsu, B, h, h, 0, 1.0, S))
+        # z through the Infinity Cache instead of HBM: the GEMM and the gather image by image (or pair by pair) over ONE z buffer that
+        # is small enough to stay on chip between its producer and its consumer and is overwritten before it is written back
+        for per in (1, 2):
+            if B % per:
+                continue
+            zs = torch.empty(per, h, h, n9, device=dev)
+
+            def strips(per=per, zs=zs):
+                for b0 in range(0, B, per):
+                    L.call("punet_conv1x1_x6_gated", x[b0:].data_ptr(), cup, None, 0, p1.data_ptr(), cup * n9, n9, 0, b9.data_ptr(), 0,
+                           zs.data_ptr(), n9, None, None, None, 0, 0, per, h, h, S)
+                    L.call("punet_upconv_gather_fwd", zs.data_ptr(), y[b0:].data_ptr(), None, 1, per, h, h, cout, S)
+
+            def whole():
+                L.call("punet_conv1x1_x6_gated", x.data_ptr(), cup, None, 0, p1.data_ptr(), cup * n9, n9, 0, b9.data_ptr(), 0,
+                       z.data_ptr(), n9, None, None, None, 0, 0, B, h, h, S)
+                L.call("punet_upconv_gather_fwd", z.data_ptr(), y.data_ptr(), None, 1, B, h, h, cout, S)
+            new[f"GEMM + gather, whole batch (z {z.numel() * 4 / 1e6:.0f} MB)"] = timeit(whole)
+            new[f"GEMM + gather, {per} image(s) at a time (z {zs.numel() * 4 / 1e6:.0f} MB)"] = timeit(strips)
         gb_f = (z.numel() + 2 * y.numel()) * 4 / 1e9
         gb_b = (dz.numel() + dzt.numel()) * 4 / 1e9
         print(f"   gather traffic: forward {gb_f:.2f} GB = {gb_f / new['gather fwd (relu + gate bits)'] * 1e3:.2f} TB/s, "
