@@ -4,7 +4,9 @@ patches (BASELINE.json metric), N GPUs of one node, one process per GPU, RCCL al
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
                   [--workload mean_teacher|punet_source|inference|fixmatch|adamt|adamatch] [--channels C] [--size S]
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+  N > 1, either way: `python bench.py --gpus N ...` by itself (it then starts its own N ranks as fresh child processes, relays
+  rank 0's line and the ranks' exit code), or under a launcher:
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 One "step" = one Mean-Teacher iteration on a batch of 4 patches per GPU (mean_teacher_trainer.py:101-131):
 teacher forward + N=8 Monte-Carlo samples + consensus masking, student forward, ELBO (BCE + KL) + L2 regulariser,
@@ -285,6 +287,104 @@ def gflop_per_patch(workload, N, H, W, channels):
     return gf
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` WITHOUT torch.distributed.run in front of it: this process becomes the launcher.  It builds the
+    library once (in a child of its own, so that no rank compiles and this process loads nothing), starts the N ranks as FRESH
+    child processes of this very file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment (what
+    torch.distributed.run would set), relays rank 0's single JSON line and returns the ranks' exit code (the first non-zero one
+    in rank order: 3 = replicas diverged, 4 = a rank's graph self-check raised).  The launcher never touches the GPU: no HIP
+    call, no torch.cuda, no exec - the ranks are ordinary children (subprocess), and when one of them fails the others, which
+    would wait in a collective for ever, are ended by their exact PIDs."""
+    import socket
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        print(r.stdout, file=sys.stderr)
+        print("[bench launcher] the library build failed; no rank was started", file=sys.stderr)
+        return 5
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PUNET_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    print(f"[bench launcher] started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}", file=sys.stderr, flush=True)
+    # rank 0's stdout is the JSON line and nothing else (main() points fd 1 at stderr for everything else): read it to the end
+    # on a thread so that a full pipe never blocks the rank, and watch all ranks meanwhile
+    import threading
+    captured = []
+    reader = threading.Thread(target=lambda: captured.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * n
+    failed = None
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                c = p.poll()
+                if c is not None:
+                    codes[i] = c
+                    if c != 0 and failed is None:
+                        failed = i
+        if failed is not None:
+            # the surviving ranks are (or will be) inside a collective the failed rank never joins: give them a moment to fail by
+            # themselves (the process group notices a lost peer), then end exactly the processes started here
+            deadline = time.time() + 20.0
+            while time.time() < deadline and any(p.poll() is None for p in procs):
+                time.sleep(0.2)
+            for i, p in enumerate(procs):
+                if p.poll() is None:
+                    p.terminate()
+                    try:
+                        p.wait(10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        p.wait()
+                if codes[i] is None:
+                    codes[i] = p.returncode
+            break
+        time.sleep(0.05)
+    reader.join(10)
+    text = (captured[0] if captured else b"").decode(errors="replace")
+    lines = [l for l in text.splitlines() if l.lstrip().startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    rc = codes[failed] if failed is not None else 0  # the code of the rank that failed FIRST (the others were ended here)
+    if rc < 0:
+        rc = 128 - rc  # a rank killed by signal s reports 128 + s, as a shell would
+    if rc or not lines:
+        print(f"[bench launcher] exit codes by rank: {codes}" + ("" if lines else "; rank 0 printed no JSON line"), file=sys.stderr)
+        rc = rc or 6
+    return rc
+
+
+def stub_body(a):
+    """`--stub-body` (tests/test_bench_launcher_cpu.py): a rank that does everything main() does AROUND the measurement - process
+    group from the environment, a collective, one JSON line from rank 0 on the saved descriptor, the exit codes - and no GPU work,
+    so that the launcher path runs on a machine without a GPU."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t)
+    out = {"metric": "stub", "value": float(t.item()), "n_gpus": world, "world_size_seen": dist.get_world_size() if world > 1 else 1,
+           "replicas_identical": True, "launched_by": "bench.py" if os.environ.get("PUNET_BENCH_LAUNCHED") else "external launcher"}
+    fail = os.environ.get("PUNET_BENCH_STUB_FAIL")  # "<rank>:<code>": that rank exits with that code before the last barrier
+    if fail and int(fail.split(":")[0]) == rank:
+        sys.exit(int(fail.split(":")[1]))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out if rank == 0 else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -321,7 +421,12 @@ def main():
                     help="one-GPU rehearsal of the data-parallel path over the REAL backend: a one-rank RCCL group with the trainers' "
                          "world size forced to 2 (one-rank collectives are the identity; the gradient scale is 1/2), so that every "
                          "data-parallel code path of this file and of the fused steps runs through ProcessGroupNCCL; not a measurement")
+    ap.add_argument("--stub-body", action="store_true", help=argparse.SUPPRESS)  # launcher test: ranks without GPU work (stub_body)
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: start the N ranks here (before anything in this process touches the GPU) and relay
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
 
     # stdout carries the ONE JSON line and nothing else: native libraries write to file descriptor 1 behind Python's back (RCCL
     # prints a version banner there when its first communicator is built), so fd 1 is pointed at stderr for the whole run and
@@ -335,7 +440,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {a.gpus} was started under a launcher with WORLD_SIZE={world}: the two must agree "
+                         f"(without a launcher, `python bench.py --gpus {a.gpus}` starts its own ranks)")
+    if a.stub_body:
+        out = stub_body(a)
+        if out is not None:
+            os.write(line_fd, (json.dumps(out) + "\n").encode())
+        return
     local = local % max(torch.cuda.device_count(), 1)  # gloo rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -495,6 +606,8 @@ def main():
                                     "to 2 (identity collectives, gradient scale 1/2) - the data-parallel code path over the real backend")
             out["replicas_identical"] = replicas["identical"]
             out["world_size_seen"] = dist.get_world_size()
+            out["exposed_allreduce_ms_per_step"] = exposed_ms  # rank 0, HIP events (config.distributed.exposed_note)
+            out["launched_by"] = "bench.py (own ranks)" if os.environ.get("PUNET_BENCH_LAUNCHED") else "external launcher"
             out["config"]["distributed"] = {
                 "world_size_seen": dist.get_world_size(), "backend": dist.get_backend(),
                 "replicas": replicas, "graph_selfcheck_bit_identical_to_eager_on_every_rank": graph_selfcheck,

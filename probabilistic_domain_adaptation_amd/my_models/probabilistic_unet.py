@@ -103,6 +103,8 @@ class ProbabilisticUnet(nn.Module):
             raise RuntimeError("ProbabilisticUnet (MI355X build) needs a ROCm GPU: there is no CPU fallback")
         self.layout = ParamLayout(input_channels, num_classes, self.num_filters, latent_dim, no_convs_fcomb)
         self.engine = PUNetEngine(self.layout, dev, conv_mode)
+        self._engines = {self.engine.conv_mode: self.engine}  # one engine per conv arithmetic, kept for the model's life
+        self._native_rts = {}                                 # one native runtime per (conv arithmetic, criterion), likewise
         self._flat = torch.zeros(self.layout.numel, dtype=torch.float32, device=dev)
         self._views = self.layout.views(self._flat)
         for name, v in self._views.items():
@@ -145,21 +147,36 @@ class ProbabilisticUnet(nn.Module):
         """The step-level native runtime of this model's configuration (runtime.NativeRuntime: the graph walk as host code
         inside libpunet_hip.so), created on first use; raises ValueError outside its domain (num_classes 1, num_filters[0] in
         {32, 64}, no_convs_fcomb 2 or 3) and for arithmetics other than "x6" (parity), "f16x3" and "f16"."""
-        rt = getattr(self, "_native_rt", None)
-        if rt is None or rt.conv_mode != self.engine.conv_mode or rt.dice != bool(self.rl_swap):
+        key = (self.engine.conv_mode, bool(self.rl_swap))
+        rt = self._native_rts.get(key)
+        if rt is None:
             from ..runtime import NativeRuntime
-            rt = self._native_rt = NativeRuntime(self.layout, self.device, self.engine.conv_mode, dice=bool(self.rl_swap))
+            rt = self._native_rts[key] = NativeRuntime(self.layout, self.device, key[0], dice=key[1])
         return rt
 
     def set_conv_mode(self, conv_mode: str):
         """Switch the 3x3 conv arithmetic of this model (engine.PUNetEngine: "x6" parity default, "f32", or a fast mode -
-        "f16x3", "f16", "x3", "bf16", "bf16s").  The engine holds no weights, so a new one is built; cached forward state is
-        dropped.  Trainers call this for mixed_precision=True (my_trainer/default_trainer.py)."""
+        "f16x3", "f16", "x3", "bf16", "bf16s").  An engine holds no weights; ONE engine (and, on first use, one native runtime)
+        per arithmetic is built and then KEPT for the model's life, so switching back and forth - mixed_precision=True applied
+        on entry to fit() and restored on exit - swaps between the same objects: `model.engine` has a stable identity per mode,
+        a hipGraph captured against an engine's buffers stays valid while the model lives, nothing is re-uploaded.
+        `model.engine` is therefore NOT the same object before and after a switch: hold `model`, not `model.engine`.
+        `release_conv_mode_cache()` frees the engines of the modes not in use.  Cached forward state is dropped."""
         if conv_mode != self.engine.conv_mode:
-            self.engine = PUNetEngine(self.layout, self.device, conv_mode)
+            eng = self._engines.get(conv_mode)
+            if eng is None:
+                eng = self._engines[conv_mode] = PUNetEngine(self.layout, self.device, conv_mode)
+            self.engine = eng
             self._state = None
             self._features_nchw = None
         return self
+
+    def release_conv_mode_cache(self):
+        """Drop the engines / native runtimes (workspaces, arenas, tables) of every conv arithmetic but the current one.  Graphs a
+        trainer captured against them keep what they need alive themselves (GraphedStep holds its engines and buffers)."""
+        cur = self.engine.conv_mode
+        self._engines = {cur: self.engine}
+        self._native_rts = {k: v for k, v in self._native_rts.items() if k[0] == cur}
 
     def __deepcopy__(self, memo):
         """deepcopy(model) -> teacher (mean_teacher_trainer.py:40): a new flat buffer with the same values."""

@@ -60,18 +60,23 @@ class _PUNetTrainerBase(DefaultTrainer):
 
     def _graphed(self, kind, tensors, body, **ema):
         """Replay (capturing first, once per kind / shapes / lr truthiness) the fused step `body` on `tensors`."""
-        key = (kind, bool(self._lr())) + tuple((k, tuple(v.shape)) for k, v in tensors.items())
-        # a graph is captured against the ENGINES of the models it runs (weight planes, tables, workspaces they own): a
-        # set_conv_mode() since then - mixed_precision applied or restored - has replaced an engine, and replaying a graph of the
-        # old one would compute in the old arithmetic through buffers that may be gone
-        engines = tuple(id(m.engine) for m in (self.model, getattr(self, "teacher", None)) if m is not None)
-        if getattr(self, "_graph_engines", engines) != engines:
-            self._graphs.clear()
-        self._graph_engines = engines
+        nets = [m for m in (self.model, getattr(self, "teacher", None)) if m is not None]
+        # a graph is captured against the ENGINES (and native runtimes) of the models it runs - weight planes, tables,
+        # workspaces, arenas they own - in one conv arithmetic: the arithmetic is part of the key (a graph of each mode can
+        # coexist: mixed_precision switches modes on entry to and exit from fit()), and the captured entry holds STRONG
+        # references to those engines, compared by identity - never by id(), which CPython reuses once an object is freed
+        # (ADVICE r4: a stale graph replaying through freed planes).  An entry whose engines are no longer the models' is dropped.
+        key = (kind, bool(self._lr()), tuple(m.engine.conv_mode for m in nets)) + tuple((k, tuple(v.shape)) for k, v in tensors.items())
+        engines = tuple(m.engine for m in nets)
         gs = self._graphs.get(key)
+        if gs is not None and not (len(gs.owners) == len(engines) and all(a is b for a, b in zip(gs.owners, engines))):
+            del self._graphs[key]
+            gs = None
         if gs is None:
             static = {k: v.to(device=self.model.device, dtype=torch.float32).clone() for k, v in tensors.items()}
             gs = self._graphs[key] = FU.GraphedStep(body, static, self.optimizer, **ema)
+            gs.owners = engines  # keeps them (and through _keep their buffers) alive as long as this graph is
+            gs.owner_runtimes = tuple(getattr(m, "_native_rts", {}).get((m.engine.conv_mode, bool(m.rl_swap))) for m in nets)
             while len(self._graphs) > self.max_graphs:
                 self._graphs.popitem(last=False)
         self._graphs.move_to_end(key)

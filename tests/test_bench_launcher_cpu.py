@@ -1,0 +1,50 @@
+"""bench.py's own launcher: a bare `python bench.py --gpus N` starts its N ranks as fresh child processes, relays
+rank 0's single JSON line and the ranks' exit code.  Runs the launcher path with a stub body (no GPU work, gloo on the CPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_bare_gpus_n_starts_its_own_ranks_and_prints_one_line(n):
+    r = run(["--gpus", str(n), "--stub-body"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout  # ONE JSON line on stdout and nothing else
+    out = json.loads(lines[0])
+    assert out["world_size_seen"] == n and out["n_gpus"] == n and out["replicas_identical"] is True
+    assert out["value"] == n * (n + 1) / 2  # the all-reduce really spanned the n ranks
+    assert out["launched_by"] == "bench.py"
+
+
+@pytest.mark.parametrize("code", [3, 4])
+def test_a_failing_rank_ends_the_run_with_its_exit_code(code):
+    """Exit codes 3 (replicas diverged) and 4 (a rank's graph self-check raised) must reach the caller, and the surviving rank,
+    which waits in a barrier for the failed one, must not be left behind."""
+    r = run(["--gpus", "2", "--stub-body"], {"PUNET_BENCH_STUB_FAIL": f"1:{code}"}, timeout=120)
+    assert r.returncode == code, (r.returncode, r.stderr[-2000:])
+    assert "exit codes by rank" in r.stderr
+
+
+def test_under_an_external_launcher_the_world_sizes_must_agree():
+    r = run(["--gpus", "4", "--stub-body"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "must agree" in r.stderr
+
+
+def test_single_process_default_is_untouched_by_the_launcher():
+    r = run(["--stub-body"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip())
+    assert out["n_gpus"] == 1 and out["launched_by"] == "external launcher"

@@ -95,6 +95,54 @@ def test_mean_teacher_graph_equals_eager_with_lr_change(dev):
     assert len(b._graphs) == 1 and a.optimizer.step_count == 5
 
 
+@pytest.mark.parametrize("runtime", ["native", "python"])
+def test_graph_replay_across_conv_mode_switches_equals_eager(dev, monkeypatch, runtime):
+    """graphs were invalidated by comparing id(engine) tuples, and every set_conv_mode() built (and freed) an engine -
+    CPython reuses ids, so x6 -> f16x3 -> x6 -> f16x3 could replay a stale graph through freed weight planes.  Now a model keeps
+    ONE engine per arithmetic, the arithmetic is part of the graph key and a captured step holds its engines by reference:
+    switching back and forth replays the right graph of each mode (two captures for four switches), bit-identical to the same
+    sequence launched eagerly, and `model.engine` is the same object each time a mode comes back."""
+    import gc
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam, MeanTeacherTrainer
+    monkeypatch.setenv("PUNET_RUNTIME", runtime)
+    data = _batches(8)
+
+    def make(graph):
+        m = _model(dev)
+        tr = MeanTeacherTrainer(name=None, train_loader=data[:1], val_loader=None, model=m, optimizer=FusedAdam(m, lr=LR), device=dev,
+                                do_consensus_masking=True, graph=graph)
+        tr.n_samples = 4
+        return tr
+
+    a, b = _pair(make)
+    seen = {}
+    for i, mode in enumerate(["x6", "f16x3", "x6", "f16x3", "f16", "x6", "f16x3", "f16"]):
+        for tr in (a, b):
+            tr.model.set_conv_mode(mode)
+            tr.teacher.set_conv_mode(mode)
+            tr.train_loader = data[i:i + 1]
+            tr._train_epoch_impl(_P(), contextlib.nullcontext, None)
+        gc.collect()  # (anything a switch had freed would be gone by now)
+        torch.cuda.synchronize()
+        _same(a, b)
+        assert seen.setdefault(mode, b.model.engine) is b.model.engine  # one engine per mode, for the model's life
+    assert len(b._graphs) == 3  # one capture per arithmetic, replayed on every return to it
+    for gs in b._graphs.values():
+        assert gs.owners[0] in seen.values()
+    # an entry whose engines are no longer the models' (cache released, a new engine built for the mode) is re-captured, not replayed
+    for m in (b.model, b.teacher, a.model, a.teacher):
+        m.set_conv_mode("x6")
+        m.release_conv_mode_cache()
+        m.set_conv_mode("f16x3")
+    assert b.model.engine is not seen["f16x3"]
+    for tr in (a, b):
+        tr.train_loader = data[:1]
+        tr._train_epoch_impl(_P(), contextlib.nullcontext, None)
+    torch.cuda.synchronize()
+    _same(a, b)
+    assert any(gs.owners[0] is b.model.engine for gs in b._graphs.values())
+
+
 @pytest.mark.parametrize("runtime,mode", [("native", "x6"), ("python", "x6"), ("native", "f16x3"), ("python", "f16x3")])
 def test_graph_survives_larger_eager_shapes_on_the_same_engine(dev, monkeypatch, runtime, mode):
     """the captured graph holds raw pointers of the engines' grow-only workspaces.  A validation pass with four
