@@ -70,6 +70,9 @@ int punet_conv_dgrad_t(const float* dz, int cout, const float* wt, int cin_total
  *     other channel counts and for 1x1).  Same results to rounding; every kernel test runs with both.
  * opts = 0 selects both defaults. */
 #define PUNET_X6_OPTS(products, shape) ((int)(products) | ((int)(shape) << 8))
+/* punet_conv3x3_splitk only, OR-ed into opts: how the last partial round is dealt - 0 (default) = by the library's cost model,
+ * 1 = never split, n >= 2 = runs of n - 1 quads (a quad = 32 contracted channels) whatever the cost model says (tests, A/B) */
+#define PUNET_X6_SPLITK(n) ((int)(n) << 16)
 /* compute units of the current device (grids are sized from it: persistent kernels launch one residency round) */
 int punet_compute_units(void);
 int punet_split_weights_x6(const float* w, void* planes, long plane_stride, int cin, int cout, int ksize, int mode,
@@ -100,6 +103,24 @@ int punet_conv3x3_x6_gated(const float* x0, int c0, const float* x1, int c1, con
 int punet_conv3x3_x6_pooled(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
                             int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out,
                             void* gate_out, float* pool_out, int relu, int B, int H, int W, int opts, void* stream);
+/* Stream-K tail (round 5; tile quantization of the persistent grid): the 3x3 forward / input-gradient
+ * kernels deal ntiles = B*ceil(H/8)*ceil(W/32)*ceil(n_out/64) equal tiles to 2 workgroups per CU; when that is not a whole
+ * number of rounds (704 x 704 patches of MitoEM/mitoem_*.py: 2.06 rounds at the 88 x 88 level, 7.56 at 352 x 352) the tiles of
+ * the last, partial round are dealt as one range of K-quads in equal runs over the workgroups, the partial accumulators meet
+ * in `scratch`, and the workgroup that completes a tile sums its parts in a fixed order and runs the epilogue: deterministic
+ * (bit-identical run to run; differs from the unsplit launch by summation order only), no workgroup ever waits for another.
+ * punet_conv3x3_splitk is the superset of punet_conv3x3_x6_gated / _pooled (f16_planes = 0: bf16 planes by `opts`) and
+ * punet_conv3x3_f16 (f16_planes = 2 | 1) with that scratch: `scratch_bytes` <= punet_conv_splitk_scratch_bytes() bytes of
+ * device memory, 16-byte aligned, whose first 4096 bytes (arrival counters) are ZERO before the first use and are left zero
+ * by every launch; one scratch serves every launch of one stream (launches of different streams need their own).
+ * scratch = NULL: no split (= the entry points above).  Used where the layer's contracted channel count is a multiple of 32
+ * (conv3x3_x6b_kernel); a no-op elsewhere. */
+size_t punet_conv_splitk_scratch_bytes(void);
+int punet_conv3x3_splitk(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride, int n_row,
+                         int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
+                         const void* gate_bits, void* gate_out, float* pool_out, int accumulate, int relu, int B, int H, int W,
+                         int opts, int f16_planes, const float* amax_x0, const float* amax_x1, const float* amax_w, float* amax_y,
+                         void* scratch, size_t scratch_bytes, void* stream);
 /* The same kernel for 1x1 convolutions (the Fcomb layers, probabilistic_unet.py:168-173): planes from
  * punet_split_weights_x6(..., ksize = 1, ...), c0/c1 multiples of 8; always the six-product parity arithmetic. */
 int punet_conv1x1_x6_gated(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,

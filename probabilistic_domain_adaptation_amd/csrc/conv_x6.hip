@@ -63,7 +63,19 @@ struct ConvX6Args {
     const float* amax_w;
     float* amax_out;
     unsigned m_ntn, m_tx, m_ty;  // floor(2^32 / d) + 1 for d = channel blocks, tiles per row, tile rows: n / d = mulhi(n, m)
-};                               // exactly while n * d < 2^32 (host check) - the tile decode without a division
+                                 // exactly while n * d < 2^32 (host check) - the tile decode without a division
+    // Stream-K tail (conv3x3_x6b_kernel only; sk_plan below).  Work ITEMS [0, sk_whole) are whole tiles, dealt round-robin.  The
+    // remaining ntiles - sk_whole tiles (fewer than one round) are a contiguous range of sk_Q = (ntiles - sk_whole) * K/32 QUADS
+    // (4 chunks = 32 contracted channels, one cycle of the kernel's four phases) dealt in runs of sk_D quads to sk_P WORKERS
+    // (workgroup v < sk_P takes quads [v * sk_D, (v + 1) * sk_D) after its whole tiles): a worker's run covers parts of at most two
+    // tiles = tail items sk_whole + 2 v and sk_whole + 2 v + 1.  A partial item's accumulators go to slot (item - sk_whole) of
+    // sk_ws (64 KB each); the workgroup whose arrival at sk_cnt[tile - sk_whole] completes the tile sums its slots in worker order
+    // and runs the tile's epilogue (and leaves the counter at zero again).  Off: sk_P = 0, sk_whole = ntiles.
+    float* sk_ws;
+    unsigned* sk_cnt;
+    int sk_whole, sk_P, sk_D, sk_Q;
+    unsigned m_D, m_nq;
+};
 
 static inline unsigned x6_magic(int d) { return (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
 
@@ -1020,29 +1032,116 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 #ifdef X6B_TRACE
     int trace_chunk = 0;
 #endif
-    int tile = blockIdx.x;
-    if (a.xcd_remap) tile = (tile & 7) * ((int)gridDim.x >> 3) + (tile >> 3);
-    if (tile >= a.ntiles) return;
-    int ch = 0;
+    // work items (block-uniform scalars): whole tiles first, then this workgroup's run of the stream-K tail (ConvX6Args)
+    const int nq = nchunks >> 2;
+    bool more = false;  // the current tail item is followed by the second one of the same worker
+    auto item_decode = [&](int it, int& tl, int& cb, int& ce, int& pt, bool& mo) __attribute__((always_inline)) {
+        if (it < a.sk_whole) {
+            tl = it; cb = 0; ce = nchunks; pt = -1; mo = false;
+        } else {
+            const unsigned j = (unsigned)__builtin_amdgcn_readfirstlane(it - a.sk_whole);
+            const unsigned v = j >> 1;
+            const unsigned q0 = v * (unsigned)a.sk_D, q1 = min(q0 + (unsigned)a.sk_D, (unsigned)a.sk_Q);
+            const unsigned t0 = __umulhi(q0, a.m_nq);      // q0 / nq (nq >= 2)
+            const unsigned b1 = (t0 + 1u) * (unsigned)nq;  // first quad of the next tile
+            unsigned tt, qb, qe;
+            if (!(j & 1u)) {
+                tt = t0; qb = q0 - t0 * (unsigned)nq; qe = min(q1, b1) - t0 * (unsigned)nq; mo = q1 > b1;
+            } else {
+                tt = t0 + 1u; qb = 0u; qe = q1 - b1; mo = false;
+            }
+            tl = a.sk_whole + (int)tt;
+            cb = (int)(4u * qb);
+            ce = (int)(4u * qe);
+            pt = qe - qb == (unsigned)nq ? -1 : (int)j;  // a run that covers a whole tile needs no hand-off
+        }
+    };
+    int wg = blockIdx.x;
+    if (a.xcd_remap) wg = (wg & 7) * ((int)gridDim.x >> 3) + (wg >> 3);
+    int item = wg;
+    if (item >= a.sk_whole) {  // fewer whole tiles than workgroups: straight to the tail
+        if (wg >= a.sk_P) return;
+        item = a.sk_whole + 2 * wg;
+    }
+    int tile, ch, ch_end, part;
+    item_decode(item, tile, ch, ch_end, part, more);
     TileInfo ti = decode(tile);
     retarget(ti);
     wlane = wlane_of(ti);
-    prefetch(0);
+    prefetch(ch);
 #pragma unroll
     for (int it = 0; it < XITER; ++it) split_unit(it);
 
+    // A part of a split tile is done: publish its accumulators, count the arrival; the LAST arriver (whichever workgroup that is)
+    // sums all parts in part order - bit-identical whoever it is - and returns true: it then runs the tile's epilogue.
+    // Inter-workgroup hand-off as MI355X_MICROARCH.md prescribes (per-XCD L2s are not coherent): every storing wave drains its
+    // stores, workgroup barrier, ONE lane: agent-scope release (L2 write-back) -> wait -> agent-scope atomic add; the last
+    // arriver: agent-scope acquire -> wait -> workgroup barrier -> plain loads.  No workgroup ever waits for another one.
+    auto sk_finish = [&]() __attribute__((always_inline)) -> bool {
+        const unsigned tt = (unsigned)(tile - a.sk_whole);
+        f32x4* const slot = reinterpret_cast<f32x4*>(a.sk_ws) + ((size_t)part * 16) * 256 + tid;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) slot[i * 256] = acc[i >> 2][i & 3];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave has stored and drained; every wave has finished its fragment reads: the LDS is free
+        // the workers whose runs meet in this tile: those of its first and of its last quad, and everyone between them
+        auto worker_of = [&](unsigned q) { return a.sk_D == 1 ? q : __umulhi(q, a.m_D); };
+        const unsigned v_first = worker_of(tt * (unsigned)nq), v_last = worker_of((tt + 1u) * (unsigned)nq - 1u);
+        volatile unsigned* const flag = reinterpret_cast<volatile unsigned*>(smem);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop its own wait behind the write-back)
+            const unsigned old = __hip_atomic_fetch_add(a.sk_cnt + tt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = old == v_last - v_first ? 1u : 0u;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(a.sk_cnt + tt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            }
+            flag[0] = last;
+        }
+        __syncthreads();
+        const bool last = flag[0] != 0u;  // block-uniform; the next phase's first barrier orders this read before any LDS write
+        if (!last) return false;
+        for (unsigned v = v_first; v <= v_last; ++v) {  // worker order, whoever arrived last: bit-reproducible
+            // worker v holds this tile in its first item iff its run STARTS in this tile
+            const unsigned sl = 2u * v + (__umulhi(v * (unsigned)a.sk_D, a.m_nq) == tt ? 0u : 1u);
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.sk_ws) + ((size_t)sl * 16) * 256 + tid;
+            if (v == v_first) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] = src[i * 256];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] += src[i * 256];
+            }
+        }
+        return true;
+    };
+
     auto phase = [&](auto ph_c) __attribute__((always_inline)) -> bool {
         constexpr int ph = decltype(ph_c)::value;
-        int nch = ch + 1, ntile = tile;
+        int nch = ch + 1, nitem = item, ntile = tile, nce = ch_end, npart = part;
+        bool nmore = more;
         TileInfo nti = ti;
-        if (ph == 3 && nch == nchunks) {
-            nch = 0;
-            ntile = tile + (int)gridDim.x;
-            if (ntile < a.ntiles) nti = decode(ntile);
+        bool has_next = true;
+        if (ph == 3 && nch == ch_end) {
+            if (item < a.sk_whole) {  // after the last whole tile: this workgroup's run of the tail, if it has one
+                nitem = item + (int)gridDim.x;
+                if (nitem >= a.sk_whole) {
+                    nitem = a.sk_whole + 2 * wg;
+                    has_next = wg < a.sk_P;
+                }
+            } else {
+                nitem = item + 1;
+                has_next = more;
+            }
+            if (has_next) {
+                item_decode(nitem, ntile, nch, nce, npart, nmore);
+                nti = decode(ntile);
+            }
         }
-        const bool has_next = ntile < a.ntiles;
         if (!has_next) nch = ch;
-        if (ph == 3 && has_next && nch == 0) retarget(nti);
+        if (ph == 3 && has_next && nitem != item) retarget(nti);
         __syncthreads();
         X6BT(0);
         __builtin_amdgcn_s_setprio(3);
@@ -1053,7 +1152,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         __builtin_amdgcn_s_waitcnt(XITER | (7 << 4) | (0 << 8));  // vmcnt(XITER) expcnt(7) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         X6BT(1);
-        if (ph == 3 && ch == nchunks - 1) epilogue_prefetch(ti);  // block-uniform
+        if (ph == 3 && ch == ch_end - 1 && part < 0) epilogue_prefetch(ti);  // block-uniform
         auto s0 = [&]() __attribute__((always_inline)) { split_unit(0); };
         auto s1 = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -1080,13 +1179,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 #ifdef X6B_TRACE
         ++trace_chunk;
 #endif
-        if (ph == 3 && ch == nchunks - 1) {  // no barrier: the epilogue touches no LDS, waves drain into it as they finish
-            epilogue(ti);
+        if (ph == 3 && ch == ch_end - 1) {  // no barrier: the epilogue touches no LDS, waves drain into it as they finish
+            bool run = true;
+            if (part >= 0) {  // block-uniform: a part of a split tile (always among the LAST items of a workgroup)
+                run = sk_finish();
+                if (run) epilogue_prefetch(ti);
+            }
+            if (run) epilogue(ti);
             zero_acc();
         }
         if (ph == 3 && ntile != tile) wlane = wlane_of(nti);  // the next tile's weight columns, from its first commit on
+        item = nitem;
         tile = ntile;
         ch = nch;
+        ch_end = nce;
+        part = npart;
+        more = nmore;
         ti = nti;
         return !has_next;
     };
@@ -1716,7 +1824,79 @@ struct F16Scales {  // fp16-operand arithmetic (planes = 2 or 1; 0 = the bf16 sp
 static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
                           int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
                           const void* gate_bits, void* gate_out, int accumulate, int relu, int B, int H, int W, int opts,
-                          void* stream, float* pool_out = nullptr, const F16Scales& f16 = F16Scales());
+                          void* stream, float* pool_out = nullptr, const F16Scales& f16 = F16Scales(), void* scratch = nullptr,
+                          size_t scratch_bytes = 0);
+
+// ---- stream-K tail of the persistent 3x3 kernels (conv3x3_x6b_kernel): what to do with the tiles of the last, partial round.
+// A launch deals ntiles equal tiles to `cap` resident workgroups; when ntiles is not a multiple of cap the last round keeps a
+// fraction of the chip busy for a whole tile time (704 x 704 patches: 1,056 tiles = 2.06 rounds at the 88 x 88 level, 3,872 =
+// 7.56 at the 352 x 352 level).  The T tiles of that round are therefore dealt as ONE range of T * K/32 quads (a quad = 4 chunks
+// = one cycle of the kernel's phases) in equal runs of D quads to P = ceil(T * nq / D) <= cap workgroups; a run covers parts of
+// at most two tiles, the parts' accumulators meet in the caller's scratch (2 slots per worker) and the workgroup that completes a
+// tile runs its epilogue (kernel comment).  Costs in units of one 8-channel chunk of one tile (~3-4 us): a partial item pays ~3
+// for publishing 64 KB, the combining workgroup ~1.5 + 0.35 per part; an unsplit tail runs ~0.8 of a tile time when its
+// workgroups have their CUs to themselves.
+constexpr size_t SK_COUNTER_BYTES = 4096, SK_SLOT_BYTES = 16 * 256 * 16;
+struct SkPlan {
+    int whole, P, D, Q;
+};
+static int punet_splitk_mode() {  // $PUNET_SPLITK: 0 = never split, n >= 1 = runs of n quads wherever a launch has a partial round
+    static const int m = [] {    // (A/B); unset = by the cost model; read once per process (an A/B switch like PUNET_CONV1X1_WIDE)
+        const char* e = getenv("PUNET_SPLITK");
+        return e ? atoi(e) : -1;
+    }();
+    return m;
+}
+static SkPlan sk_plan(int ntiles, int cap, int nchunks, size_t scratch_bytes, int force) {
+    const SkPlan whole{ntiles, 0, 1, 0};
+    const int nq = nchunks / 4;
+    // PUNET_X6_SPLITK bits of opts: 0 = the library decides, 1 = never, n >= 2 = runs of n - 1 quads
+    const int mode = force == 1 ? 0 : (force >= 2 ? force - 1 : punet_splitk_mode());
+    const int full = ntiles / cap, T = ntiles - full * cap;
+    if (mode == 0 || T == 0 || nq < 2 || scratch_bytes <= SK_COUNTER_BYTES || T * sizeof(unsigned) > SK_COUNTER_BYTES) return whole;
+    const size_t max_slots = (scratch_bytes - SK_COUNTER_BYTES) / SK_SLOT_BYTES;
+    const int Q = T * nq;
+    int D = 0;
+    if (mode > 0) {
+        D = mode > nq ? nq : mode;
+    } else {
+        // Measured (profiles/r05/streamk_tail_probe.txt; unit = one chunk of one tile with the CU shared by two workgroups, ~4.3 us):
+        // a workgroup alone on its CU runs its chunks in ~0.45 of that (whole tail of T <= cap / 2 tiles) resp. ~0.6 (a run of the
+        // stream-K tail); a partial item costs ~3 for publishing its 64 KB + fence + ticket, the combine ~0.8 per part read.
+        const double t_whole = nchunks * (2 * T <= cap ? 0.45 : 0.9);
+        double best = 0.95 * t_whole;
+        const int cand[2] = {(Q + cap - 1) / cap, (2 * Q + cap - 1) / cap};  // every resident workgroup / one workgroup per CU
+        for (int i = 0; i < 2; ++i) {
+            const int d = cand[i];
+            if (d < 1 || d >= nq) continue;  // (a run of a whole tile or more: nothing to gain)
+            const int p = (Q + d - 1) / d;
+            const double t = 4.0 * d * (2 * p <= cap ? 0.6 : 1.0) + 3.0 + 0.8 * ((double)nq / d + 1.0);
+            if (t < best) { best = t; D = d; }
+        }
+        if (D == 0) return whole;
+    }
+    const int P = (Q + D - 1) / D;
+    if (P > cap || (size_t)2 * P > max_slots) return whole;
+    return SkPlan{full * cap, P, D, Q};
+}
+
+extern "C" size_t punet_conv_splitk_scratch_bytes(void) {  // enough for every plan sk_plan can make on this device
+    return SK_COUNTER_BYTES + (size_t)2 * WG_PER_CU * punet_num_cus() * SK_SLOT_BYTES;
+}
+
+extern "C" int punet_conv3x3_splitk(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride, int n_row,
+                                    int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
+                                    const void* gate_bits, void* gate_out, float* pool_out, int accumulate, int relu, int B, int H, int W,
+                                    int opts, int f16_planes, const float* amax_x0, const float* amax_x1, const float* amax_w,
+                                    float* amax_y, void* scratch, size_t scratch_bytes, void* stream) {
+    PUNET_CHECK_ARG(f16_planes >= 0 && f16_planes <= 2, "punet_conv3x3_splitk: f16_planes must be 0 (bf16 planes by `opts`), 1 or 2 (got %d)", f16_planes);
+    PUNET_CHECK_ARG(!scratch || ((size_t)scratch % 16 == 0 && scratch_bytes >= SK_COUNTER_BYTES),
+                    "punet_conv3x3_splitk: scratch must be 16-byte aligned and hold at least its %zu counter bytes", SK_COUNTER_BYTES);
+    F16Scales f;
+    f.planes = f16_planes; f.amax_x0 = amax_x0; f.amax_x1 = amax_x1; f.amax_w = amax_w; f.amax_out = amax_y;
+    return conv_x6_launch(3, x0, c0, x1, c1, wplanes, plane_stride, n_row, n_off, bias, bias_img_stride, y, n_out, mask, gate_bits,
+                          gate_out, accumulate, relu, B, H, W, f16_planes ? (opts & 0xff0000) : opts, stream, pool_out, f, scratch, scratch_bytes);
+}
 
 extern "C" int punet_conv3x3_x6_gated(const float* x0, int c0, const float* x1, int c1, const void* wplanes,
                                       long plane_stride, int n_row, int n_off, const float* bias, int bias_img_stride,
@@ -1826,7 +2006,7 @@ extern "C" int punet_conv3x3_f16s(const void* x0, int c0, const void* x1, int c1
 static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride,
                           int n_row, int n_off, const float* bias, int bias_img_stride, float* y, int n_out, const float* mask,
                           const void* gate_bits, void* gate_out, int accumulate, int relu, int B, int H, int W, int opts,
-                          void* stream, float* pool_out, const F16Scales& f16) {
+                          void* stream, float* pool_out, const F16Scales& f16, void* scratch, size_t scratch_bytes) {
     PUNET_CHECK_ARG(x0 && wplanes && y, "punet_conv3x3_x6: null pointer");
     PUNET_CHECK_ARG(f16.planes == 0 || ((f16.planes == 1 || f16.planes == 2) && ksize == 3),
                     "punet_conv3x3_f16: planes must be 2 (hh + hl + lh) or 1, 3x3 only");
@@ -1872,9 +2052,24 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
     hipStream_t st = (hipStream_t)stream;
     a.xcd_remap = grid % 8 == 0;  // same-process A/B: +0.5-0.8 % (the tensors of this workload fit the Infinity Cache)
     a.amax_x0 = f16.amax_x0; a.amax_x1 = f16.amax_x1; a.amax_w = f16.amax_w; a.amax_out = f16.amax_out;
+    // conv3x3_x6b_kernel deals work items: whole tiles, then runs of the last partial round's quads (sk_plan)
+    a.sk_whole = a.ntiles; a.sk_P = 0; a.sk_D = 1; a.sk_Q = 0; a.m_D = 0u; a.m_nq = 0u;
+    int gridb = grid;
+    if (ksize == 3 && scratch && (c0 + c1) % 32 == 0) {
+        const SkPlan pl = sk_plan(a.ntiles, cap, (c0 + c1) / CK, scratch_bytes, (opts >> 16) & 0xff);
+        if (pl.P > 0) {
+            a.sk_whole = pl.whole; a.sk_P = pl.P; a.sk_D = pl.D; a.sk_Q = pl.Q;
+            a.m_D = pl.D > 1 ? x6_magic(pl.D) : 0u; a.m_nq = x6_magic((c0 + c1) / 32);
+            a.sk_cnt = (unsigned*)scratch;
+            a.sk_ws = (float*)((char*)scratch + SK_COUNTER_BYTES);
+            gridb = pl.whole >= cap ? cap : (pl.whole > pl.P ? pl.whole : pl.P);
+        }
+    }
+    const int xrb = gridb % 8 == 0;
     if (f16.planes == 2) {  // "f16x3": the 16 x 16 x 32 kernel where the channel count allows, as for the bf16 planes
         if (shape == 16 && (c0 + c1) % 32 == 0) {
-            if (dgrad) conv3x3_x6b_kernel<2, true, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6b_kernel<2, false, true><<<grid, 256, 0, st>>>(a);
+            a.xcd_remap = xrb;
+            if (dgrad) conv3x3_x6b_kernel<2, true, true><<<gridb, 256, 0, st>>>(a); else conv3x3_x6b_kernel<2, false, true><<<gridb, 256, 0, st>>>(a);
         } else {
             if (dgrad) conv3x3_x6_kernel<2, true, 3, false, true><<<grid, 256, 0, st>>>(a);
             else conv3x3_x6_kernel<2, false, 3, false, true><<<grid, 256, 0, st>>>(a);
@@ -1898,10 +2093,11 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
     } else if (shape == 16 && (c0 + c1) % 32 == 0 && planes >= 2) {
         // 16 x 16 x 32 MFMAs: four {tap, 8 channels} blocks per instruction.  (Not for the one-plane fast mode: that one is
         // bound by its staging, not by the matrix cores, and measured 15 % slower through this kernel.)
+        a.xcd_remap = xrb;
         if (planes == 3) {
-            if (dgrad) conv3x3_x6b_kernel<3, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6b_kernel<3, false><<<grid, 256, 0, st>>>(a);
+            if (dgrad) conv3x3_x6b_kernel<3, true><<<gridb, 256, 0, st>>>(a); else conv3x3_x6b_kernel<3, false><<<gridb, 256, 0, st>>>(a);
         } else {
-            if (dgrad) conv3x3_x6b_kernel<2, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6b_kernel<2, false><<<grid, 256, 0, st>>>(a);
+            if (dgrad) conv3x3_x6b_kernel<2, true><<<gridb, 256, 0, st>>>(a); else conv3x3_x6b_kernel<2, false><<<gridb, 256, 0, st>>>(a);
         }
     } else if (planes == 3) {
         if (dgrad) conv3x3_x6_kernel<3, true><<<grid, 256, 0, st>>>(a); else conv3x3_x6_kernel<3, false><<<grid, 256, 0, st>>>(a);

@@ -215,7 +215,7 @@ struct Pass {  // one forward / backward walk
         RT_LAUNCH(punet_conv1x1_x6_gated(x->t, cup, nullptr, 0, u.p9, (long)cup * 9 * c.cout, 9 * c.cout, 0, nullptr, 0, z, 9 * c.cout, nullptr,
                                          nullptr, nullptr, 0, 0, B, h, wd, stream));
         Act* y = rt->new_act(ar->floats((size_t)B * 4 * h * wd * c.cout), B, 2 * h, 2 * wd, c.cout, true);
-        RT_LAUNCH(punet_conv3x3_x6_gated(bridge->t, cb, nullptr, 0, u.pb, (long)9 * cb * c.cout, c.cout, 0, b(c), 0, y->t, c.cout, nullptr,
+        RT_LAUNCH(c3_gated(bridge->t, cb, nullptr, 0, u.pb, (long)9 * cb * c.cout, c.cout, 0, b(c), 0, y->t, c.cout, nullptr,
                                          nullptr, nullptr, 0, 0, B, 2 * h, 2 * wd, X6_OPTS, stream));
         if (tape) y->bits = (unsigned*)ar->take(punet_gate_dwords(B, 2 * h, 2 * wd, c.cout) * 4);
         RT_LAUNCH(punet_upconv_gather_fwd(z, y->t, y->bits, 1, B, h, wd, c.cout, stream));
@@ -241,6 +241,41 @@ struct Pass {  // one forward / backward walk
                                          (x->relu_out && !use_bits) ? x->t : nullptr, use_bits ? x->bits : nullptr, nullptr, acc, 0, B, h, wd,
                                          stream));
         return PUNET_OK;
+    }
+
+    // Stream-K scratch of this pass's 3x3 launches (punet_conv3x3_splitk, conv_x6.hip: the tiles of a launch's last partial round
+    // are dealt as K-runs over the workgroups): carved from the arena, its arrival counters zeroed once per pass (every launch
+    // leaves them zero; the memset makes a pass independent of whatever an aborted one left behind).  The 3x3 entry points of the
+    // per-op ABI are called through their superset with this scratch - same arguments otherwise (engine.py does the same).
+    void* sk = nullptr;
+    size_t sk_bytes = 0;
+    int begin_splitk() {
+        sk_bytes = punet_conv_splitk_scratch_bytes();
+        sk = ar->take(sk_bytes);
+        if (!dry && hipMemsetAsync(sk, 0, 4096, (hipStream_t)stream) != hipSuccess) {
+            punet_set_error("punet_rt: memset of the stream-K counters failed");
+            return PUNET_ERR_HIP;
+        }
+        return PUNET_OK;
+    }
+    int c3_gated(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride, int n_row, int n_off,
+                 const float* bias, int bias_img_stride, float* y, int n_out, const float* mask, const void* gate_bits, void* gate_out,
+                 int accumulate, int relu, int B, int H, int W, int opts, void* st) {
+        return punet_conv3x3_splitk(x0, c0, x1, c1, wplanes, plane_stride, n_row, n_off, bias, bias_img_stride, y, n_out, mask, gate_bits,
+                                    gate_out, nullptr, accumulate, relu, B, H, W, opts, 0, nullptr, nullptr, nullptr, nullptr, sk, sk_bytes, st);
+    }
+    int c3_pooled(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride, int n_row, int n_off,
+                  const float* bias, int bias_img_stride, float* y, int n_out, void* gate_out, float* pool_out, int relu, int B, int H,
+                  int W, int opts, void* st) {
+        return punet_conv3x3_splitk(x0, c0, x1, c1, wplanes, plane_stride, n_row, n_off, bias, bias_img_stride, y, n_out, nullptr, nullptr,
+                                    gate_out, pool_out, 0, relu, B, H, W, opts, 0, nullptr, nullptr, nullptr, nullptr, sk, sk_bytes, st);
+    }
+    int c3_f16(const float* x0, int c0, const float* x1, int c1, const void* wplanes, long plane_stride, int n_row, int n_off,
+               const float* bias, int bias_img_stride, float* y, int n_out, const float* mask, const void* gate_bits, void* gate_out,
+               float* pool_out, int accumulate, int relu, int B, int H, int W, int planes, const float* amax_x0, const float* amax_x1,
+               const float* amax_w, float* amax_y, void* st) {
+        return punet_conv3x3_splitk(x0, c0, x1, c1, wplanes, plane_stride, n_row, n_off, bias, bias_img_stride, y, n_out, mask, gate_bits,
+                                    gate_out, pool_out, accumulate, relu, B, H, W, 0, planes, amax_x0, amax_x1, amax_w, amax_y, sk, sk_bytes, st);
     }
 
     int begin_slots(int n) {  // (fp16-operand arithmetics) a zeroed pool for this pass
@@ -310,7 +345,7 @@ struct Pass {  // one forward / backward walk
             }
             y->amax = slot();
             if (q) q->amax = y->amax;  // an average never exceeds the maximum
-            RT_LAUNCH(punet_conv3x3_f16(x0->t, x0->C, x1 ? x1->t : nullptr, x1 ? x1->C : 0, planes0 + 3 * c.w_off, c.w_numel(), c.cout, 0,
+            RT_LAUNCH(c3_f16(x0->t, x0->C, x1 ? x1->t : nullptr, x1 ? x1->C : 0, planes0 + 3 * c.w_off, c.w_numel(), c.cout, 0,
                                         b(c), 0, y->t, c.cout, nullptr, nullptr, y->bits, q ? q->t : nullptr, 0, relu ? 1 : 0, B, H, W, f16,
                                         x0->amax, x1 ? x1->amax : nullptr, wslot(c), y->amax, stream));
         } else {
@@ -319,10 +354,10 @@ struct Pass {  // one forward / backward walk
             if (pooled && H % 2 == 0 && W % 2 == 0) {
                 Act* q = rt->new_act(ar->floats((size_t)B * (H / 2) * (W / 2) * c.cout), B, H / 2, W / 2, c.cout, false);
                 *pooled = q;
-                RT_LAUNCH(punet_conv3x3_x6_pooled(x0->t, x0->C, x1 ? x1->t : nullptr, x1 ? x1->C : 0, wp, c.w_numel(), c.cout, 0, b(c), 0,
+                RT_LAUNCH(c3_pooled(x0->t, x0->C, x1 ? x1->t : nullptr, x1 ? x1->C : 0, wp, c.w_numel(), c.cout, 0, b(c), 0,
                                                 y->t, c.cout, y->bits, q->t, relu ? 1 : 0, B, H, W, X6_OPTS, stream));
             } else {
-                RT_LAUNCH(punet_conv3x3_x6_gated(x0->t, x0->C, x1 ? x1->t : nullptr, x1 ? x1->C : 0, wp, c.w_numel(), c.cout, 0, b(c), 0,
+                RT_LAUNCH(c3_gated(x0->t, x0->C, x1 ? x1->t : nullptr, x1 ? x1->C : 0, wp, c.w_numel(), c.cout, 0, b(c), 0,
                                                y->t, c.cout, nullptr, nullptr, y->bits, 0, relu ? 1 : 0, B, H, W, X6_OPTS, stream));
             }
         }
@@ -458,12 +493,12 @@ struct Pass {  // one forward / backward walk
                         const bool use_bits = src->bits && mask;
                         if (f16) {
                             if (!src->gamax) src->gamax = slot();  // (accumulating: the slot keeps max(previous, new total) - a bound)
-                            RT_LAUNCH(punet_conv3x3_f16(dz, c.cout, nullptr, 0, planes1 + 3 * c.w_off, c.w_numel(), c.cin, off, nullptr, 0, g,
+                            RT_LAUNCH(c3_f16(dz, c.cout, nullptr, 0, planes1 + 3 * c.w_off, c.w_numel(), c.cin, off, nullptr, 0, g,
                                                         src->C, use_bits ? nullptr : mask, use_bits ? src->bits : nullptr, nullptr, nullptr,
                                                         acc, 0, src->B, src->H, src->W, f16, op.y->gamax, nullptr, wslot(c), src->gamax,
                                                         stream));
                         } else {
-                            RT_LAUNCH(punet_conv3x3_x6_gated(dz, c.cout, nullptr, 0, planes1 + 3 * c.w_off, c.w_numel(), c.cin, off, nullptr, 0,
+                            RT_LAUNCH(c3_gated(dz, c.cout, nullptr, 0, planes1 + 3 * c.w_off, c.w_numel(), c.cin, off, nullptr, 0,
                                                            g, src->C, use_bits ? nullptr : mask, use_bits ? src->bits : nullptr, nullptr,
                                                            acc, 0, src->B, src->H, src->W, X6_OPTS, stream));
                         }
@@ -485,7 +520,7 @@ struct Pass {  // one forward / backward walk
                     float* g = grad_into(bridge, &acc);
                     const float* mask = bridge->relu_out ? bridge->t : nullptr;
                     const bool use_bits = bridge->bits && mask;
-                    RT_LAUNCH(punet_conv3x3_x6_gated(dz, c.cout, nullptr, 0, planes1 + 3 * c.w_off, c.w_numel(), c.cin, x->C, nullptr, 0, g,
+                    RT_LAUNCH(c3_gated(dz, c.cout, nullptr, 0, planes1 + 3 * c.w_off, c.w_numel(), c.cin, x->C, nullptr, 0, g,
                                                    bridge->C, use_bits ? nullptr : mask, use_bits ? bridge->bits : nullptr, nullptr, acc, 0,
                                                    bridge->B, bridge->H, bridge->W, X6_OPTS, stream));
                 }
@@ -726,6 +761,7 @@ static int pseudo_labels_body(PunetRt* rt, const float* flat, const float* x, in
     p.f16 = rt->f16_planes;
     const int n = rt->cfg.levels, CH = rt->cfg.num_filters[0], L = rt->cfg.latent_dim, nmid = rt->cfg.no_convs_fcomb - 2;
     RT_CALL(p.begin_slots(256));
+    RT_CALL(p.begin_splitk());
     p.ws_chan = ar.floats(punet_chan_sum_workspace_floats(B, H * W, rt->cfg.num_filters[n - 1]));
     Act* xin = rt->new_act(const_cast<float*>(x), B, H, W, rt->cfg.input_channels, false, false);
     float* zs = ar.floats((size_t)N * B * L);
@@ -781,6 +817,7 @@ static int elbo_body(PunetRt* rt, const float* flat, float* gflat, const float* 
     p.dry = dry;
     p.f16 = rt->f16_planes;
     RT_CALL(p.begin_slots(1024));
+    RT_CALL(p.begin_splitk());
     p.ws_chan = ar.floats(punet_chan_sum_workspace_floats(B, H * W, rt->cfg.num_filters[n - 1] > CH ? rt->cfg.num_filters[n - 1] : CH));
     p.ws_wgrad = ar.floats(max_wgrad_ws_floats(rt, B, H, W));
     // ---- forward: posterior on [patch, segm], prior, U-Net (tapes recorded)

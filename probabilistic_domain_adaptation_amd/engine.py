@@ -281,13 +281,35 @@ class PUNetEngine:
         # K5x (csrc/upconv.hip): the first conv of an up-block with its `up` source contracted at LOW resolution - the parity
         # arithmetic only ($PUNET_UPCONV=0: the layer as written, on the materialised up-sampled tensor; an A/B switch)
         self.upconv = self.conv_mode == "x6" and os.environ.get("PUNET_UPCONV", "1") != "0"
+        # stream-K tail of the persistent 3x3 kernels (round 5; $PUNET_SPLITK=0: every launch whole, an A/B switch)
+        self.splitk = os.environ.get("PUNET_SPLITK", "") != "0"
+        self._sk = None
         self._up = {}  # (flat.data_ptr(), conv name) -> dict(w9, wb fp32 re-layouts; p9, pb forward planes; p9d input-gradient planes)
         tab, self.l2_ntensors = layout.l2_chunk_table()
         self.l2_chunks = tab.to(self.device)
         self.l2_nchunks = tab.shape[0]
 
+    def _splitk_scratch(self):
+        """The stream-K scratch of this engine's 3x3 launches (punet_conv3x3_splitk): arrival counters (zero once, left zero by
+        every launch) + partial-accumulator slots; one buffer for the engine's life - launches are stream-ordered."""
+        if self._sk is None:
+            self._sk = torch.zeros(_lib.call("punet_conv_splitk_scratch_bytes") // 4, dtype=torch.int32, device=self.device)
+        return self._sk
+
     def _timed(self, kind, flops, name, *args):
-        """Launch through the C ABI; with self.prof set, bracket the launch with HIP events on the launch stream."""
+        """Launch through the C ABI; with self.prof set, bracket the launch with HIP events on the launch stream.
+        The 3x3 split-plane entry points are re-targeted at their superset punet_conv3x3_splitk with this engine's stream-K
+        scratch (tile quantization of the persistent grid; $PUNET_SPLITK=0 leaves the launches whole)."""
+        if self.splitk and name in ("punet_conv3x3_x6_gated", "punet_conv3x3_x6_pooled", "punet_conv3x3_f16"):
+            sk = self._splitk_scratch()
+            tail = (sk.data_ptr(), 4 * sk.numel(), args[-1])
+            if name == "punet_conv3x3_x6_gated":    # ..., y, n_out, mask, gate_bits, gate_out, accumulate, relu, B, H, W, opts, stream
+                a = args[:15] + (None,) + args[15:21] + (0, None, None, None, None)
+            elif name == "punet_conv3x3_x6_pooled":  # ..., y, n_out, gate_out, pool_out, relu, B, H, W, opts, stream
+                a = args[:12] + (None, None, args[12], args[13], 0) + args[14:19] + (0, None, None, None, None)
+            else:                                    # ..., pool_out, accumulate, relu, B, H, W, planes, amax x0 / x1 / w / y, stream
+                a = args[:21] + (0,) + args[21:26]
+            name, args = "punet_conv3x3_splitk", a + tail
         if self.prof is None or (self.prof_kinds is not None and kind not in self.prof_kinds):
             return _lib.call(name, *args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
