@@ -278,6 +278,70 @@ def timed_region(runner, steps, graph, sync, dp, dev):
     return dt, t_enq, [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(steps)]
 
 
+def conv_peak_tflops(eng):
+    """Matrix peak of the arithmetic the 3x3 kernels of `eng` compute in: n MFMAs per product on the bf16 / fp16 dense peak."""
+    if not eng.x6:
+        return FP32_MFMA_PEAK_TFLOPS, 1
+    n = {"x6": 6, "x3": 3, "bf16": 1, "bf16s": 1, "f16x3": 3, "f16": 1, "f16s": 1}[eng.conv_mode]
+    return BF16_MFMA_PEAK_TFLOPS / n, n
+
+
+def instrumented_roofline(runner, steps, sync):
+    """`steps` eagerly launched steps of `runner` with HIP events around every launch of the 3x3 forward convolution (the dominant
+    kernel of every workload here): {bound, achieved, peak, unit, frac, ...} of that kernel, as the headline's `roofline`."""
+    prof = []
+    for e in runner.engines:
+        e.prof, e.prof_kinds = prof, {"conv3x3_fwd"}
+    try:
+        runner.step(False)  # first use of the events
+        sync()
+        prof.clear()
+        for _ in range(steps):
+            runner.step(False)
+        sync()
+    finally:
+        for e in runner.engines:
+            e.prof = None
+    fl = sum(p[1] for p in prof)
+    sec = sum(p[2].elapsed_time(p[3]) for p in prof) * 1e-3
+    if not prof or sec <= 0:
+        return None
+    peak, n = conv_peak_tflops(runner.model.engine)
+    ach = fl / sec / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "kernel": "3x3 forward convolution (conv3x3_x6b_kernel)", "launches_per_step": len(prof) // steps,
+            "avg_launch_ms": round(1e3 * sec / len(prof), 4), "flops_per_launch_avg": fl / len(prof),
+            "timing": f"HIP events on the launch stream around every launch, {steps} eagerly launched steps after the timed ones"}
+
+
+# BASELINE.json configs[4] asks for an HBM-bound roofline report; in this design the MC inference pass is bound by the matrix
+# cores (one U-Net + prior encoder pass of 3x3 convolutions per tile; the N samples only re-run the 1x1 Fcomb head on resident
+# features).  Algorithmic minimum traffic, SURVEY.md 8d: the weights once (78.1 MB of the 109.4 MB flat buffer: prior encoder +
+# U-Net + Fcomb) + 4 B/px in + 5 B/px out (mean fp32 + mask u8).
+def inference_hbm_report(H, W, ms_per_step):
+    algo = 78.1e6 + 9.0 * H * W
+    out = {"bound_asked_for": "hbm (BASELINE.json configs[4])", "bound_in_this_design": "mfma",
+           "why": "one tile = 1.38 TFLOP of 3x3 convolutions over 78 MB of weights + 9 B/px of image data: arithmetic intensity "
+                  f"{1382.8e9 * (H * W) / (1024 * 1024) / algo / 1e3:.1f} kFLOP/B against a ridge of 416.7 TFLOP/s / 8 TB/s = 52 FLOP/B - the pass "
+                  "cannot be HBM-bound unless activations spill: they do (every layer's output makes one round trip), and still are not the bound",
+           "algorithmic_min_bytes": int(algo), "hbm_peak_GBps": 8000.0,
+           "time_at_hbm_peak_for_algorithmic_bytes_ms": round(algo / 8e12 * 1e3, 4),
+           "frac_of_hbm_roofline_on_algorithmic_bytes": round(algo / 8e12 * 1e3 / ms_per_step, 5)}
+    try:  # counted bytes of one inference step (all kernels), from the PMC passes under profiles/ (tools/collect_profiles.sh)
+        rdir = next(r for r in ("r05", "r04") if os.path.exists(os.path.join(ROOT, "profiles", r, "pmc_hbm_traffic_inference_1024.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", rdir, "pmc_hbm_traffic_inference_1024.json")))
+        if (H, W) == (1024, 1024):
+            cb = pm["hbm_bytes_per_step"]
+            out.update({"counted_hbm_bytes_per_step": int(cb), "counted_GBps_at_this_rate": round(cb / (ms_per_step * 1e-3) / 1e9, 1),
+                        "counted_frac_of_hbm_peak": round(cb / (ms_per_step * 1e-3) / 8e12, 4),
+                        "counted_note": f"NOT measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes over "
+                                        f"this workload, summed over every kernel of a step, profiles/{rdir}/pmc_hbm_traffic_inference_1024.json "
+                                        f"(collected at commit {pm.get('git_head', 'unknown')})"})
+    except Exception:
+        pass
+    return out
+
+
 def gflop_per_patch(workload, N, H, W, channels):
     exact = (H, W, channels) == (704, 704, 3)
     gf = (GFLOP_704x3 if exact else GFLOP)[workload]
@@ -597,6 +661,10 @@ def main():
                                       else "Python engine (engine.py): one library call per kernel"),
                        "algorithmic_gflop_per_patch": gf,
                        "model_tflops_per_gpu": round(gf * patches / dt / world / 1e3, 2),
+                       "model_tflops_note": "algorithmic FLOPs of the layers AS WRITTEN in the reference / time; with K5x the up-blocks' `up` "
+                                            "halves execute a quarter of their written multiply-adds (config.up_blocks): at the headline shape that is "
+                                            "3/4 x 463.9 GFLOP per U-Net forward, input-gradient and weight-gradient pass of a batch = 1.39 of the "
+                                            "12.93 TFLOP a step is counted with, i.e. the EXECUTED matrix rate is ~10.8 % below this figure",
                        "host_enqueue_ms_per_step": round(1e3 * t_enq / a.steps, 2),
                        "ms_each_step": ms_each},
         }
@@ -736,10 +804,18 @@ def main():
                         "inference": f"one {size}x{size}x{ch} tile per step, N={n2} MC samples, mean + consensus mask "
                                      f"(punet_predictions.py:29-33 / :114-124)"}[wl]
                 unit = {"punet_source": "patches_per_s", "inference": "tiles_per_s"}.get(wl, "pairs_per_s")
-                others.append({"workload": f"{wl} (BASELINE.json configs[{idx}], per GPU): {what}",
-                               "ms_per_step": round(1e3 * d2 / 5, 3), unit: round(b2 * 5 / d2, 3),
-                               "model_tflops": round(g2 * b2 * 5 / d2 / 1e3, 2), "host_enqueue_ms_per_step": round(1e3 * e2 / 5, 2),
-                               "ms_each_step": each2})
+                entry = {"workload": f"{wl} (BASELINE.json configs[{idx}], per GPU): {what}",
+                         "ms_per_step": round(1e3 * d2 / 5, 3), unit: round(b2 * 5 / d2, 3),
+                         "model_tflops": round(g2 * b2 * 5 / d2 / 1e3, 2), "host_enqueue_ms_per_step": round(1e3 * e2 / 5, 2),
+                         "ms_each_step": each2}
+                if not a.no_kernel_timing:  # the same roofline object as the headline's, for this config's dominant kernel
+                    try:
+                        entry["roofline"] = instrumented_roofline(r2, 2, sync)
+                    except Exception as ex:
+                        entry["roofline"] = {"error": f"{type(ex).__name__}: {ex}"}
+                if wl == "inference":
+                    entry["hbm_report"] = inference_hbm_report(size, size, 1e3 * d2 / 5)
+                others.append(entry)
                 del r2
                 torch.cuda.empty_cache()
             try:  # configs[0]: the plain Unet forward on one 256x256x1 patch - the reference's CPU-runnable case, here on the GPU
@@ -761,12 +837,18 @@ def main():
                     r3.step(g3ok)
                 d3, e3, each3 = timed_region(r3, 5, g3ok, sync, dp, dev)
                 tf3 = gf * B * 5 / d3 / 1e3
+                roof3 = None
+                if not a.no_kernel_timing:
+                    try:
+                        roof3 = instrumented_roofline(r3, 2, sync)
+                    except Exception as ex:
+                        roof3 = {"error": f"{type(ex).__name__}: {ex}"}
                 out["config"]["fast_mode_f16x3"] = {
                     "workload": "the headline Mean-Teacher step in the f16x3 arithmetic (two fp16 planes per operand, per-tensor power-of-two "
                                 "scaling, 3 MFMAs per product; what mixed_precision=True selects) - REDUCED PRECISION, not the headline",
                     "ms_per_step": round(1e3 * d3 / 5, 3), "patches_per_s": round(B * 5 / d3, 3), "model_tflops": round(tf3, 2),
                     "frac_of_its_peak": round(tf3 / (BF16_MFMA_PEAK_TFLOPS / 3), 4), "peak": round(BF16_MFMA_PEAK_TFLOPS / 3, 1),
-                    "ms_each_step": each3}
+                    "ms_each_step": each3, "roofline": roof3}
                 del r3
                 torch.cuda.empty_cache()
             except Exception as ex:  # never lose the headline to an extra

@@ -66,6 +66,10 @@ if os.path.exists(stamp):
     env.update(PUNET_GIT_HEAD=head, PUNET_SOURCES_SHA16=sha)
 subprocess.check_call([sys.executable, os.path.join(here, "pmc_traffic.py"), one("pmc_fetch/*/*_counter_collection.csv"),
                        one("pmc_write/*/*_counter_collection.csv"), os.path.join(dst, "pmc_hbm_traffic_x6.json")], env=env)
+fi, wi = glob.glob(os.path.join(src, "pmc_fetch_inf/*/*_counter_collection.csv")), glob.glob(os.path.join(src, "pmc_write_inf/*/*_counter_collection.csv"))
+if fi and wi:  # configs[4]: total HBM bytes of one inference step (marker: the MC sampler runs once per step)
+    subprocess.check_call([sys.executable, os.path.join(here, "pmc_traffic_total.py"), fi[0], wi[0], "fcomb_sampler",
+                           os.path.join(dst, "pmc_hbm_traffic_inference_1024.json")], env=env)
 # the f16x3 fast mode: kernel stats + matrix-pipe utilisation of the same step
 for pat, name in (("stats_f16x3/*/*_kernel_stats.csv", "f16x3_kernel_stats.csv"),):
     f = glob.glob(os.path.join(src, pat))
