@@ -258,6 +258,97 @@ class Runner:
         self.it += 1
 
 
+class SynthRawLoader:
+    """A loader of RAW (un-normalised, un-augmented) synthetic patches with labels, resident in pinned HOST memory as a disk-backed
+    torch DataLoader would deliver them (the reference's loaders: LIVECell/livecell_mt.py:94-101): every batch crosses PCIe inside
+    the loop, the views are built on the GPU (my_utils/augment.py::DualViewLoader, K13)."""
+
+    def __init__(self, n_batches, B, H, W, C, seed):
+        base = [synth(B, H, W, seed + 17 * i, "cpu", C) for i in range(min(n_batches, 8))]  # 8 distinct batches, cycled
+        self.raw = [(40.0 + 25.0 * b[0]).clamp(0, 255).pin_memory() for b in base]  # camera-like intensities (standardised per sample later)
+        self.y = [b[3].pin_memory() for b in base]
+        self.n = n_batches
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for i in range(self.n):
+            yield self.raw[i % len(self.raw)], self.y[i % len(self.y)]
+
+
+def fit_workload(a, dev, iterations, bare_ms_per_step=None, conv_mode=None):
+    """What a user of the reference calls (LIVECell/livecell_mt.py:94-113): MeanTeacherTrainer.fit() with FusedAdam, graph=True and a
+    DualViewLoader over raw patches (both views built by K13 on the GPU), two epochs of `iterations / 2` iterations, each followed
+    by one validation pass and rank 0's checkpoints - against the bare step of the headline.  Returns the timings."""
+    import shutil
+    import tempfile
+    from probabilistic_domain_adaptation_amd.my_models import ProbabilisticUnet
+    from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam, MeanTeacherTrainer
+    from probabilistic_domain_adaptation_amd.my_utils.augment import DualViewLoader, my_strong_augmentations, my_weak_augmentations
+    B, H, W, N, C = a.batch, a.size, a.size, a.samples, a.channels
+    per_epoch = max(iterations // 2, 1)
+    model = ProbabilisticUnet(C, 1, NF, 6, 3, 1.0, consensus_masking=True, rl_swap=False, device=dev, seed=1, conv_mode=conv_mode)
+    train = DualViewLoader(SynthRawLoader(per_epoch, B, H, W, C, 900), my_weak_augmentations(seed=1), my_strong_augmentations(seed=2), dev)
+    val = DualViewLoader(SynthRawLoader(4, B, H, W, C, 1900), my_weak_augmentations(seed=3), my_strong_augmentations(seed=4), dev)
+    root = tempfile.mkdtemp(prefix="punet_fit_")
+    try:
+        tr = MeanTeacherTrainer(name="bench-fit", save_root=root, train_loader=train, val_loader=None, model=model,
+                                optimizer=FusedAdam(model, lr=1e-5), device=dev, do_consensus_masking=True, graph=True)
+        tr.n_samples = N
+        tr.fit(iterations=3)  # capture + first-use costs, not part of the measurement
+        torch.cuda.synchronize()
+        tr.val_loader = val
+        times = {"train": 0.0, "val": 0.0, "ckpt": 0.0}
+        inner_train, inner_val, inner_ckpt = tr._train_epoch_impl, tr._validate_impl, tr.save_checkpoint
+
+        def timed(key, fn):
+            def w(*args, **kw):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r = fn(*args, **kw)
+                torch.cuda.synchronize()
+                times[key] += time.perf_counter() - t0
+                return r
+            return w
+
+        host = [0.0, 0]
+        tr._train_epoch_impl, tr._validate_impl, tr.save_checkpoint = timed("train", inner_train), timed("val", inner_val), timed("ckpt", inner_ckpt)
+        it0 = tr._iteration
+        t0 = time.perf_counter()
+        tr.fit(iterations=2 * per_epoch)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        done = tr._iteration - it0
+        # host time per iteration: the same loop once more without waiting for the GPU at its end (enqueue time only)
+        tr._train_epoch_impl = inner_train
+        tr.val_loader = None
+        tr.save_root, tr.name = None, None
+        tr.max_iteration = tr._iteration + min(per_epoch, 50)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        inner_train(type("P", (), {"update": lambda self, n: None})(), __import__("contextlib").nullcontext, None)
+        t_enq = time.perf_counter() - t1
+        n_enq = min(per_epoch, 50)
+        torch.cuda.synchronize()
+        ms_iter = 1e3 * times["train"] / done
+        out = {"workload": f"MeanTeacherTrainer.fit(): {done} iterations in 2 epochs (FusedAdam, graph=True, DualViewLoader over raw "
+                           f"{H}x{W}x{C} patches in pinned host memory, batch {B}, N={N}; weak / strong views built on the GPU by K13), each epoch "
+                           f"followed by a validation pass over 4 batches and rank 0's best / latest checkpoints",
+               "iterations": done, "train_loop_ms_per_iteration": round(ms_iter, 3),
+               "train_loop_patches_per_s": round(1e3 * B / ms_iter, 3),
+               "host_ms_per_iteration": round(1e3 * t_enq / n_enq, 3),
+               "validation_s_per_epoch": round(times["val"] / 2, 3), "checkpoints_s_per_epoch": round(times["ckpt"] / 2, 3),
+               "fit_wall_s": round(wall, 3), "whole_fit_patches_per_s": round(B * done / wall, 3),
+               "final_loss": float(tr.last_loss) if tr.last_loss is not None else None}
+        if bare_ms_per_step:
+            out["bare_step_ms"] = round(bare_ms_per_step, 3)
+            out["train_loop_rate_over_bare_step_rate"] = round(bare_ms_per_step / ms_iter, 4)
+        return out
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def timed_region(runner, steps, graph, sync, dp, dev):
     """EXACTLY `steps` steps between two barriers + synchronisations; returns (seconds, max over ranks; host enqueue
     seconds; per-step GPU milliseconds)."""
@@ -454,7 +545,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="mean_teacher", choices=["mean_teacher", "punet_source", "inference", "fixmatch", "adamt", "adamatch"])
+    ap.add_argument("--workload", default="mean_teacher", choices=["mean_teacher", "punet_source", "inference", "fixmatch", "adamt", "adamatch", "fit"],
+                    help="fit = MeanTeacherTrainer.fit() with a DualViewLoader and graph=True for --fit-iterations iterations next to the bare "
+                         "mean_teacher step (the line's value stays the bare step; config.fit_loop holds the loop's rate and the ratio)")
+    ap.add_argument("--fit-iterations", type=int, default=200)
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--size", type=int, default=512)
@@ -545,6 +639,9 @@ def main():
             torch.cuda.synchronize()
 
     B, H, W, N = a.batch, a.size, a.size, a.samples
+    fit_iterations = a.fit_iterations if a.workload == "fit" else (60 if not a.no_other_configs else 0)
+    if a.workload == "fit":
+        a.workload = "mean_teacher"
     use_graph = not a.no_graph
     run = Runner(a.workload, a, dev, rank, B, H, W, N, a.channels, a.conv_mode)
     eng = run.model.engine
@@ -853,6 +950,16 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as ex:  # never lose the headline to an extra
                 out["config"]["fast_mode_f16x3"] = {"error": f"{type(ex).__name__}: {ex}"}
+        if fit_iterations and not dp and a.workload == "mean_teacher" and not a.dice:
+            try:  # the API users call, against the bare step above
+                try:
+                    del run
+                except NameError:
+                    pass
+                torch.cuda.empty_cache()
+                out["config"]["fit_loop"] = fit_workload(a, dev, fit_iterations, 1e3 * dt / a.steps, a.conv_mode)
+            except Exception as ex:  # never lose the headline to an extra
+                out["config"]["fit_loop"] = {"error": f"{type(ex).__name__}: {ex}"}
         if not a.no_cpu_baseline and not dp and not a.dice:
             out["cpu_baseline"] = cpu_baseline(a.workload, N, H, W)
         sys.stdout.flush()

@@ -160,14 +160,43 @@ def to_torch(params_np, requires_grad: bool = False) -> Params:
 # forward, so that a pre-activation within fp32 rounding of 0 (which may legitimately resolve to either side) does not
 # turn into an O(1) difference of individual gradients.  Default None = the reference's plain ReLU.
 RELU_GATES = None
+# Filled whenever RELU_GATES is in force: per layer, how many of the imposed gates differ from the oracle's
+# OWN ReLU decision (y > 0), and how far from zero the oracle's pre-activation is where they do - a handful of entries within
+# rounding of zero is what the substitution is for; a systematic gate error of the GPU forward would show up here as a count.
+RELU_GATE_REPORT: dict = {}
 
 
 def _conv_relu(P: Params, name: str, x: torch.Tensor, relu: bool = True) -> torch.Tensor:
     w = P[name + ".weight"]
     y = F.conv2d(x, w, P[name + ".bias"], stride=1, padding=w.shape[-1] // 2)
     if relu and RELU_GATES is not None and name in RELU_GATES:
-        return y * RELU_GATES[name].to(y.dtype)
+        g = RELU_GATES[name]
+        with torch.no_grad():
+            diff = (y > 0) != (g > 0)
+            n = int(diff.sum())
+            RELU_GATE_REPORT[name] = (n, float(y[diff].abs().max()) if n else 0.0, float(y.abs().max()), y.numel())
+        return y * g.to(y.dtype)
     return F.relu(y) if relu else y
+
+
+def relu_gate_report(max_fraction: float = 3e-4, max_rel_preact: float = 1e-4, clear: bool = True) -> str:
+    """Summary of RELU_GATE_REPORT; raises AssertionError when any layer has more than `max_fraction` of its gates differing
+    from the oracle's own ReLU, or a differing gate whose oracle pre-activation exceeds `max_rel_preact` of the layer's largest
+    one (i.e. a gate that rounding cannot explain).  Tests print the returned line."""
+    tot = sum(v[0] for v in RELU_GATE_REPORT.values())
+    nel = sum(v[3] for v in RELU_GATE_REPORT.values())
+    worst_rel, worst_frac, bad = 0.0, 0.0, []
+    for k, (n, pre, ymax, numel) in RELU_GATE_REPORT.items():
+        rel = pre / (ymax + 1e-30)
+        worst_rel, worst_frac = max(worst_rel, rel), max(worst_frac, n / max(numel, 1))
+        if n > max(1, max_fraction * numel) or rel > max_rel_preact:
+            bad.append(f"{k}: {n} of {numel} gates differ, |pre-activation| up to {pre:.3e} (layer max {ymax:.3e})")
+    line = (f"ReLU gates imposed on the oracle: {tot} of {nel} differ from its own ReLU over {len(RELU_GATE_REPORT)} layers "
+            f"(worst layer fraction {worst_frac:.2e}; largest |pre-activation| at a differing gate {worst_rel:.2e} of its layer's maximum)")
+    if clear:
+        RELU_GATE_REPORT.clear()
+    assert not bad, "gate differences that rounding does not explain:\n  " + "\n  ".join(bad)
+    return line
 
 
 def _pool(x):

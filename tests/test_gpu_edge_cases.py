@@ -164,7 +164,7 @@ def _random_constructor_cases(count, seed=31):
     return out
 
 
-_FUZZ = [int(v) for v in os.environ.get("PUNET_FUZZ", "12:31").split(":")]  # count:seed (more draws: PUNET_FUZZ=60:7 pytest -k random)
+_FUZZ = [int(v) for v in os.environ.get("PUNET_FUZZ", "36:31").split(":")]  # count:seed (more draws: PUNET_FUZZ=60:7 pytest -k random)
 
 
 @pytest.mark.parametrize("nf,H,W,latent,nfc,C,mode", _random_constructor_cases(*_FUZZ))
@@ -209,6 +209,7 @@ def _constructor_case(nf, H, W, latent, nfc, C, conv_mode, fuse_pool=True):
         go = O.grads_of(lo, P)
     finally:
         O.RELU_GATES = None
+    print(O.relu_gate_report())  # how many imposed gates differ from the oracle's own ReLU (bounded)
     assert (st["logits"].cpu() - aux["reconstruction"].detach()).abs().max().item() < 1e-3
     np.testing.assert_allclose([st["rec"].item(), st["kl"].item()], [aux["reconstruction_loss"].item(), aux["kl"].item()], rtol=2e-4)
     gv = lay.views(g)

@@ -116,6 +116,7 @@ def test_training_step_fullsize_against_oracle(dev, B, channels, size):
         go = O.grads_of(lo, P)
     finally:
         O.RELU_GATES = None
+    print(O.relu_gate_report())  # how many imposed gates differ from the oracle's own ReLU (bounded)
     # forward: block outputs (under the GPU's gates the oracle's activations must still agree, else the gates were wrong)
     for k, v in otaps.items():
         got = taps[k].t.permute(0, 3, 1, 2).cpu()
@@ -391,6 +392,7 @@ def test_default_filters_training_step_against_oracle(dev):
         go = O.grads_of(lo, P)
     finally:
         O.RELU_GATES = None
+    print(O.relu_gate_report())  # how many imposed gates differ from the oracle's own ReLU (bounded)
     np.testing.assert_allclose([st["rec"].item(), st["kl"].item()], [aux["reconstruction_loss"].item(), aux["kl"].item()], rtol=2e-4)
     gv = lay.views(gflat)
     worst = 0.0

@@ -127,6 +127,7 @@ def test_training_path(golden_dir, dev, name, mode):
         go = O.grads_of(lo, P)
     finally:
         O.RELU_GATES = None
+    print(O.relu_gate_report())  # how many imposed gates differ from the oracle's own ReLU (bounded)
     gv = lay.views(g)
     bad = {}
     for k, ref in go.items():

@@ -49,7 +49,7 @@ def _random_configs(count, seed=2024):
                          [pytest.param([32, 64, 64, 96], 1, 3, 6, 2, 32, 64, "x6", "bce", id="nf4"),
                           pytest.param([64, 40, 72], 3, 2, 2, 1, 24, 40, "x6", "bce", id="depth3_rgb_fcomb2_latent2"),
                           pytest.param([32, 32, 64, 64, 96], 2, 3, 6, 2, 48, 80, "x6", "bce", id="depth5_two_channels")]
-                         + _random_configs(*[int(v) for v in os.environ.get("PUNET_FUZZ_RT", "10:2024").split(":")]))
+                         + _random_configs(*[int(v) for v in os.environ.get("PUNET_FUZZ_RT", "24:2024").split(":")]))
 def test_native_runtime_equals_python_engine_bit_for_bit(dev, nf, C, nfc, latent, B, H, W, mode, crit):
     from probabilistic_domain_adaptation_amd.runtime import NativeRuntime
     m = _model(dev, nf, C, nfc, latent, rl_swap=crit == "dice")

@@ -25,7 +25,7 @@ def _random_cases(count, seed):
              8 * r.randint(1, 24)) for _ in range(count)]
 
 
-CASES += _random_cases(*[int(v) for v in os.environ.get("PUNET_FUZZ_X6", "8:5").split(":")])
+CASES += _random_cases(*[int(v) for v in os.environ.get("PUNET_FUZZ_X6", "24:5").split(":")])
 
 
 @pytest.fixture(scope="module")

@@ -16,7 +16,7 @@ CASES = [(1, 8, 32, 8, 32), (2, 16, 16, 64, 64), (1, 24, 40, 32, 96), (2, 8, 8, 
          (3, 96, 160, 96, 160), (4, 128, 128, 192, 64)]
 _r = random.Random(9)  # seeded draws: any image size from one pixel up, channel counts multiples of 8 (PUNET_FUZZ_X6=count widens)
 CASES += [(_r.randint(1, 3), _r.randint(1, 50), _r.randint(1, 70), 8 * _r.randint(1, 20), 8 * _r.randint(1, 24))
-          for _ in range(int(os.environ.get("PUNET_FUZZ_X6", "8:5").split(":")[0]))]
+          for _ in range(int(os.environ.get("PUNET_FUZZ_X6", "24:5").split(":")[0]))]
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", CASES)
