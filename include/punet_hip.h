@@ -187,6 +187,10 @@ int punet_upsample2x_bwd_gated(const float* dy, const float* xmask, const void* 
  *      punet_upconv_gather_bwd: the adjoint, dzt[b][j][t][c] = sum_q up_weight(q, j) dz[b][q - t + 1][c] with dz [B][2h][2w][cout],
  *        dzt [B][h][w][9][cout] (gather form, deterministic); the input gradient w.r.t. x is then ONE 1x1 input gradient of dzt
  *        with w9.  Interpolation weights are K5's. */
+/* where K5x applies (one rule for every graph walker) and the `up`-channel count below which a forward pass with a backward
+ * behind it keeps the layer as written */
+int punet_upconv_eligible(int cup, int cb, int cout, int ksize);
+int punet_upconv_min_cup_grad(void);
 int punet_upconv_relayout(const float* w, int cup, int cb, int cout, float* w9, float* wb, void* stream);
 int punet_upconv_gather_fwd(const float* z, float* y, void* gate_out, int relu, int B, int h, int w, int cout, void* stream);
 int punet_upconv_gather_bwd(const float* dz, float* dzt, int B, int h, int w, int cout, void* stream);

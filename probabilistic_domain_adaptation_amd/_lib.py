@@ -28,6 +28,8 @@ _SIGS = {
     "punet_split_weights_x6_batch": (_i, [_p, _p, _p, _i, _l, _i, _p]),
     "punet_conv3x3_x6": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "punet_gate_dwords": (_sz, [_i, _i, _i, _i]),
+    "punet_upconv_eligible": (_i, [_i, _i, _i, _i]),
+    "punet_upconv_min_cup_grad": (_i, []),
     "punet_conv_splitk_scratch_bytes": (_sz, []),
     "punet_conv3x3_splitk": (_i, [_p, _i, _p, _i, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p,
                                   _p, _sz, _p]),
@@ -154,7 +156,7 @@ _SIGS.update({
 })
 
 _NO_WRAP = {"punet_rt_destroy", "punet_rt_param_floats", "punet_rt_unet_floats", "punet_rt_num_entries", "punet_rt_tables_bytes",
-            "punet_rt_arena_bytes", "punet_rt_last_arena_used", "punet_conv_splitk_scratch_bytes", "punet_last_error", "punet_build_info", "punet_device_ok", "punet_compute_units", "punet_wgrad_workspace_floats", "punet_gate_dwords",
+            "punet_rt_arena_bytes", "punet_rt_last_arena_used", "punet_conv_splitk_scratch_bytes", "punet_upconv_eligible", "punet_upconv_min_cup_grad", "punet_last_error", "punet_build_info", "punet_device_ok", "punet_compute_units", "punet_wgrad_workspace_floats", "punet_gate_dwords",
             "punet_wgrad_slices", "punet_wgrad_x6_slices", "punet_upconv_wgrad_slices", "punet_upconv_wgrad_workspace_floats", "punet_small_wgrad_workspace_floats", "punet_chan_sum_workspace_floats",
             "punet_dot_bwd_workspace_floats", "punet_loss_workspace_floats", "punet_fcomb_train_supported",
             "punet_fcomb_train_workspace_floats", "punet_standardize_workspace_doubles"}

@@ -2077,7 +2077,8 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
     } else if (f16.planes == 1) {  // "f16": one fp16 product
         if (dgrad) conv3x3_x6_kernel<1, true, 3, false, true><<<grid, 256, 0, st>>>(a);
         else conv3x3_x6_kernel<1, false, 3, false, true><<<grid, 256, 0, st>>>(a);
-    } else if (ksize == 1 && c1 == 0 && c0 % 32 == 0 && punet_conv1x1_wide()) {  // wide contractions (K5x's GEMMs)
+    } else if (ksize == 1 && c1 == 0 && c0 % 32 == 0 && punet_conv1x1_wide()) {  // K5x's GEMMs AND the Fcomb layers whose contraction is a
+        // multiple of 32 (K = 32 / 64, windows n_off > 0, per-image bias: tests/test_gpu_x6.py::test_conv1x1_x6_*)
 #ifdef X6W_TRACE
         if (const char* tp = getenv("PUNET_X6W_TRACE_PTR")) a.pool_out = reinterpret_cast<float*>(strtoull(tp, nullptr, 0));
 #endif

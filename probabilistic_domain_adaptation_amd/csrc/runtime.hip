@@ -169,10 +169,9 @@ struct Pass {  // one forward / backward walk
         __bf16 *p9 = nullptr, *pb = nullptr, *p9d = nullptr;
     };
     std::vector<UpW> upw;
-    static constexpr int UPCONV_MIN_CUP_GRAD = 128;  // (engine.py: PUNetEngine.UPCONV_MIN_CUP_GRAD)
-    bool up_eligible(const Conv& c, int cup) const {  // the same rule as engine.py's _upconv_ok: the two walkers agree bit for bit
-        const int cb = c.cin - cup;
-        return rt->upconv && !f16 && c.k == 3 && cup % 8 == 0 && cb % 8 == 0 && cup > SMALL_CIN && cb > SMALL_CIN && c.cout % 64 == 0;
+    const int UPCONV_MIN_CUP_GRAD = punet_upconv_min_cup_grad();
+    bool up_eligible(const Conv& c, int cup) const {  // the library's rule, as engine.py's _upconv_ok: the two walkers agree bit for bit
+        return rt->upconv && !f16 && punet_upconv_eligible(cup, c.cin - cup, c.cout, c.k);
     }
     int up_index(int ci) const {  // up-block of conv ci (its entry conv), -1 otherwise
         for (size_t j = 0; j < rt->unet_up.size(); ++j)

@@ -441,6 +441,17 @@ int shift_of(int c4) {  // log2 when a power of two, else -1
 
 }  // namespace
 
+// ONE statement of where the low-resolution form applies, used by both graph walkers (engine.py::_upconv_ok / _split_up and
+// runtime.hip::up_eligible - ADVICE r4: the rule used to be written out three times): the 3x3 entry convolution of an up-block with
+// `cup` up-sampled and `cb` bridge channels, both past the first-layer kernels' range (> 7) and multiples of 8, and whole 64-channel
+// output blocks (the gather publishes gate bits per 64-channel block).  punet_upconv_min_cup_grad(): below this many `up` channels a
+// forward pass that a backward follows keeps the layer as written (the gather's cost is per OUTPUT channel, the matrix work it saves
+// per `up` channel: at 128 the form still wins by ~0.1 ms per launch at 512 x 512, below that it is unmeasured).
+extern "C" int punet_upconv_eligible(int cup, int cb, int cout, int ksize) {
+    return ksize == 3 && cup > 7 && cb > 7 && cup % 8 == 0 && cb % 8 == 0 && cout > 0 && cout % 64 == 0;
+}
+extern "C" int punet_upconv_min_cup_grad(void) { return 128; }
+
 extern "C" int punet_upconv_relayout(const float* w, int cup, int cb, int cout, float* w9, float* wb, void* stream) {
     PUNET_CHECK_ARG(w && w9 && wb && cup > 0 && cb > 0 && cout > 0 && cout % 4 == 0, "punet_upconv_relayout: bad args (cup=%d cb=%d cout=%d)",
                     cup, cb, cout);

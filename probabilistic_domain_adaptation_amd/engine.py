@@ -468,14 +468,24 @@ class PUNetEngine:
         return y
 
     # ---------------------------------------------------------------- K5x: up-block entry conv at low resolution
-    UPCONV_MIN_CUP_GRAD = 128  # forward passes a backward follows keep the layer as written below this many `up` channels (untested
-    # territory: the gather's cost is per output channel, the saved matrix work per `up` channel; at 128 the form still wins by ~0.1 ms
-    # per launch at 512 x 512 - tools/pushdown_probe.py; it was 256 while the weight gradient still needed the up-sampled tensor)
+    @property
+    def UPCONV_MIN_CUP_GRAD(self) -> int:
+        """Forward passes a backward follows keep the layer as written below this many `up` channels (the library's figure, shared
+        with csrc/runtime.hip)."""
+        return _lib.call("punet_upconv_min_cup_grad")
 
     def _upconv_ok(self, c: ConvP, x: Act, bridge: Act) -> bool:
-        """Shapes the low-resolution form serves (same rule as csrc/runtime.hip: the two graph walkers agree bit for bit)."""
-        return (self.upconv and c.k == 3 and x.C % 8 == 0 and bridge.C % 8 == 0 and x.C > SMALL_CIN and bridge.C > SMALL_CIN
-                and c.cout % 64 == 0 and x.t.dtype == torch.float32 and bridge.t.dtype == torch.float32)
+        """Shapes the low-resolution form serves: the library's rule (punet_upconv_eligible, also used by csrc/runtime.hip: the two
+        graph walkers agree bit for bit) on fp32 tensors in the parity arithmetic."""
+        return bool(self.upconv and x.t.dtype == torch.float32 and bridge.t.dtype == torch.float32
+                    and _lib.call("punet_upconv_eligible", x.C, bridge.C, c.cout, c.k))
+
+    def _up_entry(self, flat, name: str) -> dict:
+        d = self._up.get((flat.data_ptr(), name))
+        if d is None:
+            raise RuntimeError(f"K5x planes of {name} are missing for this parameter buffer: call prepare_forward_weights / "
+                               "prepare_dgrad_weights on it before a pass (they re-lay out and split the up-blocks' entry slabs)")
+        return d
 
     def _up_weights(self, flat, c: ConvP, cup: int, mode: int):
         """Re-layout + plane split of one up-block entry slab: w9 [cup][9 cout] (the 1x1 form of the `up` rows) and the bridge rows
@@ -505,7 +515,7 @@ class PUNetEngine:
         for j, names in enumerate(self.L.unet_up):
             c = self.L.convs[names[0]]
             cup = c.cin - nf[len(nf) - 2 - j]
-            if c.k == 3 and cup % 8 == 0 and (c.cin - cup) % 8 == 0 and cup > SMALL_CIN and c.cin - cup > SMALL_CIN and c.cout % 64 == 0:
+            if _lib.call("punet_upconv_eligible", cup, c.cin - cup, c.cout, c.k):
                 self._up_weights(flat, c, cup, mode)
 
     def upconv_fwd(self, flat, name: str, x: Act, bridge: Act, tape=None, taps=None) -> Act:
@@ -514,7 +524,7 @@ class PUNetEngine:
         c = self.L.convs[name]
         B, h, w, cup, cb = x.B, x.H, x.W, x.C, bridge.C
         H, W = 2 * h, 2 * w
-        d = self._up[(flat.data_ptr(), name)]
+        d = self._up_entry(flat, name)
         z = self._empty(B, h, w, 9 * c.cout)
         self._timed("conv1x1_fwd", 2.0 * B * h * w * cup * 9 * c.cout, "punet_conv1x1_x6_gated", x.ptr, cup, None, 0, d["p9"].data_ptr(),
                     cup * 9 * c.cout, 9 * c.cout, 0, None, 0, z.data_ptr(), 9 * c.cout, None, None, None, 0, 0, B, h, w, _stream())
@@ -1064,7 +1074,7 @@ class PUNetEngine:
         low-resolution form (csrc/upconv.hip): the nine adjoint-interpolated maps of dz ONCE, then the weight gradient of the `up`
         rows (x^T . maps, rows [0, cup) of every tap) and d loss / d x (one 1x1 input gradient with w9, gated by x's ReLU)."""
         B, h, w, cup = x.B, x.H, x.W, x.C
-        d = self._up[(flat.data_ptr(), c.name)]
+        d = self._up_entry(flat, c.name)
         dzt = self._empty(B, h, w, 9 * c.cout)
         _lib.call("punet_upconv_gather_bwd", dz.data_ptr(), dzt.data_ptr(), B, h, w, c.cout, _stream())
         ns = _lib.call("punet_upconv_wgrad_slices", cup, c.cout, B, h, w)

@@ -351,11 +351,14 @@ def test_one_call_supervised_and_joint_steps(dev, monkeypatch):
     assert abs(float(ls) - float(sc2[0] + sc2[1] + 1e-5 * sc2[2])) <= 1e-6 * abs(float(ls))
 
 
-@pytest.mark.parametrize("dice,products", [(0, 6), (1, 3)])
-def test_c_host_runs_the_training_loop(dev, tmp_path, dice, products):
+@pytest.mark.parametrize("dice,products,rccl", [(0, 6, 0), (1, 3, 0), (0, 6, 1)])
+def test_c_host_runs_the_training_loop(dev, tmp_path, dice, products, rccl):
     """tools/c_host/mean_teacher_host.c - plain C99, no Python, no torch - drives three Mean-Teacher iterations through
     punet_rt_self_training_step; students, teachers, pseudo-labels, masks and loss terms equal the Python trainers' fused step
-    bit for bit (BCE in the parity arithmetic; Dice in f16x3)."""
+    bit for bit (BCE in the parity arithmetic; Dice in f16x3).  rccl = 1: the same loop as a DATA-PARALLEL host - an RCCL
+    communicator built in C, the flat gradient all-reduced through PunetRtHooks (U-Net slice on a communication stream under the
+    encoders' backward, remainder before the update): with the one rank a one-GPU box can hold the collectives are the identity
+    and the result must not change by a bit."""
     import copy
     import struct
     import subprocess
@@ -376,8 +379,12 @@ def test_c_host_runs_the_training_loop(dev, tmp_path, dice, products):
         f.write(struct.pack(f"<4i{len(nf)}i7id", 1, len(nf), 6, 3, *nf, B, H, W, n, iters, dice, products, lr))
         for a in (m.flat_params, m.engine.to_nhwc(x1), m.engine.to_nhwc(x2), e_pl, e_s):
             f.write(a.detach().cpu().contiguous().numpy().astype(np.float32).tobytes())
-    r = subprocess.run([exe, str(case), str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    env = dict(os.environ, PUNET_C_HOST_RCCL=str(rccl), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, str(case), str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout
+    if rccl:
+        if "data parallel: RCCL communicator" not in r.stdout:
+            pytest.skip("the C host was built without RCCL (no rccl.h / librccl.so in this image)")
     opt = FusedAdam(m, lr=lr)
     for _ in range(iters):
         loss, yy, zz, _ = FU.fused_self_training_step(m, t, opt, x1, x2, n, True, e_pl.to(dev), e_s.to(dev), 0.999, 1e-5)

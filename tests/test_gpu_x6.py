@@ -251,6 +251,29 @@ def test_conv1x1_x6_fwd_and_dgrad(L, B, H, W, cin, cout, rows):
     assert rel_err(nchw(DX), x.grad) < 3e-6
 
 
+@pytest.mark.parametrize("B,H,W,rows,cout,off,cs", [(2, 16, 64, 72, 64, 0, 64), (2, 16, 64, 72, 64, 64, 8), (4, 128, 128, 40, 32, 0, 32),
+                                                    (4, 128, 128, 96, 64, 32, 64)])
+def test_conv1x1_x6_dgrad_channel_window_and_many_tiles(L, B, H, W, rows, cout, off, cs):
+    """the wide 1x1 kernel (conv1x1_x6w_kernel) also serves the Fcomb layers - contractions of 32 / 64 channels, output
+    windows (n_off > 0) of a wider weight, more tiles than the persistent grid: the input gradient w.r.t. channels [off, off + cs)
+    of a layer with `rows` input channels (Fcomb's first layer: features + latent rows), accumulated into an existing tensor."""
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(B, rows, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(cout, rows, 1, 1, generator=g) / np.sqrt(rows)).requires_grad_(True)
+    dz = torch.randn(B, cout, H, W, generator=g)
+    F.conv2d(x, w).backward(dz)
+    Wp = w.detach().permute(2, 3, 1, 0).contiguous().cuda()  # [1][1][rows][cout]
+    nw = rows * cout
+    pd = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+    L.call("punet_split_weights_x6", Wp.data_ptr(), pd.data_ptr(), nw, rows, cout, 1, 1, S())
+    prev = torch.randn(B, cs, H, W, generator=g)
+    DX = nhwc(prev)
+    L.call("punet_conv1x1_x6_gated", nhwc(dz).data_ptr(), cout, None, 0, pd.data_ptr(), nw, rows, off, None, 0, DX.data_ptr(), cs,
+           None, None, None, 1, 0, B, H, W, S())
+    torch.cuda.synchronize()
+    assert rel_err(nchw(DX), prev + x.grad[:, off:off + cs]) < 3e-6
+
+
 @pytest.mark.parametrize("B,H,W,c0,c1,cout", [(2, 16, 32, 64, 0, 64), (1, 24, 40, 32, 0, 96), (1, 8, 8, 128, 64, 128),
                                               (3, 2, 2, 16, 0, 8), (1, 64, 96, 64, 0, 200)])
 def test_conv_x6_pooled_epilogue_is_bit_identical(L, B, H, W, c0, c1, cout):

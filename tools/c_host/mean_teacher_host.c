@@ -8,12 +8,47 @@
  *           float64 lr, then float32 arrays: params [P] (state-dict order, conv weights [ky][kx][cin][cout]), x1 [B][H][W][C],
  *           x2 [B][H][W][C], eps_pl [N][B][latent], eps_s [B][latent]   (the same batch and draws every iteration: a parity case)
  * out.bin:  float32 student [P], teacher [P], y [B][H][W], z [B][H][W], scalars [3] of the last iteration
- * tests/test_gpu_runtime.py::test_c_host_runs_the_training_loop compares out.bin with the Python trainers' fused step, bit for bit. */
+ * tests/test_gpu_runtime.py::test_c_host_runs_the_training_loop compares out.bin with the Python trainers' fused step, bit for bit.
+ *
+ * Data parallelism without Python (SURVEY.md 8(b)'s punet_allreduce_grads sketch; built with -DPUNET_HOST_RCCL): with
+ * $PUNET_C_HOST_RCCL=1 the host creates an RCCL communicator (ncclCommInitRank over $PUNET_C_HOST_WORLD ranks, default ONE: all a
+ * one-GPU box can hold) and passes PunetRtHooks to the step: `after_unet` starts ncclAllReduce of the U-Net's slice
+ * [0, punet_rt_unet_floats) of the flat gradient on a communication stream as soon as that slice is final (it then runs under the
+ * encoders' backward), `before_update` reduces the remainder and makes the compute stream wait for both - the same split exchange
+ * as my_trainer/fused.py::allreduce_grads, with 1 / world_size in the optimizer's state block.  With one rank the collectives are
+ * the identity and out.bin must equal the run without them bit for bit (the same test, parametrised). */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <hip/hip_runtime_api.h>
 #include "punet_hip.h"
+#ifdef PUNET_HOST_RCCL
+#include <rccl/rccl.h>
+typedef struct {
+    ncclComm_t comm;
+    hipStream_t compute, comm_stream;
+    hipEvent_t ready, done;
+    float* grad;
+    size_t unet_floats, all_floats;
+    int failed;
+} DpCtx;
+/* the U-Net's gradient slice is final and enqueued on the compute stream: reduce it on the communication stream from there on */
+static void dp_after_unet(void* p) {
+    DpCtx* c = (DpCtx*)p;
+    if (hipEventRecord(c->ready, c->compute) != hipSuccess || hipStreamWaitEvent(c->comm_stream, c->ready, 0) != hipSuccess ||
+        ncclAllReduce(c->grad, c->grad, c->unet_floats, ncclFloat, ncclSum, c->comm, c->comm_stream) != ncclSuccess)
+        c->failed = 1;
+}
+/* the whole gradient is final: reduce the remainder, then the optimizer (next on the compute stream) waits for both reductions */
+static void dp_before_update(void* p) {
+    DpCtx* c = (DpCtx*)p;
+    if (hipEventRecord(c->ready, c->compute) != hipSuccess || hipStreamWaitEvent(c->comm_stream, c->ready, 0) != hipSuccess ||
+        ncclAllReduce(c->grad + c->unet_floats, c->grad + c->unet_floats, c->all_floats - c->unet_floats, ncclFloat, ncclSum, c->comm,
+                      c->comm_stream) != ncclSuccess ||
+        hipEventRecord(c->done, c->comm_stream) != hipSuccess || hipStreamWaitEvent(c->compute, c->done, 0) != hipSuccess)
+        c->failed = 1;
+}
+#endif
 
 #define HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
 #define PUNET(x) do { int r_ = (x); if (r_ != 0) { fprintf(stderr, "%s -> %d: %s\n", #x, r_, punet_last_error()); return 3; } } while (0)
@@ -88,11 +123,46 @@ int main(int argc, char** argv) {
     if (ab0 > ab) ab = ab0;
     HIP(hipMalloc(&arena, ab));
 
+    const PunetRtHooks* hooks = NULL;
+#ifdef PUNET_HOST_RCCL
+    PunetRtHooks hk;
+    DpCtx dp;
+    memset(&dp, 0, sizeof dp);
+    const char* want = getenv("PUNET_C_HOST_RCCL");
+    if (want && want[0] == '1') {
+        const char* ws = getenv("PUNET_C_HOST_WORLD");
+        const char* rk = getenv("PUNET_C_HOST_RANK");
+        const int world = ws ? atoi(ws) : 1, rank = rk ? atoi(rk) : 0;
+        ncclUniqueId id;
+        if (world != 1) { fprintf(stderr, "this demonstration host exchanges the unique id in-process: one rank only\n"); return 6; }
+        if (ncclGetUniqueId(&id) != ncclSuccess || ncclCommInitRank(&dp.comm, world, id, rank) != ncclSuccess) {
+            fprintf(stderr, "RCCL communicator could not be built\n");
+            return 6;
+        }
+        HIP(hipStreamCreate(&dp.comm_stream));
+        HIP(hipEventCreateWithFlags(&dp.ready, hipEventDisableTiming));
+        HIP(hipEventCreateWithFlags(&dp.done, hipEventDisableTiming));
+        dp.compute = stream; dp.grad = grad; dp.unet_floats = (size_t)punet_rt_unet_floats(rt); dp.all_floats = P;
+        hk.after_unet = dp_after_unet; hk.before_update = dp_before_update; hk.ctx = &dp;
+        hooks = &hk;
+        const double scale = 1.0 / world;  /* gradients are summed over ranks; the optimizer's state block carries 1 / world_size */
+        HIP(hipMemcpy((char*)hstate + 7 * sizeof(double), &scale, sizeof scale, hipMemcpyHostToDevice));
+        printf("data parallel: RCCL communicator of %d rank(s), U-Net slice %zu of %zu gradient floats reduced under the encoders' backward\n",
+               world, dp.unet_floats, P);
+    }
+#endif
     for (int it = 0; it < iterations; ++it)
         PUNET(punet_rt_self_training_step(rt, student, teacher, grad, m, v, hstate, hyper, /*ema=*/1, x1, x2, B, H, W, eps_pl, N, eps_s,
                                           0.9f, 0.1f, /*masking=*/1, /*use_consensus=*/1, /*beta=*/1.f, /*reg_weight=*/1e-5f, 0.9f,
-                                          0.999f, 1e-8f, y, z, scalars, NULL, arena, ab, stream));
+                                          0.999f, 1e-8f, y, z, scalars, hooks, arena, ab, stream));
     HIP(hipStreamSynchronize(stream));
+#ifdef PUNET_HOST_RCCL
+    if (hooks) {
+        if (dp.failed) { fprintf(stderr, "a collective could not be enqueued\n"); return 7; }
+        HIP(hipStreamSynchronize(dp.comm_stream));
+        ncclCommDestroy(dp.comm);
+    }
+#endif
 
     FILE* o = fopen(argv[2], "wb");
     if (!o) { perror(argv[2]); return 1; }
