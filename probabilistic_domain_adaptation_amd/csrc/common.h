@@ -187,6 +187,7 @@ __device__ __forceinline__ void splitf16_pair(float a, float b, float s, unsigne
         asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "v"(s), "v"(h));
         return;
     }
+
 #endif
     {
     const punet_f32x2 x = {a * s, b * s};
@@ -220,3 +221,20 @@ __device__ __forceinline__ f32x16 punet_mfma32(const uint4& a, const uint4& b, f
     else
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(punet_bf16x8, a), __builtin_bit_cast(punet_bf16x8, b), c, 0, 0, 0);
 }
+
+// Zero `bytes` (a multiple of 4) of device memory with a KERNEL, not hipMemsetAsync: every pass of the step-level runtime zeroes a
+// few small regions (amax slots, arrival counters) between kernels, and inside a captured hipGraph a memset node is executed by
+// another path than the kernel nodes around it - round 5 saw a replayed f16x3 step read amax slots that its memset node had not
+// cleared yet (tests/test_gpu_graph.py::test_graph_replay_across_conv_mode_switches_equals_eager under PUNET_CONV_MODE=f16x3:
+// wrong losses, then NaN, depending on what else the process had enqueued).  As a kernel node it is ordered like everything else.
+static __global__ void punet_zero_fill_kernel(unsigned* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t punet_zero_fill(void* p, size_t bytes, hipStream_t st) {
+    const size_t n = bytes / 4;
+    if (!n) return hipSuccess;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+    punet_zero_fill_kernel<<<grid, 256, 0, st>>>((unsigned*)p, n);
+    return hipGetLastError();
+}
+

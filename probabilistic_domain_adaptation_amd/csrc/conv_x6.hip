@@ -1728,7 +1728,7 @@ extern "C" int punet_split_weights_f16(const float* w, void* planes, long plane_
     PUNET_CHECK_ARG((mode == 0 ? cin : cout) % 8 == 0, "punet_split_weights_f16: the contracted channel count must be a multiple of 8");
     PUNET_CHECK_ARG(plane_stride >= 9l * cin * cout, "punet_split_weights_f16: plane_stride too small");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(amax_w, 0, sizeof(float), st) != hipSuccess) {
+    if (punet_zero_fill(amax_w, sizeof(float), st) != hipSuccess) {
         punet_set_error("punet_split_weights_f16: memset failed");
         return PUNET_ERR_HIP;
     }
@@ -1752,7 +1752,7 @@ extern "C" int punet_split_weights_f16_batch(const float* flat, void* planes, co
     long grid = (total_units + 255) / 256;
     if (grid > 8192) grid = 8192;
     if (compute_amax) {  // (the forward and the input-gradient orientation of one weight state share the slots: compute once)
-        if (hipMemsetAsync(wamax, 0, sizeof(float) * (size_t)nconv, st) != hipSuccess) {
+        if (punet_zero_fill(wamax, sizeof(float) * (size_t)nconv, st) != hipSuccess) {
             punet_set_error("punet_split_weights_f16_batch: memset failed");
             return PUNET_ERR_HIP;
         }

@@ -1105,7 +1105,7 @@ __global__ void amax_bound_kernel(const float* a, float ca, const float* b, floa
 
 extern "C" int punet_amax(const float* x, long n, float* slot, int zero_first, void* stream) {
     PUNET_CHECK_ARG(x && slot && n > 0 && ((uintptr_t)x & 15) == 0, "punet_amax: bad args (x must be 16-byte aligned)");
-    if (zero_first && hipMemsetAsync(slot, 0, sizeof(float), STREAM) != hipSuccess) {
+    if (zero_first && punet_zero_fill(slot, sizeof(float), STREAM) != hipSuccess) {
         punet_set_error("punet_amax: memset failed");
         return PUNET_ERR_HIP;
     }
@@ -1311,7 +1311,7 @@ extern "C" int punet_nhwc_to_nchw(const float* x, float* y, int B, int C, long H
 extern "C" int punet_align_distribution(const float* y, const float* source_distribution, float* out, float* ratio,
                                         unsigned long long* count_ws, long P, void* stream) {
     PUNET_CHECK_ARG(y && source_distribution && out && count_ws && P > 0, "punet_align_distribution: bad args");
-    if (hipMemsetAsync(count_ws, 0, sizeof(unsigned long long), STREAM) != hipSuccess) {
+    if (punet_zero_fill(count_ws, sizeof(unsigned long long), STREAM) != hipSuccess) {
         punet_set_error("punet_align_distribution: hipMemsetAsync failed");
         return PUNET_ERR_HIP;
     }

@@ -251,7 +251,7 @@ struct Pass {  // one forward / backward walk
     int begin_splitk() {
         sk_bytes = punet_conv_splitk_scratch_bytes();
         sk = ar->take(sk_bytes);
-        if (!dry && hipMemsetAsync(sk, 0, 4096, (hipStream_t)stream) != hipSuccess) {
+        if (!dry && punet_zero_fill(sk, 4096, (hipStream_t)stream) != hipSuccess) {
             punet_set_error("punet_rt: memset of the stream-K counters failed");
             return PUNET_ERR_HIP;
         }
@@ -283,7 +283,7 @@ struct Pass {  // one forward / backward walk
         slots = ar->floats(n);
         nslots = n;
         next_slot = 0;
-        if (!dry && hipMemsetAsync(slots, 0, (size_t)n * 4, (hipStream_t)stream) != hipSuccess) {
+        if (!dry && punet_zero_fill(slots, (size_t)n * 4, (hipStream_t)stream) != hipSuccess) {
             punet_set_error("punet_rt: memset of the amax slots failed");
             return PUNET_ERR_HIP;
         }
