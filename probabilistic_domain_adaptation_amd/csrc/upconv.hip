@@ -433,6 +433,182 @@ __global__ __launch_bounds__(512, 2) void upconv_wgrad_x6_kernel(UpWgradArgs a) 
     }
 }
 
+// ---- round 5: the same weight gradient with a 128 x 64 (ci, co) tile, 32-pixel tiles and TWO operand image sets.
+// The first kernel above owns 64 x 64 channels x 3 taps and 64-pixel tiles in one single-buffered 96 KB image set: at the deepest
+// up-block (cup = 512, cout = 256) that is 96 channel groups x 2 pixel slices = 192 workgroups on 256 CUs, the nine adjoint maps
+// are re-read by 8 ci tiles, x by 12 (co, tap) groups (923 MB fetched per launch against ~430 MB algorithmic), two barriers per
+// tile: 0.31 of the peak's matrix cycles.  Here a workgroup owns 128 ci x 64 co x 3 taps: its 8 waves = 2 co blocks x 2 ci
+// halves (two 32-channel blocks each) x 2 halves of a 32-pixel tile (the halves are two split-K slabs); per tile it stages
+// 16 KB of x + 24 KB of dzt for the same 36 MFMAs per wave (0.625 x the bytes per MFMA), the nine maps are read by HALF as many
+// ci tiles, and with 2 x 60 KB of images the next tile is written while the current one is still being read: ONE barrier per
+// tile.  48 channel groups x 5 slices = 240 workgroups at the deepest block (12 x 21, 3 x 85 at the other two).
+constexpr int U2CI = 128, U2PD = 32, U2IMG = U2PD * UROWB;  // 2 KB images: 32 pixels x 32 channels
+constexpr int U2X = 3 * 4 * U2IMG, U2D = UTAPS * 3 * 2 * U2IMG, U2SET = U2X + U2D;  // 24 KB + 36 KB per set
+
+__global__ __launch_bounds__(512, 2) void upconv_wgrad_x6w_kernel(UpWgradArgs a) {
+    constexpr int NP = 3;
+    constexpr int XIT = U2PD * (U2CI / 4) / 512, DIT = UTAPS * U2PD * (UWC / 4) / 512;  // 2 and 3 float4 units per thread and tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int cob = wave & 1, cih = (wave >> 1) & 1, ks = wave >> 2;  // co block, ci half (blocks 2 cih, 2 cih + 1), 16-pixel half of the tile
+    const int co_tiles = (a.cout + UWC - 1) / UWC;
+    const int tg = blockIdx.y % 3;
+    const int co_tile = (blockIdx.y / 3) % co_tiles, ci_tile = blockIdx.y / (3 * co_tiles);
+    const int ci0 = ci_tile * U2CI, co0 = co_tile * UWC;
+    const int slice = blockIdx.x;
+    const long ntiles = (a.M + U2PD - 1) / U2PD;
+
+    f32x16 acc[2][UTAPS];
+#pragma unroll
+    for (int i = 0; i < 2 * UTAPS; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i / UTAPS][i % UTAPS][r] = 0.f;
+
+    const int l16 = lane & 15, q = l16 >> 2, p4 = l16 & 3, cb = (lane >> 4) & 1;
+    const int lane_off = (8 * half + q) * UROWB + (16 * cb + 4 * p4) * 2;  // (wgrad_x6.hip: the transposing read's lane mapping)
+
+    float4 rx[XIT], rd[DIT];
+    unsigned inmask = 0u;
+    auto prefetch = [&](long tile) __attribute__((always_inline)) {
+        const long p0 = tile * U2PD;
+        inmask = 0u;
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int u = tid + it * 512;
+            const int c4 = u % (U2CI / 4), pix = u / (U2CI / 4);
+            const int c = ci0 + c4 * 4;
+            const bool in = p0 + pix < a.M && c < a.cs;
+            const long pp = p0 + pix < a.M ? p0 + pix : a.M - 1;
+            rx[it] = *reinterpret_cast<const float4*>(a.x + (size_t)pp * a.cs + min(c, a.cs - 4));
+            inmask = in ? inmask | (1u << it) : inmask;
+        }
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const int u = tid + it * 512;
+            const int c4 = u % (UWC / 4), tap = (u / (UWC / 4)) % UTAPS, pix = u / ((UWC / 4) * UTAPS);
+            const int c = co0 + c4 * 4;
+            const bool in = p0 + pix < a.M && c < a.cout;
+            const long pp = p0 + pix < a.M ? p0 + pix : a.M - 1;
+            rd[it] = *reinterpret_cast<const float4*>(a.dzt + ((size_t)pp * 9 + (3 * tg + tap)) * a.cout + min(c, a.cout - 4));
+            inmask = in ? inmask | (1u << (XIT + it)) : inmask;
+        }
+    };
+    up_bf16x4 px[XIT + DIT][NP];
+    auto split_unit = [&](int i) __attribute__((always_inline)) {  // i < XIT: x unit, else dzt unit
+        const float4 v = i < XIT ? rx[i < XIT ? i : 0] : rd[i >= XIT ? i - XIT : 0];
+        const float4 r = (inmask >> i) & 1u ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        uint2 ph, pm, pl;
+        split3_quad<NP>(r, ph, pm, pl);
+        px[i][0] = __builtin_bit_cast(up_bf16x4, ph);
+        px[i][1] = __builtin_bit_cast(up_bf16x4, pm);
+        px[i][2] = __builtin_bit_cast(up_bf16x4, pl);
+    };
+    auto commit = [&](int set) __attribute__((always_inline)) {
+        char* const sX = smem + set * U2SET;  // [plane][ci block][32 px][32 ch]
+        char* const sD = sX + U2X;            // [tap][plane][co block][32 px][32 ch]
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int u = tid + it * 512;
+            const int c4 = u % (U2CI / 4), pix = u / (U2CI / 4);
+            const int off = (c4 >> 3) * U2IMG + pix * UROWB + (c4 & 7) * 8;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<up_bf16x4*>(sX + p * 4 * U2IMG + off) = px[it][p];
+        }
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const int u = tid + it * 512;
+            const int c4 = u % (UWC / 4), tap = (u / (UWC / 4)) % UTAPS, pix = u / ((UWC / 4) * UTAPS);
+            const int off = (c4 >> 3) * U2IMG + pix * UROWB + (c4 & 7) * 8;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<up_bf16x4*>(sD + (tap * NP + p) * 2 * U2IMG + off) = px[XIT + it][p];
+        }
+    };
+
+    int set = 0;
+    if (slice < ntiles) {
+        prefetch(slice);
+#pragma unroll
+        for (int i = 0; i < XIT + DIT; ++i) split_unit(i);
+        commit(0);
+    }
+    for (long tile = slice; tile < ntiles; tile += a.nslices) {
+        const long next = tile + a.nslices;
+        const bool has_next = next < ntiles;  // block-uniform
+        prefetch(has_next ? next : tile);     // in flight across the barrier and the MFMAs (a re-fetch of the last tile is dropped)
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // vmcnt(63) expcnt(7) lgkmcnt(0): this wave's LDS writes of set `set` have landed
+        __builtin_amdgcn_s_barrier();         // ... and everybody's; everybody has finished reading the other set (the previous tile)
+        {
+            const char* const sX = smem + set * U2SET;
+            const char* const sD = sX + U2X;
+            UpFrag fa[2][NP];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+                        fa[c2][p].half4[r] = up_tr_read(sX, (p * 4 + 2 * cih + c2) * U2IMG + (16 * ks + 4 * r) * UROWB + lane_off);
+#pragma unroll
+            for (int t = 0; t < UTAPS; ++t) {
+                UpFrag fb[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+                        fb[p].half4[r] = up_tr_read(sD, ((t * NP + p) * 2 + cob) * U2IMG + (16 * ks + 4 * r) * UROWB + lane_off);
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    f32x16 c = acc[c2][t];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c2][1].v, fb[1].v, c, 0, 0, 0);  // mm
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c2][2].v, fb[0].v, c, 0, 0, 0);  // lh
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c2][0].v, fb[2].v, c, 0, 0, 0);  // hl
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c2][1].v, fb[0].v, c, 0, 0, 0);  // mh
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c2][0].v, fb[1].v, c, 0, 0, 0);  // hm
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c2][0].v, fb[0].v, c, 0, 0, 0);  // hh
+                    acc[c2][t] = c;
+                }
+                // the next tile's split in the shadow of these MFMAs (its loads were issued in front of the barrier)
+                if (t == 0) {
+                    split_unit(0);
+                    split_unit(1);
+                } else if (t == 1) {
+                    split_unit(2);
+                    split_unit(3);
+                } else {
+                    split_unit(4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (has_next) commit(set ^ 1);  // into the set nobody reads any more (everybody passed this tile's barrier)
+        set ^= 1;
+    }
+    // slab (2 slice + ks): rows [tap][ci], columns co - the layout of wgrad3x3_x6_kernel's slabs (reduce_slabs sums them)
+    const int co = co0 + cob * 32 + l31;
+    if (co < a.cout) {
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int t = 0; t < UTAPS; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = ci0 + (2 * cih + c2) * 32 + mfma32_row(r, half);
+                    if (ci < a.cs) a.partial[((((size_t)(2 * slice + ks)) * 9 + 3 * tg + t) * a.cs + ci) * a.cout + co] = acc[c2][t][r];
+                }
+    }
+}
+
+// $PUNET_UPCONV_WGRAD=64: the first kernel (64 x 64 tiles, 64-pixel tiles, one image set), for same-box A/B runs; read once
+static int punet_upconv_wgrad_wide() {
+    static const int on = [] {
+        const char* e = getenv("PUNET_UPCONV_WGRAD");
+        return !(e && e[0] == '6');
+    }();
+    return on;
+}
+
 int shift_of(int c4) {  // log2 when a power of two, else -1
     for (int s = 0; s < 16; ++s)
         if ((1 << s) == c4) return s;
@@ -491,8 +667,9 @@ extern "C" int punet_upconv_gather_bwd(const float* dz, float* dzt, int B, int h
 
 // split-K slices of punet_upconv_wgrad_x6 (about one resident workgroup per CU) and its workspace (4 slabs per slice)
 extern "C" int punet_upconv_wgrad_slices(int cup, int cout, int B, int h, int w) {
-    const long ntiles = ((long)B * h * w + UNPD - 1) / UNPD;
-    const int groups = 3 * ceil_div(cup, UWC) * ceil_div(cout, UWC);
+    const bool wide = punet_upconv_wgrad_wide();
+    const long ntiles = ((long)B * h * w + (wide ? U2PD : UNPD) - 1) / (wide ? U2PD : UNPD);
+    const int groups = 3 * ceil_div(cup, wide ? U2CI : UWC) * ceil_div(cout, UWC);
     if (groups < 1 || ntiles < 1) return 1;
     long ns = punet_num_cus() / groups;
     if (ns > ntiles) ns = ntiles;
@@ -507,14 +684,27 @@ extern "C" int punet_upconv_wgrad_x6(const float* x, int cup, const float* dzt, 
                     "punet_upconv_wgrad_x6: bad args (cup=%d cout=%d cin_total=%d nslices=%d)", cup, cout, cin_total, nslices);
     UpWgradArgs a{};
     a.x = x; a.dzt = dzt; a.partial = workspace; a.cs = cup; a.cout = cout; a.nslices = nslices; a.M = (long)B * h * w;
-    constexpr int SMEM = 3 * 2 * UIMG + UTAPS * 3 * 2 * UIMG;  // 98,304 B
-    if (hipFuncSetAttribute((const void*)upconv_wgrad_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
-        punet_set_error("punet_upconv_wgrad_x6: cannot reserve %d bytes of LDS", SMEM);
-        return PUNET_ERR_HIP;
+    int nslabs;
+    if (punet_upconv_wgrad_wide()) {
+        constexpr int SMEM = 2 * U2SET;  // 122,880 B
+        if (hipFuncSetAttribute((const void*)upconv_wgrad_x6w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
+            punet_set_error("punet_upconv_wgrad_x6: cannot reserve %d bytes of LDS", SMEM);
+            return PUNET_ERR_HIP;
+        }
+        const dim3 grid(nslices, 3 * ceil_div(cup, U2CI) * ceil_div(cout, UWC));
+        upconv_wgrad_x6w_kernel<<<grid, 512, SMEM, STREAM>>>(a);
+        nslabs = 2 * nslices;
+    } else {
+        constexpr int SMEM = 3 * 2 * UIMG + UTAPS * 3 * 2 * UIMG;  // 98,304 B
+        if (hipFuncSetAttribute((const void*)upconv_wgrad_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
+            punet_set_error("punet_upconv_wgrad_x6: cannot reserve %d bytes of LDS", SMEM);
+            return PUNET_ERR_HIP;
+        }
+        const dim3 grid(nslices, 3 * ceil_div(cup, UWC) * ceil_div(cout, UWC));
+        upconv_wgrad_x6_kernel<<<grid, 512, SMEM, STREAM>>>(a);
+        nslabs = 4 * nslices;
     }
-    const dim3 grid(nslices, 3 * ceil_div(cup, UWC) * ceil_div(cout, UWC));
-    upconv_wgrad_x6_kernel<<<grid, 512, SMEM, STREAM>>>(a);
     PUNET_LAUNCH_CHECK("upconv_wgrad_x6");
     // rows [tap][ci] of the slabs -> rows [0, cup) of every tap's [cin_total][cout] block of dw (deterministic: slabs in slice order)
-    return punet_launch_reduce_slabs(workspace, 4 * nslices, (size_t)9 * cup * cout, 9 * cup, cout, cup, cin_total, 0, dw, accumulate, scale, STREAM);
+    return punet_launch_reduce_slabs(workspace, nslabs, (size_t)9 * cup * cout, 9 * cup, cout, cup, cin_total, 0, dw, accumulate, scale, STREAM);
 }
