@@ -150,6 +150,9 @@ def test_cost_model_splits_the_704_levels_and_leaves_whole_rounds_alone(L):
     """opts = default (no override): the library's own plan.  At the 88 x 88 x 512 level of a 704 x 704 patch (1,056 tiles on 512
     resident workgroups) it must split - seen as a result that differs in the last bits from the unsplit launch - and at the
     64 x 64 x 512 level of a 512 x 512 patch (512 tiles: one whole round) it must not (bit-identical)."""
+    import os
+    if os.environ.get("PUNET_SPLITK"):
+        pytest.skip("$PUNET_SPLITK overrides the library's plan")
     cap = 2 * L.call("punet_compute_units")
     g = torch.Generator().manual_seed(4)
     sc = Scratch(L)
