@@ -824,7 +824,7 @@ def main():
                 if a.workload == "mean_teacher" and (B, H, W, N) == (4, 512, 512, 8) and eng.conv_mode in ("x6", "f32"):
                     fn, key = {"x6": ("pmc_hbm_traffic_x6.json", "conv3x3_x6b_kernel<3, false>"),
                                "f32": ("pmc_hbm_traffic.json", "conv_mfma_kernel<3, false>")}[eng.conv_mode]
-                    rdir = next(r for r in ("r04", "r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", r, fn)))
+                    rdir = next(r for r in ("r05", "r04", "r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", r, fn)))
                     pm = json.load(open(os.path.join(ROOT, "profiles", rdir, fn)))
                     if key not in pm["kernels"]:  # (round 3 added a template argument to the kernels' names)
                         key = key.replace("<3, false>", "<3, false, false>")
