@@ -205,3 +205,75 @@ def test_split_tail_with_fp16_planes_publishes_the_same_amax(L):
     assert rel_err(outs[0][0], outs[1][0]) < 4e-6
     assert outs[0][1].item() == outs[0][0].abs().max().item() and abs(outs[0][1].item() - outs[1][1].item()) <= 2e-6 * outs[1][1].item()
     assert sc.counters_zero()
+
+
+def _random_split_cases(count, seed):
+    import random
+    r = random.Random(seed)
+    out = []
+    for _ in range(count):
+        c0 = 32 * r.randint(1, 8)
+        c1 = r.choice([0, 0, 32 * r.randint(1, 4)])
+        nq = (c0 + c1) // 32
+        out.append((r.randint(1, 4), r.randint(3, 70), r.randint(3, 100), c0, c1, 8 * r.randint(1, 40), r.randint(1, max(1, nq - 1)) if nq > 1 else 1))
+    return out
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,cout,run", _random_split_cases(16, 77))
+def test_split_tail_seeded_draws_against_the_whole_launch(L, B, H, W, c0, c1, cout, run):
+    """Seeded draws over batch, image size (any, ragged tiles included), one or two sources, output channels that are not multiples
+    of the 64-channel tile, and the run length: the split launch equals the whole launch up to summation order, three launches in
+    a row are bit-identical, the counters end at zero."""
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+    cin = c0 + c1
+    X0 = torch.relu(torch.randn(B, H, W, c0, generator=g)).cuda()
+    X1 = torch.relu(torch.randn(B, H, W, c1, generator=g)).cuda() if c1 else None
+    w = (torch.randn(3, 3, cin, cout, generator=g) / np.sqrt(cin * 9)).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    nw = 9 * cin * cout
+    pf = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+    L.call("punet_split_weights_x6", w.data_ptr(), pf.data_ptr(), nw, cin, cout, 3, 0, S())
+    sc = Scratch(L)
+    outs = []
+    for s_, r_ in ((sc, run), (sc, run), (sc, run), (None, -1)):
+        Y = torch.full((B, H, W, cout), float("nan"), device="cuda")
+        conv(L, s_, X0, X1, pf, nw, cout, 0, b, Y, cout, None, None, None, 0, 1, B, H, W, r_)
+        outs.append(Y)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.isfinite(outs[0]).all() and rel_err(outs[0], outs[3]) < 4e-6
+    assert sc.counters_zero()
+
+
+def test_split_tail_under_load_from_another_stream(L):
+    """MI355X_MICROARCH.md: test every inter-workgroup hand-off under UNEVEN load.  A side stream keeps the chip busy with large
+    GEMMs of its own (its workgroups take CUs and L2 away at arbitrary moments) while the main stream runs split launches back to
+    back: every result must be bit-identical to the one computed on an idle chip."""
+    g = torch.Generator().manual_seed(12)
+    sc = Scratch(L)
+    layers = []
+    for (B, H, W, cin, cout, run) in [(4, 88, 88, 512, 512, 0), (4, 96, 96, 256, 256, 1), (4, 65, 88, 512, 512, 0), (2, 40, 72, 128, 192, 1)]:
+        x = torch.relu(torch.randn(B, H, W, cin, generator=g)).cuda()
+        w = (torch.randn(3, 3, cin, cout, generator=g) / np.sqrt(cin * 9)).cuda()
+        b = torch.randn(cout, generator=g).cuda()
+        nw = 9 * cin * cout
+        pf = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+        L.call("punet_split_weights_x6", w.data_ptr(), pf.data_ptr(), nw, cin, cout, 3, 0, S())
+        Y = torch.empty(B, H, W, cout, device="cuda")
+        conv(L, sc, x, None, pf, nw, cout, 0, b, Y, cout, None, None, None, 0, 1, B, H, W, run)
+        layers.append((B, H, W, cin, cout, run, x, pf, nw, b, Y))
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda")
+    stop = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        for _ in range(60):  # ~60 x 0.1-0.3 ms of foreign work spread over the test
+            a = torch.tanh(a @ a * 1e-3)
+        stop.record()
+    for rep in range(10):
+        for i, (B, H, W, cin, cout, run, x, pf, nw, b, ref) in enumerate(layers):
+            Y = torch.empty(B, H, W, cout, device="cuda")
+            conv(L, sc, x, None, pf, nw, cout, 0, b, Y, cout, None, None, None, 0, 1, B, H, W, run)
+            assert torch.equal(Y, ref), f"repetition {rep} of layer {i} differs from the idle-chip result"
+    torch.cuda.synchronize()
+    assert sc.counters_zero()
