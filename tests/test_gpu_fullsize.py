@@ -79,8 +79,8 @@ def test_inference_fullsize_against_oracle(dev, channels, size, n):
     assert (ym.cpu() - probs.mean(0)).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("B,channels,size", [(1, 1, 512), (1, 3, 704), (2, 1, 512)],
-                         ids=["512x512x1-B1", "704x704x3-B1", "512x512x1-B2"])
+@pytest.mark.parametrize("B,channels,size", [(1, 1, 512), (1, 3, 704), (2, 1, 512), (4, 1, 512)],
+                         ids=["512x512x1-B1", "704x704x3-B1", "512x512x1-B2", "512x512x1-B4"])
 def test_training_step_fullsize_against_oracle(dev, B, channels, size):
     """The production instantiations (persistent grids with tile wrap-around, 256 split-K slabs, XCD remap, fused pooling,
     LDS-DMA weight staging) against the CPU oracle's autograd at the bench's patch sizes and filters, nf = [64, 128, 256, 512],
@@ -88,7 +88,11 @@ def test_training_step_fullsize_against_oracle(dev, B, channels, size):
       * one 512 x 512 x 1 patch (configs[1] / [2]);
       * one 704 x 704 x 3 patch (configs[3], adamatch_trainer.py:56-116): the 3- and 4-channel first-layer weight-gradient
         kernels (`conv3x3_small_wgrad_kernel<3>`, `<4>`) and the non-power-of-two tiling at full size;
-      * a batch of two 512 x 512 patches: split-K slices that cross image boundaries, the per-image z term, the batch-mean KL.
+      * a batch of two 512 x 512 patches: split-K slices that cross image boundaries, the per-image z term, the batch-mean KL;
+      * a batch of FOUR 512 x 512 patches (round 5): exactly the student pass of the bench's headline step -
+        the tile counts, rounds and split-K slices the timed launches have.
+    (At 704 x 704 the 3x3 launches of the 88 x 88 and 176 x 176 levels finish through the stream-K tail: this is where that path
+    meets the oracle's gradients.)
     The oracle's ReLUs are gated by the GPU's own forward activations (which are checked first), so that a
     pre-activation within fp32 rounding of 0 cannot turn into an O(1) difference of single gradient entries."""
     m = _model(dev, channels=channels)
