@@ -6,6 +6,7 @@
 // four consecutive output channels of a pixel (Cout/4 threads per pixel -> one coalesced 16 B x Cout/4
 // store per pixel), keeps its 9*CIN weight float4s in registers and walks a strip of pixels.
 // No input gradient exists for them (the image needs none).
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "punet_hip.h"
@@ -155,6 +156,130 @@ __global__ __launch_bounds__(256) void conv3x3_small_wgrad_kernel(const float* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 5: the first layer with 2..4 input channels (MitoEM-shaped 3-channel patches, the posterior's [image, label] input) on the
+// matrix cores.  The VALU kernel above needs 9 CIN loads + 36 CIN FMAs + their addressing per output quad: with one channel it is
+// bound by its stores (4.4 TB/s), with three / four it is bound by its vector instructions (1.25 / 1.13 TB/s: 0.40 / 0.45 ms per
+// launch at 704 x 704, batch 4).  As a GEMM the layer is out[px][co] = sum_k P[px][k] W[k][co] with k = tap * CIN + c < 9 CIN <= 36:
+// ONE (CIN <= 3) or TWO v_mfma_f32_16x16x32 K-steps per {16 pixels, 16 channels} in the six-product arithmetic of every other
+// layer (operands split into three bf16 planes: fp32-accurate) - ~25 us of matrix time per launch, i.e. the
+// kernel is back at its stores.  A lane (pixel l16, k-octet g) gathers its 8 patch values itself (offsets per lane, fixed for the
+// kernel); the weights are split once per workgroup into LDS planes in the A-operand order.  Output mapping = the 3x3 kernels':
+// a lane holds one pixel and four consecutive channels per accumulator quad (16-byte stores).
+typedef float fm_f32x4 __attribute__((ext_vector_type(4)));
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_first_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, float* __restrict__ y, int cout,
+                                                                int B, int H, int W, int relu, float* __restrict__ amax_out) {
+    constexpr int KT = 9 * CIN, KS = (KT + 31) / 32;
+    extern __shared__ __attribute__((aligned(16))) uint4 swp[];  // [plane][ks][g][co] units of 8 k-values (bf16)
+    __shared__ float sam[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, g = lane >> 4;
+    const int units = KS * 4 * cout;
+    for (int u = tid; u < units; u += 256) {
+        const int co = u % cout, kg = u / cout;  // kg = ks * 4 + g: k = 8 kg .. 8 kg + 7
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * kg + j;
+            v[j] = k < KT ? w[(size_t)k * cout + co] : 0.f;
+        }
+        uint4 ph, pm, pl;
+        split3_pair<3>(v[0], v[1], ph.x, pm.x, pl.x);
+        split3_pair<3>(v[2], v[3], ph.y, pm.y, pl.y);
+        split3_pair<3>(v[4], v[5], ph.z, pm.z, pl.z);
+        split3_pair<3>(v[6], v[7], ph.w, pm.w, pl.w);
+        swp[u] = ph;
+        swp[units + u] = pm;
+        swp[2 * units + u] = pl;
+    }
+    __syncthreads();
+    // this lane's 8 KS patch elements: tap offset (in floats, relative to the pixel) and (dy, dx) for the border test
+    int koff[KS][8], kdy[KS][8], kdx[KS][8];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 32 * ks + 8 * g + j;
+            const int t = k / CIN, c = k % CIN;
+            const bool real = k < KT;
+            kdy[ks][j] = real ? t / 3 - 1 : 0x40000000;  // (a row that is never inside the image)
+            kdx[ks][j] = real ? t % 3 - 1 : 0;
+            koff[ks][j] = real ? ((t / 3 - 1) * W + (t % 3 - 1)) * CIN + c : 0;
+        }
+    const int bpr = (W + 15) / 16;  // 16-pixel blocks per image row
+    const long nblk = (long)B * H * bpr;
+    float am = 0.f;
+    // two 16-pixel blocks per iteration: their 16 KS gathers are in flight together, and a weight fragment read serves both
+    constexpr int NB = 2;
+    for (long blk0 = ((long)blockIdx.x * 4 + wave) * NB; blk0 < nblk; blk0 += (long)gridDim.x * 4 * NB) {
+        uint4 pf[NB][KS][3];
+        float* yp[NB];
+        bool pin[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const long blk = blk0 + nb < nblk ? blk0 + nb : nblk - 1;  // (wave-uniform; a duplicate of the last block stores nothing)
+            const int row = (int)(blk / bpr), bx = (int)(blk % bpr);   // row = b * H + py
+            const int py = row % H, px = bx * 16 + l16;
+            pin[nb] = px < W && blk0 + nb < nblk;
+            const float* xp = x + ((size_t)row * W + (px < W ? px : W - 1)) * CIN;
+            yp[nb] = y + ((size_t)row * W + px) * cout + 4 * g;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool in = pin[nb] && (unsigned)(py + kdy[ks][j]) < (unsigned)H && (unsigned)(px + kdx[ks][j]) < (unsigned)W;
+                    v[j] = in ? xp[koff[ks][j]] : 0.f;
+                }
+                split3_pair<3>(v[0], v[1], pf[nb][ks][0].x, pf[nb][ks][1].x, pf[nb][ks][2].x);
+                split3_pair<3>(v[2], v[3], pf[nb][ks][0].y, pf[nb][ks][1].y, pf[nb][ks][2].y);
+                split3_pair<3>(v[4], v[5], pf[nb][ks][0].z, pf[nb][ks][1].z, pf[nb][ks][2].z);
+                split3_pair<3>(v[6], v[7], pf[nb][ks][0].w, pf[nb][ks][1].w, pf[nb][ks][2].w);
+            }
+        }
+        for (int co0 = 0; co0 < cout; co0 += 16) {
+            fm_f32x4 c[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) c[nb] = fm_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int wu = (ks * 4 + g) * cout + co0 + l16;
+                const uint4 wh = swp[wu], wm = swp[units + wu], wl = swp[2 * units + wu];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    c[nb] = punet_mfma16<false>(wm, pf[nb][ks][1], c[nb]);  // mm
+                    c[nb] = punet_mfma16<false>(wh, pf[nb][ks][2], c[nb]);  // lh
+                    c[nb] = punet_mfma16<false>(wl, pf[nb][ks][0], c[nb]);  // hl
+                    c[nb] = punet_mfma16<false>(wh, pf[nb][ks][1], c[nb]);  // mh
+                    c[nb] = punet_mfma16<false>(wm, pf[nb][ks][0], c[nb]);  // hm
+                    c[nb] = punet_mfma16<false>(wh, pf[nb][ks][0], c[nb]);  // hh
+                }
+            }
+            const fm_f32x4 bq = bias ? *reinterpret_cast<const fm_f32x4*>(bias + co0 + 4 * g) : fm_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                fm_f32x4 v = c[nb] + bq;
+                if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                if (pin[nb]) {
+                    *reinterpret_cast<fm_f32x4*>(yp[nb] + co0) = v;
+                    am = fmaxf(fmaxf(am, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                }
+            }
+        }
+    }
+    if (amax_out) punet_amax_publish_block256(amax_out, am, sam);  // (block-uniform)
+}
+
+// $PUNET_FIRST_MFMA=0: the VALU kernel for every channel count, as before round 5 (same-box A/B); read once per process
+static int punet_first_mfma() {
+    static const int on = [] {
+        const char* e = getenv("PUNET_FIRST_MFMA");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 constexpr int SMALL_WGRAD_BLOCKS = 1024;
 
 }  // namespace
@@ -167,10 +292,26 @@ static int small_fwd_launch(int out16, const float* x, int cin, const float* w, 
     PUNET_CHECK_ARG(cout >= 4 && cout % 4 == 0 && 256 % (cout / 4) == 0 && cout <= 1024,
                     "punet_conv3x3_small_fwd: cout/4 must divide 256 (got cout=%d)", cout);
     PUNET_CHECK_ARG((unsigned long long)W * (cin > cout ? cin : cout) < (1ull << 31), "punet_conv3x3_small_fwd: image row too long");
+    float* yf = (float*)y;
+    if (out16 == 0 && cin >= 2 && cin <= 4 && cout % 16 == 0 && punet_first_mfma()) {  // fp32 output, 2..4 channels: on the matrix cores
+        PUNET_CHECK_ARG((unsigned long long)B * H * W < (1ull << 31), "punet_conv3x3_small_fwd: more than 2^31 pixels");
+        const int ks = (9 * cin + 31) / 32;
+        const size_t lds = (size_t)3 * ks * 4 * cout * sizeof(uint4);
+        PUNET_CHECK_ARG(lds <= 64 * 1024, "punet_conv3x3_small_fwd: cout %d needs %zu bytes of LDS for the weight planes", cout, lds);
+        const long nblk = (long)B * H * ceil_div(W, 16);
+        const int cap = 8 * punet_num_cus();  // 8 workgroups of 4 waves per CU: the kernel lives on memory-level parallelism
+        const int grid1 = (int)((nblk + 7) / 8 < cap ? (nblk + 7) / 8 : cap);  // (a wave takes two blocks per iteration)
+        switch (cin) {
+            case 2: conv3x3_first_mfma_kernel<2><<<grid1, 256, lds, stream>>>(x, w, bias, yf, cout, B, H, W, relu, amax_y); break;
+            case 3: conv3x3_first_mfma_kernel<3><<<grid1, 256, lds, stream>>>(x, w, bias, yf, cout, B, H, W, relu, amax_y); break;
+            default: conv3x3_first_mfma_kernel<4><<<grid1, 256, lds, stream>>>(x, w, bias, yf, cout, B, H, W, relu, amax_y); break;
+        }
+        PUNET_LAUNCH_CHECK("conv3x3_first_mfma");
+        return PUNET_OK;
+    }
     const int ppb = 256 / (cout / 4);
     const int xiter = 8;
     const dim3 grid(ceil_div(W, ppb * xiter), B * H < 65535 ? B * H : 65535);
-    float* yf = (float*)y;
     const size_t wlds = cin > 4 ? (size_t)9 * cin * (cout / 4) * sizeof(float4) : 0;  // 5..8 channels: weights in LDS (<= 72 KB)
     PUNET_CHECK_ARG(wlds <= 160 * 1024, "punet_conv3x3_small_fwd: cin %d x cout %d needs more than 160 KB of LDS for the weights", cin, cout);
 #define PUNET_SMALL_FWD_ATTR(K)                                                                                                \

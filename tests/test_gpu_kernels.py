@@ -146,7 +146,11 @@ def test_conv_dgrad_wgrad(dev, B, H, W, c0, c1, cout, k):
     assert rel_err(wunpack(dw2), exp) < 5e-6
 
 
-@pytest.mark.parametrize("cin,cout,B,H,W", [(1, 64, 2, 16, 24), (2, 64, 1, 32, 32), (3, 32, 2, 8, 40), (1, 32, 1, 8, 8)])
+@pytest.mark.parametrize("cin,cout,B,H,W", [(1, 64, 2, 16, 24), (2, 64, 1, 32, 32), (3, 32, 2, 8, 40), (1, 32, 1, 8, 8),
+                                             # round 5: 2..4 channels run the first layer on the matrix cores (conv3x3_first_mfma_kernel): ragged
+                                             # 16-pixel blocks, a single row / column, four channels (two K-steps), wide first layers
+                                             (3, 64, 2, 13, 37), (4, 64, 1, 9, 50), (4, 128, 2, 5, 17), (2, 256, 1, 3, 16), (3, 64, 1, 1, 1),
+                                             (3, 16, 1, 40, 3), (4, 8, 1, 6, 6)])
 def test_conv_small(dev, cin, cout, B, H, W):
     g = torch.Generator().manual_seed(4)
     x = torch.randn(B, cin, H, W, generator=g)

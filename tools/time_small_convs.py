@@ -10,7 +10,7 @@ def t(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for (B, H, W, cin) in [(4, 512, 512, 1), (4, 512, 512, 2), (4, 704, 704, 3), (4, 704, 704, 4)]:
+for (B, H, W, cin) in [(4, 512, 512, 1), (4, 704, 704, 1), (4, 512, 512, 2), (4, 512, 512, 3), (4, 704, 704, 3), (4, 704, 704, 4)]:
     cout = 64
     x = torch.randn(B, H, W, cin, device="cuda"); w = torch.randn(3, 3, cin, cout, device="cuda"); b = torch.randn(cout, device="cuda")
     y = torch.empty(B, H, W, cout, device="cuda"); dz = torch.randn(B, H, W, cout, device="cuda")
