@@ -271,6 +271,102 @@ __global__ __launch_bounds__(256) void conv3x3_first_mfma_kernel(const float* __
     if (amax_out) punet_amax_publish_block256(amax_out, am, sam);  // (block-uniform)
 }
 
+// The weight / bias gradient of the same layers on the matrix cores:  dW[k][co] = sum_px P[px][k] dz[px][co]  with the PIXELS as the
+// contracted dimension (32 per MFMA): A = P^T - lane (row k = 16 kb + l16, g) gathers patch element k of 8 consecutive pixels -,
+// B = dz - lane (column co = 16 cb + l16, g) loads channel co of the same 8 pixels (16 lanes = 64 contiguous bytes of one pixel).
+// Row 9 CIN of P is the constant 1 of every valid pixel: its row of the product is the bias gradient.  Six-product arithmetic
+// as everywhere; a wave keeps its [KB x 16][cout] accumulators over all its 32-pixel blocks, the four waves of a workgroup are summed
+// through LDS, and the workgroup writes ONE partial slab in conv3x3_small_wgrad_kernel's layout (the same slab reduction follows).
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_first_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                                      float* __restrict__ partial, int cout, int B, int H, int W) {
+    constexpr int KT = 9 * CIN, ROWS = KT + 1, KB = (ROWS + 15) / 16;
+    extern __shared__ __attribute__((aligned(16))) float sredf[];  // [4 waves][KB * 16][cout]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, g = lane >> 4;
+    const int ncb = cout / 16;  // <= 8 (host)
+    fm_f32x4 acc[KB][8];
+#pragma unroll
+    for (int i = 0; i < KB * 8; ++i) acc[i / 8][i % 8] = fm_f32x4{0.f, 0.f, 0.f, 0.f};
+    // this lane's patch rows k = 16 kb + l16: tap offset relative to the pixel, (dy, dx) for the border test; row KT = the ones row
+    int roff[KB], rdy[KB], rdx[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int k = 16 * kb + l16, t = k / CIN, c = k % CIN;
+        const bool real = k < KT;
+        rdy[kb] = real ? t / 3 - 1 : (k == KT ? 0 : 0x40000000);
+        rdx[kb] = real ? t % 3 - 1 : 0;
+        roff[kb] = real ? ((t / 3 - 1) * W + (t % 3 - 1)) * CIN + c : 0;
+    }
+    const int bpr = (W + 31) / 32;  // 32-pixel blocks per image row
+    const long nblk = (long)B * H * bpr;
+    for (long blk = (long)blockIdx.x * 4 + wave; blk < nblk; blk += (long)gridDim.x * 4) {
+        const int row = (int)(blk / bpr), bx = (int)(blk % bpr);  // row = b * H + py
+        const int py = row % H, px0 = bx * 32 + 8 * g;              // this lane's 8 pixels: px0 .. px0 + 7
+        const float* xr = x + (size_t)row * W * CIN;
+        const float* dr = dz + (size_t)row * W * cout;
+        uint4 af[KB][3];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const bool ones = 16 * kb + l16 == KT;
+            const bool rowin = (unsigned)(py + rdy[kb]) < (unsigned)H;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int px = px0 + j;
+                const bool in = rowin && px < W && (unsigned)(px + rdx[kb]) < (unsigned)W;
+                const float xv = in && !ones ? xr[px * CIN + roff[kb]] : 0.f;
+                v[j] = ones ? (px < W ? 1.f : 0.f) : xv;
+            }
+            split3_pair<3>(v[0], v[1], af[kb][0].x, af[kb][1].x, af[kb][2].x);
+            split3_pair<3>(v[2], v[3], af[kb][0].y, af[kb][1].y, af[kb][2].y);
+            split3_pair<3>(v[4], v[5], af[kb][0].z, af[kb][1].z, af[kb][2].z);
+            split3_pair<3>(v[6], v[7], af[kb][0].w, af[kb][1].w, af[kb][2].w);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) {
+            if (cb < ncb) {  // (wave-uniform)
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int px = px0 + j;
+                    v[j] = px < W ? dr[(size_t)px * cout + 16 * cb + l16] : 0.f;
+                }
+                uint4 bh, bm, bl;
+                split3_pair<3>(v[0], v[1], bh.x, bm.x, bl.x);
+                split3_pair<3>(v[2], v[3], bh.y, bm.y, bl.y);
+                split3_pair<3>(v[4], v[5], bh.z, bm.z, bl.z);
+                split3_pair<3>(v[6], v[7], bh.w, bm.w, bl.w);
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    fm_f32x4 c = acc[kb][cb];
+                    c = punet_mfma16<false>(af[kb][1], bm, c);  // mm
+                    c = punet_mfma16<false>(af[kb][0], bl, c);  // hl
+                    c = punet_mfma16<false>(af[kb][2], bh, c);  // lh
+                    c = punet_mfma16<false>(af[kb][0], bm, c);  // hm
+                    c = punet_mfma16<false>(af[kb][1], bh, c);  // mh
+                    c = punet_mfma16<false>(af[kb][0], bh, c);  // hh
+                    acc[kb][cb] = c;
+                }
+            }
+        }
+    }
+    // D[row = k][col = co]: lane (l16 = co within the block, g) holds rows 4 g .. 4 g + 3
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+            if (cb < ncb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sredf[((size_t)wave * KB * 16 + 16 * kb + 4 * g + r) * cout + 16 * cb + l16] = acc[kb][cb][r];
+    __syncthreads();
+    for (int u = tid; u < ROWS * cout; u += 256) {
+        const int k = u / cout, co = u % cout;
+        float sum = sredf[(size_t)k * cout + co];
+        for (int wv = 1; wv < 4; ++wv) sum += sredf[((size_t)wv * KB * 16 + k) * cout + co];
+        partial[((size_t)blockIdx.x * ROWS + k) * cout + co] = sum;
+    }
+}
+
 // $PUNET_FIRST_MFMA=0: the VALU kernel for every channel count, as before round 5 (same-box A/B); read once per process
 static int punet_first_mfma() {
     static const int on = [] {
@@ -385,6 +481,32 @@ extern "C" int punet_conv3x3_small_wgrad(const float* x, int cin, const float* d
                     "punet_conv3x3_small_wgrad: cout/4 must divide 64 (got cout=%d)", cout);
     const size_t P = (size_t)B * H * W;
     PUNET_CHECK_ARG(P < (1ull << 31), "punet_conv3x3_small_wgrad: more than 2^31 pixels");
+    if (cin >= 2 && cin <= 4 && cout % 16 == 0 && cout <= 128 && punet_first_mfma()) {  // 2..4 channels: on the matrix cores (round 5)
+        const int rows = 9 * cin + 1, kb = (rows + 15) / 16;
+        const size_t shmem = (size_t)4 * kb * 16 * cout * sizeof(float);
+        const long nblk = (long)B * H * ceil_div(W, 32);
+        int gridm = (int)((nblk + 3) / 4 < SMALL_WGRAD_BLOCKS ? (nblk + 3) / 4 : SMALL_WGRAD_BLOCKS);
+#define PUNET_FIRST_WGRAD(CI)                                                                                                        \
+    do {                                                                                                                             \
+        if (shmem > 48 * 1024 && hipFuncSetAttribute((const void*)conv3x3_first_wgrad_mfma_kernel<CI>,                               \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess) {        \
+            (void)hipGetLastError();                                                                                                 \
+            punet_set_error("punet_conv3x3_small_wgrad: cannot opt in to %zu bytes of dynamic LDS", shmem);                          \
+            return PUNET_ERR_HIP;                                                                                                    \
+        }                                                                                                                            \
+        conv3x3_first_wgrad_mfma_kernel<CI><<<gridm, 256, shmem, stream>>>(x, dz, workspace, cout, B, H, W);                         \
+    } while (0)
+        switch (cin) {
+            case 2: PUNET_FIRST_WGRAD(2); break;
+            case 3: PUNET_FIRST_WGRAD(3); break;
+            default: PUNET_FIRST_WGRAD(4); break;
+        }
+#undef PUNET_FIRST_WGRAD
+        PUNET_LAUNCH_CHECK("conv3x3_first_wgrad_mfma");
+        const size_t slab = (size_t)rows * cout;
+        return punet_launch_reduce_slabs_pair(workspace, slab, 9 * cin, cout, cin, cin, 0, dw, workspace + (size_t)9 * cin * cout, slab, dbias,
+                                              gridm, accumulate, scale, stream);
+    }
     const int groups = cout / 4;
     int grid = B * H;  // one image row per block and round
     if (grid > SMALL_WGRAD_BLOCKS) grid = SMALL_WGRAD_BLOCKS;
