@@ -73,6 +73,10 @@ int punet_conv_dgrad_t(const float* dz, int cout, const float* wt, int cin_total
 /* punet_conv3x3_splitk only, OR-ed into opts: how the last partial round is dealt - 0 (default) = by the library's cost model,
  * 1 = never split, n >= 2 = runs of n - 1 quads (a quad = 32 contracted channels) whatever the cost model says (tests, A/B) */
 #define PUNET_X6_SPLITK(n) ((int)(n) << 16)
+/* OR-ed into opts: lay the tiles of THIS launch over each image separately even where the library would fold the batch into one
+ * virtual image row (round 5: widths that are not whole 32-pixel tiles while B * W is - 88, 176, 48 ... at batch 4; results are
+ * bit-identical either way, tests/test_gpu_fold.py) */
+#define PUNET_X6_NOFOLD (1 << 24)
 /* compute units of the current device (grids are sized from it: persistent kernels launch one residency round) */
 int punet_compute_units(void);
 int punet_split_weights_x6(const float* w, void* planes, long plane_stride, int cin, int cout, int ksize, int mode,

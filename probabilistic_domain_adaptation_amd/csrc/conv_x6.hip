@@ -75,12 +75,17 @@ struct ConvX6Args {
     unsigned* sk_cnt;
     int sk_whole, sk_P, sk_D, sk_Q;
     unsigned m_D, m_nq;
+    // FOLD instantiations of conv3x3_x6b_kernel (round 5): tiles walk the VIRTUAL image row of B * W pixels (vtiles_x = B * W / 32
+    // tiles, m_ty = its reciprocal, m_W = the reciprocal of W for "which image")
+    int vtiles_x;
+    unsigned m_W;
 };
 
 static inline unsigned x6_magic(int d) { return (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
 
 struct TileInfo {
     int b, ty0, tx0, n0;
+    int bpos;  // FOLD: first tile column that belongs to image b + 1 (1..31), 32 = the tile lies inside image b
 };
 
 union U4 {
@@ -592,11 +597,19 @@ __device__ unsigned long long punet_x6b_trace[4 * 16];  // top barrier passed, o
 #endif
 // F16: fp16 planes (NP = 2: h + l, products hh + hl + lh; NP = 1: h) with power-of-two scaling from the operands' amax slots
 // (common.h) instead of bf16 planes; the epilogue rescales by the exact inverse and publishes the output's amax.
-template <int NP, bool DGRAD, bool F16 = false>
+// FOLD (round 5; tile WIDTH quantization): a 32-pixel tile column does not fit image widths such as 88 or 176 (2.75 and 5.5 tiles:
+// 8.3 % of those levels' MFMAs multiplied padding).  The FOLD instantiation lays the tiles over the VIRTUAL row of all B images side by
+// side (B * W pixels: 352 = 11 tiles, 704 = 22), so a tile may hold the last columns of image b and the first ones of image b + 1.
+// The LDS halo image of such a tile gets TWO extra columns where the images meet - the right halo of b and the left halo of b + 1,
+// which the staging fills with zeros by its ordinary out-of-image test - so every tap still sits at a fixed offset from its pixel;
+// lanes right of the seam read 2 columns further (one per-lane add per K-step and 16-pixel half), the epilogue maps a lane's
+// tile column back to (image, x).  Per pixel the contraction runs in the same order as in the unfolded kernel: results are
+// bit-identical (tests/test_gpu_fold.py).  Chosen by the host when W % 32 != 0, W >= 32 and B * W % 32 == 0.
+template <int NP, bool DGRAD, bool F16 = false, bool FOLD = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     static_assert(!F16 || NP <= 2, "fp16 operands: one or two planes");
     constexpr int KS = 3, KK = 9, PAD = 1;
-    constexpr int HTH = TH + KS - 1, HTW = TW + KS - 1;
+    constexpr int HTH = TH + KS - 1, HTW = TW + KS - 1 + (FOLD ? 2 : 0);
     constexpr int NPIX = HTH * HTW;
     // LDS image: rows 48 pixels apart.  ds_read_b128 is served in groups that mix lanes of lane groups (0, 1) and (2, 3);
     // two lane groups of one instruction are conflict-free iff their pixel offsets agree mod 16 (256 bytes = all 64 banks).
@@ -655,12 +668,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 #else
         const unsigned ut = (unsigned)__builtin_amdgcn_readfirstlane(tile);
         const unsigned s1 = ntn == 1 ? ut : __umulhi(ut, a.m_ntn);  // (the reciprocal of 1 does not fit 32 bits)
-        const unsigned s2 = tiles_x == 1 ? s1 : __umulhi(s1, a.m_tx);
-        const unsigned s3 = tiles_y == 1 ? s2 : __umulhi(s2, a.m_ty);
         t.n0 = (int)(ut - s1 * (unsigned)ntn) * TN;
-        t.tx0 = (int)(s1 - s2 * (unsigned)tiles_x) * TW;
-        t.ty0 = (int)(s2 - s3 * (unsigned)tiles_y) * TH;
-        t.b = (int)s3;
+        if constexpr (FOLD) {
+            const unsigned s2 = a.vtiles_x == 1 ? s1 : __umulhi(s1, a.m_tx);  // (m_tx = the reciprocal of vtiles_x here)
+            const unsigned vx0 = (s1 - s2 * (unsigned)a.vtiles_x) * TW;        // virtual column of the tile's first pixel
+            t.ty0 = (int)s2 * TH;
+            t.b = (int)__umulhi(vx0, a.m_W);                                    // vx0 / W  (W >= 32 > 1)
+            t.tx0 = (int)(vx0 - (unsigned)t.b * (unsigned)a.W);
+            t.bpos = min(a.W - t.tx0, TW);
+        } else {
+            const unsigned s2 = tiles_x == 1 ? s1 : __umulhi(s1, a.m_tx);
+            const unsigned s3 = tiles_y == 1 ? s2 : __umulhi(s2, a.m_ty);
+            t.tx0 = (int)(s1 - s2 * (unsigned)tiles_x) * TW;
+            t.ty0 = (int)(s2 - s3 * (unsigned)tiles_y) * TH;
+            t.b = (int)s3;
+            t.bpos = TW;
+        }
 #endif
         return t;
     };
@@ -693,10 +716,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
             const int pix = u / (CK / 4);
 #endif
             const int py = pix / HTW, px = pix % HTW;
-            const int gy = ti.ty0 + py - PAD, gx = ti.tx0 + px - PAD;
+            const int gy = ti.ty0 + py - PAD;
+            int gx = ti.tx0 + px - PAD, ioff = 0;
+            if constexpr (FOLD) {
+                // halo columns 0 .. bpos + 1 belong to image b (column bpos + 1 = its right halo: x = W, zero), bpos + 2 .. to image
+                // b + 1 (column bpos + 2 = its left halo: x = -1, zero); without a seam (bpos = 32) columns 34, 35 are never read
+                const bool second = px > ti.bpos + 1;
+                gx = second ? px - 3 - ti.bpos : gx;
+                ioff = second && ti.b + 1 < a.B ? a.H * a.W : 0;  // (never beyond the last image, even for a column nobody reads)
+            }
             xin[it] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            xpix[it] = min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1);  // inside image xb (32-bit); the image
-        }                                                                          // base is a uniform 64-bit term
+            xpix[it] = min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1) + ioff;  // inside image xb (32-bit); the image
+        }                                                                                 // base is a uniform 64-bit term
 #if X6B_PLANE_IN == 2
         xbase0 = reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.x0) + (size_t)ti.b * ((size_t)(a.H * a.W) * 8));
         xbase1 = reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.x1) + (size_t)ti.b * ((size_t)(a.H * a.W) * 8));
@@ -824,6 +855,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         {X6B_O(3, 4), X6B_O(3, 7), X6B_O(3, 5), X6B_O(3, 8)}};
 #undef X6B_O
 #undef X6B_P
+    int fold_adj[2] = {0, 0};
+    auto set_fold = [&](const TileInfo& t) __attribute__((always_inline)) {
+        if constexpr (FOLD) {
+            fold_adj[0] = l16 >= t.bpos ? 2 : 0;
+            fold_adj[1] = 16 + l16 >= t.bpos ? 2 : 0;
+        }
+    };
     int koffA[9], koffB[9];
 #pragma unroll
     for (int ki = 0; ki < 9; ++ki) {
@@ -837,6 +875,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     auto kstep = [&](auto ki_c, auto&& mid) __attribute__((always_inline)) {
         constexpr int P1 = NP > 1 ? 1 : 0, P2 = NP > 2 ? 2 : 0;
         const int offA = koffA[decltype(ki_c)::value], offB = koffB[decltype(ki_c)::value];
+        // FOLD: lanes whose pixel lies right of the seam read two LDS columns further (fold_adj: per lane and 16-pixel half, set
+        // at the tile switch)
+        const int offAh[2] = {offA + (FOLD ? fold_adj[0] : 0), offA + (FOLD ? fold_adj[1] : 0)};
         // all four channel blocks' weight fragments resident (48 registers), pixel fragments streamed with one block of
         // lookahead (12 + 12): every fragment is read once per K-step (24 reads per 96 MFMAs, as in the 32 x 32 x 16 kernel)
         U4 bw[NP][4];
@@ -846,13 +887,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
             for (int cb = 0; cb < 4; ++cb) bw[p][cb].u = sW[p * WSLAB + offB + 16 * cb];
         U4 ax[2][NP];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) ax[0][p].u = sX[offA + p * NPIXA + (2 * wave) * HTWP];
+        for (int p = 0; p < NP; ++p) ax[0][p].u = sX[offAh[0] + p * NPIXA + (2 * wave) * HTWP];
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb) {
             if (pb < 3) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    ax[(pb + 1) & 1][p].u = sX[offA + p * NPIXA + (2 * wave + ((pb + 1) >> 1)) * HTWP + 16 * ((pb + 1) & 1)];
+                    ax[(pb + 1) & 1][p].u = sX[offAh[(pb + 1) & 1] + p * NPIXA + (2 * wave + ((pb + 1) >> 1)) * HTWP + 16 * ((pb + 1) & 1)];
             }
             U4(&A)[NP] = ax[pb & 1];
 #pragma unroll
@@ -890,9 +931,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        const int gx = ti.tx0 + 16 * h + l16, gy = ti.ty0 + 2 * wave + m;
-                        const unsigned gd = (unsigned)(((((ti.b * a.H + gy) * tiles_x + (ti.tx0 / TW)) * ntn + (ti.n0 / TN)) << 6) +
-                                                       16 * h + l16 + 32 * (g & 1));
+                        int gx = ti.tx0 + 16 * h + l16, bb = ti.b;
+                        const int gy = ti.ty0 + 2 * wave + m;
+                        if constexpr (FOLD) {
+                            const bool second = 16 * h + l16 >= ti.bpos;
+                            gx = second ? 16 * h + l16 - ti.bpos : gx;
+                            bb += second ? 1 : 0;
+                        }
+                        // dword of (pixel, channel) in the punet_gate_dwords layout: block {row, x / 32, channel block}, slot x % 32
+                        const unsigned gd = (unsigned)(((((bb * a.H + gy) * tiles_x + (gx >> 5)) * ntn + (ti.n0 / TN)) << 6) +
+                                                       (gx & 31) + 32 * (g & 1));
                         gpre[2 * h + m] = (gy < a.H && gx < a.W) ? a.gate_bits[gd] : 0u;
                     }
             }
@@ -922,10 +970,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 #if X6B_TIMING & 4
         if (acc[0][0][0] != 1.2345e-30f) return;
 #endif
-        // uniform 64-bit base of image ti.b in the output-shaped tensors; offsets inside the image stay 32-bit
+        // uniform 64-bit base of image ti.b in the output-shaped tensors; offsets inside the image stay 32-bit (FOLD: a lane right
+        // of the seam adds one image - the host checks that two images stay below 2^31 elements)
         const size_t img = (size_t)ti.b * ((size_t)(a.H * a.W) * N);
         float* const yb = a.y + img;
         const float* const mb = a.mask ? a.mask + img : nullptr;
+        const unsigned img1 = (unsigned)(a.H * a.W) * (unsigned)N;  // elements of one image
         f32x4 bq[4];
         if (!DGRAD) {
 #pragma unroll
@@ -936,15 +986,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         };
 #pragma unroll
         for (int h = 0; h < 2; ++h) {  // 16-pixel half of the row; rows m = 0, 1 are pixel blocks h and 2 + h
-            const int gx = ti.tx0 + 16 * h + l16;
+            int gx = ti.tx0 + 16 * h + l16, bb = ti.b;
+            unsigned ioff = 0u;  // FOLD: this lane's pixel belongs to image b + 1
+            if constexpr (FOLD) {
+                const bool second = 16 * h + l16 >= ti.bpos;
+                gx = second ? 16 * h + l16 - ti.bpos : gx;
+                bb += second ? 1 : 0;
+                ioff = second ? img1 : 0u;
+            }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int gy = ti.ty0 + 2 * wave + m;
                 const bool pix_in = F || (gy < a.H && gx < a.W);
-                // dword of (pixel, channel) in the punet_gate_dwords layout: (x % 32) + 32 * ((c % 8) / 4) = 16 h + l16 + 32 (g & 1)
-                const unsigned gd = (unsigned)(((((ti.b * a.H + gy) * tiles_x + (ti.tx0 / TW)) * ntn + (ti.n0 / TN)) << 6) +
-                                               16 * h + l16 + 32 * (g & 1));
-                const unsigned pbase = (unsigned)((gy * a.W + gx) * N + cq);
+                // dword of (pixel, channel) in the punet_gate_dwords layout: block {row, x / 32, channel block}, slot
+                // (x % 32) + 32 * ((c % 8) / 4) (= 16 h + l16 + 32 (g & 1) without FOLD: tiles start at multiples of 32)
+                const unsigned gd = (unsigned)(((((bb * a.H + gy) * tiles_x + (gx >> 5)) * ntn + (ti.n0 / TN)) << 6) +
+                                               (gx & 31) + 32 * (g & 1));
+                const unsigned pbase = (unsigned)((gy * a.W + gx) * N + cq) + ioff;
                 unsigned gin = 0u, gout = 0u;
                 if (DGRAD && f_gate_bits) gin = gpre[2 * h + m];  // epilogue_prefetch (0 outside the image)
 #pragma unroll
@@ -985,7 +1043,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
             if (!DGRAD && f_pool) {  // uniform: AvgPool2d(2, 2) of the output, order ((y00 + y01) + y10) + y11
                 const int gy0 = ti.ty0 + 2 * wave;
                 const bool ok0 = F || (gy0 < a.H && gx < a.W);
-                const unsigned qbase = (unsigned)(((gy0 >> 1) * (a.W >> 1) + (gx >> 1)) * N + cq);
+                const unsigned qbase = (unsigned)(((gy0 >> 1) * (a.W >> 1) + (gx >> 1)) * N + cq) + (ioff >> 2);
                 float* const qb = a.pool_out + (img >> 2);  // the pooled image has a quarter of the pixels
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
@@ -1007,7 +1065,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 #if X6B_GENERAL_EPILOGUE
         epilogue_ec(ti, X6B_EC(0));
 #else
-        const bool full = ti.ty0 + TH <= a.H && ti.tx0 + TW <= a.W && ti.n0 + TN <= N;  // block-uniform
+        // block-uniform (FOLD: every column of a tile is a pixel of image b or b + 1 - the virtual row is whole tiles)
+        const bool full = ti.ty0 + TH <= a.H && (FOLD || ti.tx0 + TW <= a.W) && ti.n0 + TN <= N;
         if (!DGRAD) {
             if (full && a.relu && a.bias && !a.mask) {
                 if (a.gate_out) {
@@ -1067,6 +1126,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     item_decode(item, tile, ch, ch_end, part, more);
     TileInfo ti = decode(tile);
     retarget(ti);
+    set_fold(ti);
     wlane = wlane_of(ti);
     prefetch(ch);
 #pragma unroll
@@ -1195,6 +1255,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
         ch_end = nce;
         part = npart;
         more = nmore;
+        if (FOLD && ph == 3 && ntile != tile) set_fold(nti);  // (after this tile's last fragment reads and its epilogue)
         ti = nti;
         return !has_next;
     };
@@ -1840,6 +1901,13 @@ constexpr size_t SK_COUNTER_BYTES = 4096, SK_SLOT_BYTES = 16 * 256 * 16;
 struct SkPlan {
     int whole, P, D, Q;
 };
+static int punet_fold_on() {  // $PUNET_FOLD=0: tiles per image as before round 5 (A/B; results are bit-identical either way)
+    static const int on = [] {
+        const char* e = getenv("PUNET_FOLD");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
 static int punet_splitk_mode() {  // $PUNET_SPLITK: 0 = never split, n >= 1 = runs of n quads wherever a launch has a partial round
     static const int m = [] {    // (A/B); unset = by the cost model; read once per process (an A/B switch like PUNET_CONV1X1_WIDE)
         const char* e = getenv("PUNET_SPLITK");
@@ -2065,11 +2133,40 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
             gridb = pl.whole >= cap ? cap : (pl.whole > pl.P ? pl.whole : pl.P);
         }
     }
+    // FOLD: tiles over the virtual row of all B images when the width is not whole 32-pixel tiles but B * W is (kernel comment)
+    bool fold = false;
+    if (ksize == 3 && shape == 16 && (c0 + c1) % 32 == 0 && (f16.planes == 0 ? planes == 3 : f16.planes == 2) && punet_fold_on() && !((opts >> 24) & 1) &&
+        W % TW != 0 && W >= TW && ((long)B * W) % TW == 0 && (!pool_out || W % 2 == 0) &&
+        2ull * (unsigned long long)H * W * (c0 > c1 ? (c0 > n_out ? c0 : n_out) : (c1 > n_out ? c1 : n_out)) < (1ull << 31)) {
+        fold = true;
+        a.vtiles_x = (int)((long)B * W / TW);
+        a.m_W = x6_magic(W);
+        a.m_tx = x6_magic(a.vtiles_x);
+        a.ntiles = ceil_div(H, TH) * a.vtiles_x * ceil_div(n_out, TN);
+    }
+    if (fold) {  // (the tile count changed: plan the stream-K tail again)
+        a.sk_whole = a.ntiles; a.sk_P = 0; a.sk_D = 1; a.sk_Q = 0; a.m_D = 0u; a.m_nq = 0u;
+        gridb = a.ntiles < cap ? a.ntiles : cap;
+        if (scratch) {
+            const SkPlan pl = sk_plan(a.ntiles, cap, (c0 + c1) / CK, scratch_bytes, (opts >> 16) & 0xff);
+            if (pl.P > 0) {
+                a.sk_whole = pl.whole; a.sk_P = pl.P; a.sk_D = pl.D; a.sk_Q = pl.Q;
+                a.m_D = pl.D > 1 ? x6_magic(pl.D) : 0u; a.m_nq = x6_magic((c0 + c1) / 32);
+                a.sk_cnt = (unsigned*)scratch;
+                a.sk_ws = (float*)((char*)scratch + SK_COUNTER_BYTES);
+                gridb = pl.whole >= cap ? cap : (pl.whole > pl.P ? pl.whole : pl.P);
+            }
+        }
+    }
     const int xrb = gridb % 8 == 0;
     if (f16.planes == 2) {  // "f16x3": the 16 x 16 x 32 kernel where the channel count allows, as for the bf16 planes
         if (shape == 16 && (c0 + c1) % 32 == 0) {
             a.xcd_remap = xrb;
-            if (dgrad) conv3x3_x6b_kernel<2, true, true><<<gridb, 256, 0, st>>>(a); else conv3x3_x6b_kernel<2, false, true><<<gridb, 256, 0, st>>>(a);
+            if (fold) {
+                if (dgrad) conv3x3_x6b_kernel<2, true, true, true><<<gridb, 256, 0, st>>>(a); else conv3x3_x6b_kernel<2, false, true, true><<<gridb, 256, 0, st>>>(a);
+            } else {
+                if (dgrad) conv3x3_x6b_kernel<2, true, true><<<gridb, 256, 0, st>>>(a); else conv3x3_x6b_kernel<2, false, true><<<gridb, 256, 0, st>>>(a);
+            }
         } else {
             if (dgrad) conv3x3_x6_kernel<2, true, 3, false, true><<<grid, 256, 0, st>>>(a);
             else conv3x3_x6_kernel<2, false, 3, false, true><<<grid, 256, 0, st>>>(a);
@@ -2096,7 +2193,11 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
         // bound by its staging, not by the matrix cores, and measured 15 % slower through this kernel.)
         a.xcd_remap = xrb;
         if (planes == 3) {
-            if (dgrad) conv3x3_x6b_kernel<3, true><<<gridb, 256, 0, st>>>(a); else conv3x3_x6b_kernel<3, false><<<gridb, 256, 0, st>>>(a);
+            if (fold) {
+                if (dgrad) conv3x3_x6b_kernel<3, true, false, true><<<gridb, 256, 0, st>>>(a); else conv3x3_x6b_kernel<3, false, false, true><<<gridb, 256, 0, st>>>(a);
+            } else {
+                if (dgrad) conv3x3_x6b_kernel<3, true><<<gridb, 256, 0, st>>>(a); else conv3x3_x6b_kernel<3, false><<<gridb, 256, 0, st>>>(a);
+            }
         } else {
             if (dgrad) conv3x3_x6b_kernel<2, true><<<gridb, 256, 0, st>>>(a); else conv3x3_x6b_kernel<2, false><<<gridb, 256, 0, st>>>(a);
         }

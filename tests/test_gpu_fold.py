@@ -1,0 +1,118 @@
+"""GPU: the FOLD instantiations of the 3x3 split-plane kernels (round 5, tile WIDTH quantization).  When the image width is not a
+whole number of 32-pixel tiles but B * W is (88 or 176 pixels at batch 4: the deep levels of 704 x 704 patches), the tiles are
+laid over the virtual row of all B images side by side; a tile may hold the last columns of one image and the first ones of the
+next, with two zero columns between them in its LDS halo image.  Per pixel the contraction runs in the same order as in the
+unfolded launch, so everything must be BIT-identical to it: outputs, ReLU gate bits, the fused 2x2 average, the gated and
+accumulating input gradient, two sources, the fp16-plane arithmetic, and the combination with the stream-K tail."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+NOFOLD = 1 << 24
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from probabilistic_domain_adaptation_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def S():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(L, x0, x1, planes, nw, n_row, n_off, bias, y, n_out, gate_bits, gate_out, pool, accumulate, relu, B, H, W, extra_opts, scratch,
+         f16=0, amax=(None, None, None, None)):
+    L.call("punet_conv3x3_splitk", x0.data_ptr(), x0.shape[-1], x1.data_ptr() if x1 is not None else None,
+           x1.shape[-1] if x1 is not None else 0, planes.data_ptr(), nw, n_row, n_off, bias.data_ptr() if bias is not None else None, 0,
+           y.data_ptr(), n_out, None, gate_bits.data_ptr() if gate_bits is not None else None,
+           gate_out.data_ptr() if gate_out is not None else None, pool.data_ptr() if pool is not None else None, accumulate, relu,
+           B, H, W, L.x6_opts(6, 16) | extra_opts, f16, *[t.data_ptr() if t is not None else None for t in amax],
+           scratch.data_ptr() if scratch is not None else None, 4 * scratch.numel() if scratch is not None else 0, S())
+
+
+# (B, H, W, c0, c1, cout): W % 32 != 0, W >= 32, B * W % 32 == 0; heights ragged against the 8-row tiles as well
+CASES = [(4, 88, 88, 64, 0, 64), (4, 22, 88, 128, 0, 192), (2, 16, 48, 64, 64, 64), (4, 9, 40, 96, 0, 96), (8, 6, 36, 32, 0, 32),
+         (4, 44, 176, 64, 0, 128), (2, 10, 80, 160, 32, 200), (4, 130, 72, 32, 0, 64)]
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,cout", CASES)
+@pytest.mark.parametrize("splitk", [1, 0, 2], ids=["whole", "planned-tail", "forced-tail"])
+def test_folded_launch_is_bit_identical_to_the_unfolded_one(L, B, H, W, c0, c1, cout, splitk):
+    g = torch.Generator().manual_seed(B * 100 + W)
+    cin = c0 + c1
+    X0 = torch.randn(B, H, W, c0, generator=g).cuda()
+    X1 = torch.randn(B, H, W, c1, generator=g).cuda() if c1 else None
+    w = (torch.randn(3, 3, cin, cout, generator=g) / np.sqrt(cin * 9)).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    nw = 9 * cin * cout
+    pf = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+    pd = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+    L.call("punet_split_weights_x6", w.data_ptr(), pf.data_ptr(), nw, cin, cout, 3, 0, S())
+    L.call("punet_split_weights_x6", w.data_ptr(), pd.data_ptr(), nw, cin, cout, 3, 1, S())
+    scratch = torch.zeros(L.call("punet_conv_splitk_scratch_bytes") // 4, dtype=torch.int32, device="cuda")
+    sk = splitk << 16
+    even = H % 2 == 0 and W % 2 == 0
+    res = {}
+    for tag, extra in (("fold", sk), ("per-image", sk | NOFOLD)):
+        Y = torch.full((B, H, W, cout), float("nan"), device="cuda")
+        gate = torch.zeros(L.call("punet_gate_dwords", B, H, W, cout), dtype=torch.int32, device="cuda")
+        pool = torch.full((B, H // 2, W // 2, cout), float("nan"), device="cuda") if even else None
+        call(L, X0, X1, pf, nw, cout, 0, b, Y, cout, None, gate, pool, 0, 1, B, H, W, extra, scratch)
+        # input gradient w.r.t. the first source, gated by the bits the forward of a layer with c0 outputs would have published,
+        # accumulating into an existing tensor
+        gx = torch.randint(-2 ** 31, 2 ** 31 - 1, (L.call("punet_gate_dwords", B, H, W, c0),), generator=g, dtype=torch.int64).to(torch.int32).cuda() \
+            if tag == "fold" else res["gx"]
+        res["gx"] = gx
+        DZ = torch.randn(B, H, W, cout, generator=torch.Generator().manual_seed(5)).cuda()
+        DX = torch.randn(B, H, W, c0, generator=torch.Generator().manual_seed(6)).cuda()
+        call(L, DZ, None, pd, nw, cin, 0, None, DX, c0, gx, None, None, 1, 0, B, H, W, extra, scratch)
+        torch.cuda.synchronize()
+        res[tag] = (Y, gate, pool, DX)
+    for i, name in enumerate(("output", "gate bits", "pooled output", "input gradient")):
+        a_, b_ = res["fold"][i], res["per-image"][i]
+        if a_ is None:
+            continue
+        assert torch.isfinite(a_.float()).all() if a_.dtype.is_floating_point else True, name
+        assert torch.equal(a_, b_), f"{name}: folded and per-image launches differ"
+    assert int(scratch[:1024].abs().sum().item()) == 0
+
+
+def test_folded_launch_against_torch_and_in_fp16_planes(L):
+    """One folded shape against PyTorch's convolution (the unfolded kernel is held to it elsewhere; this guards against both being
+    wrong the same way), and the two-plane fp16 arithmetic folded vs per image, amax publication included."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    B, H, W, cin, cout = 4, 24, 88, 64, 96
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, w, b, padding=1))
+    X = x.permute(0, 2, 3, 1).contiguous().cuda()
+    Wp = w.permute(2, 3, 1, 0).contiguous().cuda()
+    nw = 9 * cin * cout
+    pf = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+    L.call("punet_split_weights_x6", Wp.data_ptr(), pf.data_ptr(), nw, cin, cout, 3, 0, S())
+    Y = torch.empty(B, H, W, cout, device="cuda")
+    call(L, X, None, pf, nw, cout, 0, b.cuda(), Y, cout, None, None, None, 0, 1, B, H, W, 1 << 16, None)
+    torch.cuda.synchronize()
+    got = Y.permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max().item() / ref.abs().max().item() < 2e-6
+    # fp16 planes
+    ph = torch.zeros(3 * nw, dtype=torch.bfloat16, device="cuda")
+    aw = torch.zeros(1, device="cuda")
+    L.call("punet_split_weights_f16", Wp.data_ptr(), ph.data_ptr(), nw, cin, cout, 0, aw.data_ptr(), S())
+    ax = X.abs().max().reshape(1).contiguous()
+    outs = []
+    for extra in (1 << 16, (1 << 16) | NOFOLD):
+        Yh = torch.empty(B, H, W, cout, device="cuda")
+        ay = torch.zeros(1, device="cuda")
+        call(L, X, None, ph, nw, cout, 0, b.cuda(), Yh, cout, None, None, None, 0, 1, B, H, W, extra, None, f16=2, amax=(ax, None, aw, ay))
+        torch.cuda.synchronize()
+        outs.append((Yh, ay))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert (outs[0][0].permute(0, 3, 1, 2).cpu() - ref).abs().max().item() / ref.abs().max().item() < 3e-6
