@@ -604,7 +604,8 @@ __device__ unsigned long long punet_x6b_trace[4 * 16];  // top barrier passed, o
 // which the staging fills with zeros by its ordinary out-of-image test - so every tap still sits at a fixed offset from its pixel;
 // lanes right of the seam read 2 columns further (one per-lane add per K-step and 16-pixel half), the epilogue maps a lane's
 // tile column back to (image, x).  Per pixel the contraction runs in the same order as in the unfolded kernel: results are
-// bit-identical (tests/test_gpu_fold.py).  Chosen by the host when W % 32 != 0, W >= 32 and B * W % 32 == 0.
+// bit-identical (tests/test_gpu_fold.py).  Chosen by the host when W % 32 != 0, W >= 32 and the virtual row needs fewer tiles than
+// the B images do (the row may end inside its last tile: what lies beyond is zero on the way in and not stored on the way out).
 template <int NP, bool DGRAD, bool F16 = false, bool FOLD = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
     static_assert(!F16 || NP <= 2, "fp16 operands: one or two planes");
@@ -723,7 +724,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
                 // b + 1 (column bpos + 2 = its left halo: x = -1, zero); without a seam (bpos = 32) columns 34, 35 are never read
                 const bool second = px > ti.bpos + 1;
                 gx = second ? px - 3 - ti.bpos : gx;
-                ioff = second && ti.b + 1 < a.B ? a.H * a.W : 0;  // (never beyond the last image, even for a column nobody reads)
+                ioff = second && ti.b + 1 < a.B ? a.H * a.W : 0;  // (never beyond the last image: the virtual row may end inside a tile)
+                gx = second && ti.b + 1 >= a.B ? -1 : gx;         // ... and what lies beyond it is zero
             }
             xin[it] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             xpix[it] = min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1) + ioff;  // inside image xb (32-bit); the image
@@ -941,7 +943,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
                         // dword of (pixel, channel) in the punet_gate_dwords layout: block {row, x / 32, channel block}, slot x % 32
                         const unsigned gd = (unsigned)(((((bb * a.H + gy) * tiles_x + (gx >> 5)) * ntn + (ti.n0 / TN)) << 6) +
                                                        (gx & 31) + 32 * (g & 1));
-                        gpre[2 * h + m] = (gy < a.H && gx < a.W) ? a.gate_bits[gd] : 0u;
+                        gpre[2 * h + m] = (gy < a.H && gx < a.W && bb < a.B) ? a.gate_bits[gd] : 0u;
                     }
             }
         } else {
@@ -997,7 +999,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int gy = ti.ty0 + 2 * wave + m;
-                const bool pix_in = F || (gy < a.H && gx < a.W);
+                const bool pix_in = F || (gy < a.H && gx < a.W && bb < a.B);
                 // dword of (pixel, channel) in the punet_gate_dwords layout: block {row, x / 32, channel block}, slot
                 // (x % 32) + 32 * ((c % 8) / 4) (= 16 h + l16 + 32 (g & 1) without FOLD: tiles start at multiples of 32)
                 const unsigned gd = (unsigned)(((((bb * a.H + gy) * tiles_x + (gx >> 5)) * ntn + (ti.n0 / TN)) << 6) +
@@ -1042,7 +1044,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
             }
             if (!DGRAD && f_pool) {  // uniform: AvgPool2d(2, 2) of the output, order ((y00 + y01) + y10) + y11
                 const int gy0 = ti.ty0 + 2 * wave;
-                const bool ok0 = F || (gy0 < a.H && gx < a.W);
+                const bool ok0 = F || (gy0 < a.H && gx < a.W && bb < a.B);
                 const unsigned qbase = (unsigned)(((gy0 >> 1) * (a.W >> 1) + (gx >> 1)) * N + cq) + (ioff >> 2);
                 float* const qb = a.pool_out + (img >> 2);  // the pooled image has a quarter of the pixels
 #pragma unroll
@@ -1065,8 +1067,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 #if X6B_GENERAL_EPILOGUE
         epilogue_ec(ti, X6B_EC(0));
 #else
-        // block-uniform (FOLD: every column of a tile is a pixel of image b or b + 1 - the virtual row is whole tiles)
-        const bool full = ti.ty0 + TH <= a.H && (FOLD || ti.tx0 + TW <= a.W) && ti.n0 + TN <= N;
+        // block-uniform (FOLD: every column of a tile is a pixel of image b or b + 1, except behind the end of the virtual row)
+        const bool full = ti.ty0 + TH <= a.H && (FOLD ? (ti.bpos == TW || ti.b + 1 < a.B) : ti.tx0 + TW <= a.W) && ti.n0 + TN <= N;
         if (!DGRAD) {
             if (full && a.relu && a.bias && !a.mask) {
                 if (a.gate_out) {
@@ -2136,10 +2138,10 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
     // FOLD: tiles over the virtual row of all B images when the width is not whole 32-pixel tiles but B * W is (kernel comment)
     bool fold = false;
     if (ksize == 3 && shape == 16 && (c0 + c1) % 32 == 0 && (f16.planes == 0 ? planes == 3 : f16.planes == 2) && punet_fold_on() && !((opts >> 24) & 1) &&
-        W % TW != 0 && W >= TW && ((long)B * W) % TW == 0 && (!pool_out || W % 2 == 0) &&
+        W % TW != 0 && W >= TW && ceil_div(B * W, TW) < B * ceil_div(W, TW) && (!pool_out || W % 2 == 0) &&
         2ull * (unsigned long long)H * W * (c0 > c1 ? (c0 > n_out ? c0 : n_out) : (c1 > n_out ? c1 : n_out)) < (1ull << 31)) {
         fold = true;
-        a.vtiles_x = (int)((long)B * W / TW);
+        a.vtiles_x = ceil_div(B * W, TW);
         a.m_W = x6_magic(W);
         a.m_tx = x6_magic(a.vtiles_x);
         a.ntiles = ceil_div(H, TH) * a.vtiles_x * ceil_div(n_out, TN);
