@@ -2078,6 +2078,17 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
                           const void* gate_bits, void* gate_out, int accumulate, int relu, int B, int H, int W, int opts,
                           void* stream, float* pool_out, const F16Scales& f16, void* scratch, size_t scratch_bytes) {
     PUNET_CHECK_ARG(x0 && wplanes && y, "punet_conv3x3_x6: null pointer");
+    // A 1x1 convolution does not see the image geometry: where nothing else refers to it (no gate bits in or out, no fp32 mask, no
+    // per-image bias) the launch walks the flat list of B * H * W pixels as ONE image of 32-pixel rows - no partial tile columns
+    // (K5x's GEMMs at 704 x 704 run on 44 / 88 / 176-pixel-wide tensors: 1.4 / 2.75 / 5.5 tiles; round 5).  Same products in the
+    // same order per pixel: bit-identical.
+    if (ksize == 1 && !mask && !gate_bits && !gate_out && !pool_out && bias_img_stride == 0 && B > 0 && H > 0 && W > 0 && W % TW != 0 &&
+        ((long)B * H * W) % TW == 0 && (long)B * H * W / TW < (1l << 24) &&
+        (unsigned long long)B * H * W * (c0 > n_out ? c0 : n_out) < (1ull << 31)) {
+        H = (int)((long)B * H * W / TW);
+        W = TW;
+        B = 1;
+    }
     PUNET_CHECK_ARG(f16.planes == 0 || ((f16.planes == 1 || f16.planes == 2) && ksize == 3),
                     "punet_conv3x3_f16: planes must be 2 (hh + hl + lh) or 1, 3x3 only");
     const int planes = punet_x6_planes_of(opts), shape = punet_x6_shape_of(opts);

@@ -46,9 +46,12 @@ class Scratch:
         return int(self.t[:1024].abs().sum().item()) == 0
 
 
+NOFOLD = 1 << 24  # PUNET_X6_NOFOLD: this module is about the rounds of per-image tiling (tests/test_gpu_fold.py covers the folded launches)
+
+
 def sk_opts(L, run):
     """run = quads (32 contracted channels) per workgroup run of the tail: PUNET_X6_SPLITK(run + 1); 0 = the library's plan, -1 = never"""
-    return L.x6_opts(6, 16) | ((run + 1 if run > 0 else (1 if run < 0 else 0)) << 16)
+    return L.x6_opts(6, 16) | ((run + 1 if run > 0 else (1 if run < 0 else 0)) << 16) | NOFOLD
 
 
 def conv(L, sc, x0, x1, planes, nw, n_row, n_off, bias, y, n_out, gate_bits, gate_out, pool, accumulate, relu, B, H, W, parts,
