@@ -160,3 +160,33 @@ def test_mean_teacher_iteration_with_folded_levels_against_the_oracle(L):
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     for k, v in Ps.items():
         assert (sd[k] - v.detach()).abs().max().item() <= 2.5e-3, k  # (Adam's first step: sign(g) * lr; 2 lr where g is ~0)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(4, 44, 44, 128, 576), (4, 11, 88, 64, 64), (2, 8, 50, 32, 96)])
+def test_pure_1x1_launches_walk_the_flat_pixel_list(L, B, H, W, cin, cout):
+    """A 1x1 convolution without gate bits, mask or per-image bias does not see the image geometry: the launcher runs it over the
+    flat list of B * H * W pixels as one image of 32-pixel rows (K5x's GEMMs at 704 x 704: 44 / 88 / 176-pixel-wide tensors).  The
+    result equals PyTorch's and, bit for bit, the same call on the explicitly flattened tensor."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / np.sqrt(cin)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, w, b)
+    X = x.permute(0, 2, 3, 1).contiguous().cuda()
+    Wp = w.permute(2, 3, 1, 0).contiguous().cuda()
+    nw = cin * cout
+    pf = torch.empty(3 * nw, dtype=torch.bfloat16, device="cuda")
+    L.call("punet_split_weights_x6", Wp.data_ptr(), pf.data_ptr(), nw, cin, cout, 1, 0, S())
+    bd = b.cuda()
+    Y = torch.full((B, H, W, cout), float("nan"), device="cuda")
+    L.call("punet_conv1x1_x6_gated", X.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, bd.data_ptr(), 0, Y.data_ptr(), cout, None, None,
+           None, 0, 0, B, H, W, S())
+    Y2 = torch.full((B, H, W, cout), float("nan"), device="cuda")
+    n = B * H * W
+    L.call("punet_conv1x1_x6_gated", X.data_ptr(), cin, None, 0, pf.data_ptr(), nw, cout, 0, bd.data_ptr(), 0, Y2.data_ptr(), cout, None, None,
+           None, 0, 0, 1, n // 32, 32, S())
+    torch.cuda.synchronize()
+    assert torch.equal(Y, Y2)
+    got = Y.permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max().item() / ref.abs().max().item() < 2e-6
