@@ -238,3 +238,15 @@ static inline hipError_t punet_zero_fill(void* p, size_t bytes, hipStream_t st) 
     return hipGetLastError();
 }
 
+
+// $PUNET_FOLD (an A/B switch, read once per process): tiles / strips laid over the virtual row of all B images where the width is
+// not whole 32-pixel tiles (round 5; conv3x3_x6b_kernel<..., FOLD> and wgrad3x3_x6r_kernel<..., FOLD>).  unset / 1 = wherever it
+// saves tiles, 0 = per image as before round 5, 2 = the forward / input-gradient kernel only (whose results are bit-identical either
+// way; the weight gradient's agree to rounding).
+static inline int punet_fold_mode() {
+    static const int m = [] {
+        const char* e = getenv("PUNET_FOLD");
+        return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
+    }();
+    return m;
+}

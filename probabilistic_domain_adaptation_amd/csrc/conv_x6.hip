@@ -1903,13 +1903,6 @@ constexpr size_t SK_COUNTER_BYTES = 4096, SK_SLOT_BYTES = 16 * 256 * 16;
 struct SkPlan {
     int whole, P, D, Q;
 };
-static int punet_fold_on() {  // $PUNET_FOLD=0: tiles per image as before round 5 (A/B; results are bit-identical either way)
-    static const int on = [] {
-        const char* e = getenv("PUNET_FOLD");
-        return !(e && e[0] == '0');
-    }();
-    return on;
-}
 static int punet_splitk_mode() {  // $PUNET_SPLITK: 0 = never split, n >= 1 = runs of n quads wherever a launch has a partial round
     static const int m = [] {    // (A/B); unset = by the cost model; read once per process (an A/B switch like PUNET_CONV1X1_WIDE)
         const char* e = getenv("PUNET_SPLITK");
@@ -2148,7 +2141,7 @@ static int conv_x6_launch(int ksize, const float* x0, int c0, const float* x1, i
     }
     // FOLD: tiles over the virtual row of all B images when the width is not whole 32-pixel tiles but B * W is (kernel comment)
     bool fold = false;
-    if (ksize == 3 && shape == 16 && (c0 + c1) % 32 == 0 && (f16.planes == 0 ? planes == 3 : f16.planes == 2) && punet_fold_on() && !((opts >> 24) & 1) &&
+    if (ksize == 3 && shape == 16 && (c0 + c1) % 32 == 0 && (f16.planes == 0 ? planes == 3 : f16.planes == 2) && punet_fold_mode() != 0 && !((opts >> 24) & 1) &&
         W % TW != 0 && W >= TW && ceil_div(B * W, TW) < B * ceil_div(W, TW) && (!pool_out || W % 2 == 0) &&
         2ull * (unsigned long long)H * W * (c0 > c1 ? (c0 > n_out ? c0 : n_out) : (c1 > n_out ? c1 : n_out)) < (1ull << 31)) {
         fold = true;

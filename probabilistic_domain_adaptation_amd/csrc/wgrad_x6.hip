@@ -55,7 +55,7 @@ constexpr int WTH = 2, WTW = 32, WC = 64;
 #define PUNET_WGRAD_SB 0  // (one region per pixel group was needed at 255 VGPRs; at 180 the free schedule is 0.5-1 % faster)
 #endif
 constexpr int GT0 = PUNET_WGRAD_T0, GT1 = 9 - GT0, GTMAX = GT0 > GT1 ? GT0 : GT1;
-constexpr int HTH = WTH + 2, HTW = WTW + 2;
+constexpr int HTH = WTH + 2, HTW = WTW + 2, HTW_BASE = HTW;
 constexpr int NPX = HTH * HTW;   // 136 halo pixels
 constexpr int NPD = WTH * WTW;   // 64 pixels
 constexpr int ROWB = 64;         // bytes per [pixel][32 ch] bf16 row
@@ -359,11 +359,14 @@ constexpr int DIMGR = DSLOTS * WTW * ROWB;  // one (plane, co block) ring image:
 
 // xa / db: per-lane byte offsets of the tile's four X rows / two dZ rows, INCLUDING the wave's channel-block image (the
 // remaining compile-time part - plane, column, tap - then fits the 16-bit offset field of the LDS instruction)
-template <int NP, int T0, int NT, bool F16, typename F>
+// XR = bytes of one (plane, ci block) ring image (XIMGR; larger in the FOLD instantiation, whose rows have two more pixels);
+// xs (FOLD only): per lane, the byte shift of its pixels where they lie right of the image seam, by 16-pixel column half
+template <int NP, int T0, int NT, bool F16, int XR, bool FOLD, typename F>
 __device__ __forceinline__ void tile_mfma_r(f32x16 (&acc)[GTMAX], const char* sX, const char* sD, const int (&xa)[4],
-                                            const int (&db)[2], F&& between) {
+                                            const int (&db)[2], const int (&xs)[2], F&& between) {
     constexpr int P1 = NP > 1 ? 1 : 0, P2 = NP > 2 ? 2 : 0;
     constexpr int NS = NPD / 16;
+    constexpr int XIMGR = XR;  // (shadows the namespace constant inside this function)
 #if PUNET_WGRAD_PREFETCH
     // Software-pipelined by hand: the fragments of step i + 1 (one tap of one 16-pixel group; the dZ fragments too where a
     // new pixel group begins) are read BEFORE the six MFMAs of step i are issued, into the other half of a double buffer.
@@ -385,7 +388,8 @@ __device__ __forceinline__ void tile_mfma_r(f32x16 (&acc)[GTMAX], const char* sX
 #pragma unroll
         for (int p = 0; p < NP; ++p)
 #pragma unroll
-            for (int r = 0; r < 2; ++r) aa[p].half4[r] = tr_read(sX, p * 2 * XIMGR + (col0 + kx + 4 * r) * ROWB + xa[row + ky]);
+            for (int r = 0; r < 2; ++r)
+                aa[p].half4[r] = tr_read(sX, p * 2 * XIMGR + (col0 + kx + 4 * r) * ROWB + xa[row + ky] + (FOLD ? xs[col0 / 16] : 0));
     };
     load_b(0, b[0]);
 #pragma unroll
@@ -432,7 +436,7 @@ __device__ __forceinline__ void tile_mfma_r(f32x16 (&acc)[GTMAX], const char* sX
             for (int p = 0; p < NP; ++p)
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
-                    a[p].half4[r] = tr_read(sX, p * 2 * XIMGR + (col0 + kx + 4 * r) * ROWB + xa[row + ky]);
+                    a[p].half4[r] = tr_read(sX, p * 2 * XIMGR + (col0 + kx + 4 * r) * ROWB + xa[row + ky] + (FOLD ? xs[col0 / 16] : 0));
             f32x16 c = acc[tt];
             if (NP > 2) {
                 c = punet_mfma32<F16>(a[P1].u, b[P1].u, c);  // mm
@@ -459,10 +463,18 @@ __device__ __forceinline__ void tile_mfma_r(f32x16 (&acc)[GTMAX], const char* sX
 // X16 (one plane only; the "bf16s" / "f16s" fast modes): the activation operand x holds bf16 / fp16 - its staging is a plain
 // 8-byte copy.  F16: fp16 planes (NP <= 2) scaled by exact powers of two from the operands' amax slots (common.h; an operand
 // STORED as fp16 is unscaled), the slabs are written rescaled.
-template <int NP, bool X16 = false, bool F16 = false>
+// FOLD (round 5; see conv3x3_x6b_kernel): the 32-pixel column strips run over the VIRTUAL row of all B images side by side where
+// the width is not whole strips (88 = 2.75, 176 = 5.5); a strip that holds the end of image b and the start of image b + 1 gets two
+// zero pixels per X row at the seam (the right halo of b, the left halo of b + 1: filled by the ordinary out-of-image test), and
+// the fragment reads of pixels right of the seam are shifted by those two pixels.  Widths that are multiples of 8 only (a
+// fragment's 4-pixel sub-blocks then never straddle a seam).  Sums run over the same pixels; only their ORDER differs from the
+// per-image launch (strips are cut elsewhere), i.e. results agree to rounding, not bit for bit.
+template <int NP, bool X16 = false, bool F16 = false, bool FOLD = false>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
     static_assert(!X16 || NP == 1, "16-bit activation storage exists for the one-plane arithmetic only");
     static_assert(!F16 || NP <= 2, "fp16 operands: one or two planes");
+    constexpr int HTW = ::HTW_BASE + (FOLD ? 2 : 0);            // (shadow the namespace constants: rows of the X ring are 36 pixels)
+    constexpr int XIMGR = XSLOTS * HTW * ROWB;
     float sxs = 1.f, sds = 1.f;  // F16: operand scales (block-uniform)
     if constexpr (F16) {
         if (!X16) sxs = punet_f16_scale_from(a.amax_x);
@@ -493,8 +505,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
     const int ci_tile = blockIdx.y / co_tiles, co_tile = blockIdx.y % co_tiles;
     const int ci0 = ci_tile * WC, co0 = co_tile * WC;
     const int slice = blockIdx.x;
-    const int tiles_x = (a.W + WTW - 1) / WTW, tiles_y = (a.H + WTH - 1) / WTH;
-    const int ntiles = a.B * tiles_x * tiles_y;
+    const int tiles_x = FOLD ? (a.B * a.W + WTW - 1) / WTW : (a.W + WTW - 1) / WTW, tiles_y = (a.H + WTH - 1) / WTH;
+    const int ntiles = (FOLD ? 1 : a.B) * tiles_x * tiles_y;  // FOLD: tiles_x strips over the virtual row of all images
     const int t_begin = (int)((long)slice * ntiles / a.nslices), t_end = (int)((long)(slice + 1) * ntiles / a.nslices);
 
     f32x16 acc[GTMAX];
@@ -568,27 +580,54 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
         constexpr int TA = decltype(ta_c)::value, TB = decltype(tb_c)::value;
         for (int t = t_begin; t < t_end;) {
             const int sid = t / tiles_y, ty_s = t - sid * tiles_y;
-            const int txi = sid % tiles_x, b = sid / tiles_x;
             const int run = min(t_end - t, tiles_y - ty_s);  // tiles of this run: down the strip until its end or the slice's
-            const int tx0 = txi * WTW;
-            const float* const xb = X16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.x) + (size_t)b * ((size_t)(a.H * a.W) * a.cs))
-                                        : a.x + (size_t)b * ((size_t)(a.H * a.W) * a.cs);
+            // FOLD: the strip starts at pixel tx0 of image b and holds `seam` pixels of it (>= 32: no seam); the rest is image b + 1
+            const int b = FOLD ? (sid * WTW) / a.W : sid / tiles_x;
+            const int tx0 = FOLD ? sid * WTW - b * a.W : (sid % tiles_x) * WTW;
+            const int seam = a.W - tx0;
+            const bool have2 = b + 1 < a.B;
+            auto x_image = [&](int bb) __attribute__((always_inline)) {
+                return X16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(a.x) + (size_t)bb * ((size_t)(a.H * a.W) * a.cs))
+                           : a.x + (size_t)bb * ((size_t)(a.H * a.W) * a.cs);
+            };
+            const float* const xb = x_image(b);
             const float* const dbp = a.dz + (size_t)b * ((size_t)(a.H * a.W) * a.cout);
+            const float* const xb2 = FOLD ? x_image(have2 ? b + 1 : b) : xb;
+            const float* const dbp2 = FOLD ? a.dz + (size_t)(have2 ? b + 1 : b) * ((size_t)(a.H * a.W) * a.cout) : dbp;
+            // position p of an X ring row (0 .. HTW - 1) / pixel j of a dZ row -> x inside its image; returns "of the second image"
+            // (the positions seam + 1 and seam + 2 come out as x = W and x = -1: the two halo zeros at the seam)
+            auto xpos = [&](int p, int& gx_) __attribute__((always_inline)) -> bool {
+                const bool second = FOLD && p >= seam + 2;
+                gx_ = second ? p - seam - 3 : tx0 + p - 1;
+                return second;
+            };
+            auto dpos = [&](int j, int& gx_) __attribute__((always_inline)) -> bool {
+                const bool second = FOLD && j >= seam;
+                gx_ = second ? j - seam : tx0 + j;
+                return second;
+            };
+            int xs[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) xs[c] = FOLD && 16 * c + 8 * half >= seam ? 2 * ROWB : 0;
 
             // ---- prologue of the run: the first tile's four X rows and two dZ rows in full (slots 0..3 / 0..1)
             __syncthreads();  // the previous run's last readers are done
             for (int u = tid; u < 4 * HTW * C4; u += 512) {
                 const int c4 = u % C4, pix = u / C4, hr = pix / HTW, px = pix % HTW;
-                const int gy = 2 * ty_s - 1 + hr, gx_ = tx0 + px - 1;
-                const bool in = gy >= 0 && gy < a.H && gx_ >= 0 && gx_ < a.W && ci0 + c4 * 4 < a.cs;
-                const float4 v = load_x(xb, gy, gx_, c4);
+                int gx_;
+                const bool second = xpos(px, gx_);
+                const int gy = 2 * ty_s - 1 + hr;
+                const bool in = gy >= 0 && gy < a.H && gx_ >= 0 && gx_ < a.W && ci0 + c4 * 4 < a.cs && (!second || have2);
+                const float4 v = load_x(second ? xb2 : xb, gy, gx_, c4);
                 put_x((c4 >> 3) * XIMGR + (hr * HTW + px) * ROWB + (c4 & 7) * 8, v, in);
             }
             for (int u = tid; u < 2 * WTW * C4; u += 512) {
                 const int c4 = u % C4, pix = u / C4, row = pix / WTW, px = pix % WTW;
-                const int gy = 2 * ty_s + row, gx_ = tx0 + px;
-                const bool in = gy < a.H && gx_ < a.W && co0 + c4 * 4 < a.cout;
-                float4 v = load_d(dbp, gy, gx_, c4);
+                int gx_;
+                const bool second = dpos(px, gx_);
+                const int gy = 2 * ty_s + row;
+                const bool in = gy < a.H && gx_ < a.W && co0 + c4 * 4 < a.cout && (!second || have2);
+                float4 v = load_d(second ? dbp2 : dbp, gy, gx_, c4);
                 if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
                 put_planes(sD, DIMGR, (c4 >> 3) * DIMGR + (row * WTW + px) * ROWB + (c4 & 7) * 8, v, sds);
@@ -627,20 +666,24 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
                 for (int it = 0; it < XIT; ++it) {
                     const int u = min(tid + it * 512, XNEW - 1);
                     const int c4 = u % C4, pix = u / C4, nr = pix / HTW, px = pix % HTW;
-                    const int gy = 2 * ty + 3 + nr, gx_ = tx0 + px - 1;
-                    const bool in = gy < a.H && gx_ >= 0 && gx_ < a.W && ci0 + c4 * 4 < a.cs;
-                    rx[it] = load_x(xb, gy, gx_, c4);
+                    int gx_;
+                    const bool second = xpos(px, gx_);
+                    const int gy = 2 * ty + 3 + nr;
+                    const bool in = gy < a.H && gx_ >= 0 && gx_ < a.W && ci0 + c4 * 4 < a.cs && (!second || have2);
+                    rx[it] = load_x(second ? xb2 : xb, gy, gx_, c4);
                     inmask = in ? inmask | (1u << it) : inmask;
                 }
     #pragma unroll
                 for (int it = 0; it < DIT; ++it) {
                     const int u = tid + it * 512;
                     const int c4 = u % C4, pix = u / C4, nr = pix / WTW, px = pix % WTW;
-                    const int gy = 2 * ty + 2 + nr, gx_ = tx0 + px;
+                    int gx_;
+                    const bool second = dpos(px, gx_);
+                    const int gy = 2 * ty + 2 + nr;
                     // (the run's last tile stages too - no branch in the MFMA stream, the rows land in ring slots nobody reads
                     // - but its dZ rows count as outside: they must not enter the column sums a second time)
-                    const bool in = has_next && gy < a.H && gx_ < a.W && co0 + c4 * 4 < a.cout;
-                    rd[it] = load_d(dbp, gy, gx_, c4);
+                    const bool in = has_next && gy < a.H && gx_ < a.W && co0 + c4 * 4 < a.cout && (!second || have2);
+                    rd[it] = load_d(second ? dbp2 : dbp, gy, gx_, c4);
                     inmask = in ? inmask | (1u << (XIT + it)) : inmask;
                 }
                 auto commit_x = [&](int it) __attribute__((always_inline)) {
@@ -670,7 +713,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
                         for (int it = 0; it < DIT; ++it) commit_d(it);
                     }
                 };
-                tile_mfma_r<NP, TA, TB, F16>(acc, sX, sD, xa, db_, between);
+                tile_mfma_r<NP, TA, TB, F16, XIMGR, FOLD>(acc, sX, sD, xa, db_, xs, between);
                 WGTR(1);
                 __syncthreads();
                 WGTR(2);
@@ -700,8 +743,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
     }
 }
 
-constexpr int smem_bytes_r(int np) {
-    const int operands = np * 2 * (XIMGR + DIMGR);  // 127,488 B at NP = 3
+constexpr int smem_bytes_r(int np, bool fold = false) {
+    const int operands = np * 2 * (XIMGR + (fold ? XSLOTS * 2 * ROWB : 0) + DIMGR);  // 127,488 B at NP = 3 (FOLD: 132,096 B)
     return operands > 512 * 16 ? operands : 512 * 16;
 }
 
@@ -732,6 +775,18 @@ int launch_wgrad_f16(const WgradX6Args& a, dim3 grid, hipStream_t stream) {
         return PUNET_ERR_HIP;
     }
     wgrad3x3_x6r_kernel<NP, X16, true><<<grid, 512, smem_bytes_r(NP), stream>>>(a);
+    return PUNET_OK;
+}
+
+// the FOLD instantiations: the three-plane bf16 and the two-plane fp16 arithmetic (fp32 storage)
+template <int NP, bool F16>
+int launch_wgrad_fold(const WgradX6Args& a, dim3 grid, hipStream_t stream) {
+    if (hipFuncSetAttribute((const void*)wgrad3x3_x6r_kernel<NP, false, F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            smem_bytes_r(NP, true)) != hipSuccess) {
+        punet_set_error("punet_conv_wgrad_x6: cannot reserve %d bytes of LDS", smem_bytes_r(NP, true));
+        return PUNET_ERR_HIP;
+    }
+    wgrad3x3_x6r_kernel<NP, false, F16, true><<<grid, 512, smem_bytes_r(NP, true), stream>>>(a);
     return PUNET_OK;
 }
 
@@ -815,7 +870,11 @@ static int wgrad_x6_impl(bool x16, const float* x, int cs, const float* dz, int 
     a.B = B; a.H = H; a.W = W; a.nslices = nslices;
     a.amax_x = amax_x; a.amax_dz = amax_dz;
     dim3 grid(nslices, ceil_div(cs, WC) * ceil_div(cout, WC));
-    const int rc0 = f16planes == 2 ? launch_wgrad_f16<2, false>(a, grid, stream)
+    // FOLD (see the kernel): strips over the virtual row of all images where that saves strips; x6 and f16x3 only
+    const bool fold = punet_fold_mode() == 1 && !(opts & PUNET_X6_NOFOLD) && !x16 && (f16planes == 2 || (f16planes == 0 && planes == 3)) &&
+                      W >= WTW && W % 8 == 0 && ceil_div(B * W, WTW) < B * ceil_div(W, WTW) && PUNET_WGRAD_ROLLING;
+    const int rc0 = fold ? (f16planes == 2 ? launch_wgrad_fold<2, true>(a, grid, stream) : launch_wgrad_fold<3, false>(a, grid, stream))
+                    : f16planes == 2 ? launch_wgrad_f16<2, false>(a, grid, stream)
                     : f16planes == 1 ? (x16 ? launch_wgrad_f16<1, true>(a, grid, stream) : launch_wgrad_f16<1, false>(a, grid, stream))
                     : x16 ? launch_wgrad_x16(a, grid, stream)
                     : planes == 3 ? launch_wgrad<3>(a, grid, stream)

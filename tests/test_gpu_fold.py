@@ -147,9 +147,12 @@ def test_mean_teacher_iteration_with_folded_levels_against_the_oracle(L):
         y_en, z_en = m.sample_consensus(n, 0.9, 0.1, True, e_t.to(dev))                    # the Python engine
     torch.cuda.synchronize()
     assert torch.equal(y_rt, y_en) and torch.equal(z_rt, z_en)
-    safe = ((torch.sigmoid(O.sample_logits(Po, cfg, x1, e_t)) - 0.9).abs().min(0).values > 1e-5) if hasattr(O, "sample_logits") else None
     assert (y_rt.cpu() - yo).abs().max().item() < 1e-4
-    assert int((z_rt.cpu() != zo).sum()) <= (0 if safe is None else int((~safe).sum()))
+    with torch.no_grad():  # the consensus mask may differ where a sample's sigmoid lies within 1e-5 of a threshold (fp32 summation order)
+        st = O.punet_forward(Po, cfg, x1, None, False)
+        probs = torch.sigmoid(torch.stack([O.punet_sample(Po, cfg, st, e_t[i]) for i in range(n)]))
+    safe = ((probs - 0.9).abs().min(0).values > 1e-5) & ((probs - 0.1).abs().min(0).values > 1e-5)
+    assert torch.equal(z_rt.cpu()[safe], zo[safe])
     t = copy.deepcopy(m)
     opt = FusedAdam(m, lr=1e-3)
     loss, y, z, _ = FU.fused_self_training_step(m, t, opt, x1.to(dev), x2.to(dev), n, True, e_t.to(dev), e_s.to(dev), 0.99, 1e-5)
@@ -190,3 +193,49 @@ def test_pure_1x1_launches_walk_the_flat_pixel_list(L, B, H, W, cin, cout):
     assert torch.equal(Y, Y2)
     got = Y.permute(0, 3, 1, 2).cpu()
     assert (got - ref).abs().max().item() / ref.abs().max().item() < 2e-6
+
+
+# ---- the weight-gradient kernel's FOLD instantiation: 32-pixel column strips over the virtual row of all images (widths that are
+# multiples of 8).  The sums run over the same pixels in another ORDER than the per-image launch: equal to rounding, not bit for bit.
+WG_CASES = [(4, 88, 88, 64, 64), (4, 44, 176, 64, 128), (2, 16, 48, 64, 64), (3, 12, 88, 64, 64), (4, 9, 40, 96, 96),
+            (2, 10, 80, 160, 32), (4, 130, 72, 32, 64), (5, 7, 56, 32, 64), (2, 3, 104, 8, 16), (7, 5, 40, 24, 40)]
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", WG_CASES)
+def test_folded_weight_gradient_against_autograd_and_the_unfolded_launch(L, B, H, W, cin, cout):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B * 1000 + W)
+    x = (torch.randn(B, cin, H, W, generator=g) * torch.exp2(torch.randint(-6, 6, (B, cin, H, W), generator=g).float())).double()
+    dz = (torch.randn(B, cout, H, W, generator=g) * torch.exp2(torch.randint(-6, 6, (B, cout, H, W), generator=g).float())).double()
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w, b, padding=1).backward(dz)
+    X = x.float().permute(0, 2, 3, 1).contiguous().cuda()
+    DZ = dz.float().permute(0, 2, 3, 1).contiguous().cuda()
+    ns = L.call("punet_wgrad_x6_slices", cin, cout, B, H, W)
+    ws = torch.empty(L.call("punet_wgrad_workspace_floats", cin, cout, 3, ns), device="cuda")
+    out = {}
+    for name, opts in (("fold", 0), ("nofold", NOFOLD)):
+        dw = torch.full((3, 3, cin, cout), float("nan"), device="cuda")
+        db = torch.full((cout,), float("nan"), device="cuda")
+        L.call("punet_conv_wgrad_x6", X.data_ptr(), cin, DZ.data_ptr(), cout, dw.data_ptr(), cin, 0, db.data_ptr(), ws.data_ptr(), ns,
+               B, H, W, 0, 1.0, opts, S())
+        torch.cuda.synchronize()
+        out[name] = (dw.permute(3, 2, 0, 1).double().cpu(), db.double().cpu())
+    rel = lambda a_, b_: (a_ - b_).abs().max().item() / (b_.abs().max().item() + 1e-300)
+    for name in out:
+        assert rel(out[name][0], w.grad) < 5e-6, name
+        assert rel(out[name][1], b.grad) < 5e-6, name
+    assert rel(out["fold"][0], out["nofold"][0]) < 2e-6
+    # f16x3 planes (no options word at this entry point: folded whenever the shape is; unit scales, operands inside fp16's range)
+    xs, ds = x.float() * 2.0 ** -4, dz.float() * 2.0 ** -4
+    xs = torch.where(xs.abs() < 2.0 ** -10, torch.zeros_like(xs), xs)  # (nothing under fp16's two-plane resolution)
+    ds = torch.where(ds.abs() < 2.0 ** -10, torch.zeros_like(ds), ds)
+    w2 = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xs.double(), w2, None, padding=1).backward(ds.double())
+    X2, D2 = xs.permute(0, 2, 3, 1).contiguous().cuda(), ds.permute(0, 2, 3, 1).contiguous().cuda()
+    dw = torch.full((3, 3, cin, cout), float("nan"), device="cuda")
+    L.call("punet_conv_wgrad_f16", X2.data_ptr(), cin, D2.data_ptr(), cout, dw.data_ptr(), cin, 0, None, ws.data_ptr(), ns, B, H, W, 0, 1.0,
+           2, 0, None, None, S())
+    torch.cuda.synchronize()
+    assert rel(dw.permute(3, 2, 0, 1).double().cpu(), w2.grad) < 2e-5
