@@ -1294,8 +1294,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 // wave; the split moved between the MFMA groups (+1-2 %); a double-buffered form with the whole staging inside the K-step and one
 // barrier per phase measured +-0 (251 / 255 / 339 vs 249 / 259 / 342 us) and was removed again.  Without its epilogue the kernel
 // takes 207 / 187 / 207 us: writing z (151 / 302 / 604 MB: 9 cout floats per low-resolution pixel) costs 12 / 25 / 39 % - the
-// 512 x 512 block's GEMM is bound by that write, not by anything inside the K loop.  The stores are 32-byte pieces of 32 pixels;
-// as a timing-only permutation into whole 128-byte lines (X6W_TIMING bit 16) they measure 239 -> 234 / 255 -> 235 / 337 -> 304 us.
+// 512 x 512 block's GEMM is bound by that write, not by anything inside the K loop.  The stores were 32-byte pieces of 32 pixels;
+// as a timing-only permutation into whole 128-byte lines they measured 239 -> 234 / 255 -> 235 / 337 -> 304 us (round 5: built, X6W_LINES).
 // The transposed tile (pixels as A: a lane holds one channel of 16 pixels, whole lines by dword stores) was built, passed its
 // tests and measured 254 / 266 / 348 us on a box where the input gradients ran 2 % slower - four times the store instructions
 // queue in front of the next tile's loads; the float4 form needs an LDS transposition for ~0.1 ms of the step: not built
@@ -1304,7 +1304,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x6b_kernel(ConvX6Args a) {
 // read the 128 contiguous bytes of one pixel.  Tile, accumulator mapping, epilogue semantics and gate-bit layout are
 // conv3x3_x6_kernel's (weights as A, pixels as B: a lane holds one pixel and four consecutive channels per register quad).
 #ifndef X6W_TIMING  // timing-only builds of conv1x1_x6w_kernel (WRONG results): 1 = no epilogue, 2 = no split arithmetic, 4 = no activation
-#define X6W_TIMING 0  // loads, 8 = no MFMAs, 16 = the epilogue's stores as whole 128-byte lines (tools/ab_variants.sh conv_x6.hip ...)
+#define X6W_TIMING 0  // loads, 8 = no MFMAs (tools/ab_variants.sh conv_x6.hip ...)
+#endif
+// Round 5: the epilogue's stores as WHOLE 128-byte lines.  In the accumulator layout a lane holds one pixel and four consecutive
+// channels per register quad: a store instruction writes 32-byte pieces of 32 pixels.  Each 32-channel block of a wave's 32 pixels
+// now goes through a wave-private LDS buffer ([pixel][32 channels]) and is stored as 8 pixels x 128 contiguous bytes per
+// instruction (8 lanes per pixel); an accumulating input gradient reads the old values in the same pattern.  Same values, same
+// operations per element: bit-identical (X6W_LINES=0: the direct stores, A/B).
+#ifndef X6W_LINES
+#define X6W_LINES 1
 #endif
 // NB = 32-channel output blocks per wave: 2 = a 64-channel tile and 32-channel phases (above); 4 = a 128-channel tile and 16-channel
 // phases - the same 48 MFMAs per wave and phase, but every staged activation value and every pixel fragment serves twice the output
@@ -1331,6 +1339,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
     __shared__ uint4 smem[NSUB * (SUBX + SUBW)];      // 61,440 B (NB = 2) / 36,864 B (NB = 4)
     uint4* sX = smem;
     uint4* sW = smem + NSUB * SUBX;
+#if X6W_LINES
+    // the epilogue's transposition buffer, PRIVATE to a wave (no barrier): 32 pixels x 32 channels as rows of 9 float4 (a pitch of
+    // 144 bytes: the 16 lanes of a ds_write_b128 pass hit 16 different bank quads)
+    constexpr int EP = 9;
+    __shared__ float4 sE[4][32 * EP];
+#endif
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1509,20 +1523,39 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x6w_kernel(ConvX6Args a) {
                             v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
                         }
                     }
+#if X6W_LINES
+                    sE[wave][l31 * EP + 2 * rg + half] = v;  // (values of lanes / channels outside the tensor are never stored)
+                    if (!DGRAD && ok)
+                        gout |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u))
+                                << (16 * (nb & 1) + 4 * rg);
+                    if (rg == 3) {  // the block's 32 x 32 values are in the buffer: 8 pixels x 128 bytes per instruction
+                        const int cq = ti.n0 + nb * 32 + (lane & 7) * 4;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int px_ = 8 * i + (lane >> 3);
+                            float4 t = sE[wave][px_ * EP + (lane & 7)];
+                            if (gy < a.H && ti.tx0 + px_ < a.W && cq < N) {
+                                float* const dst = yb + (unsigned)((gy * a.W + ti.tx0 + px_) * N + cq);
+                                if (DGRAD && a.accumulate) {
+                                    const float4 o = *reinterpret_cast<const float4*>(dst);
+                                    t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+                                }
+                                *reinterpret_cast<float4*>(dst) = t;
+                            }
+                        }
+                    }
+#else
                     if (ok) {
                         if (DGRAD && a.accumulate) {
                             const float4 o = *reinterpret_cast<const float4*>(yb + pbase + ch);
                             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                         }
-#if X6W_TIMING & 16  // the same bytes in whole 128-byte lines per 8 lanes (a permutation of the tile: WRONG results)
-                        *reinterpret_cast<float4*>(yb + (unsigned)((gy * a.W + ti.tx0 + rg * 8 + (lane >> 3)) * N + ti.n0 + nb * 32 + (lane & 7) * 4)) = v;
-#else
                         *reinterpret_cast<float4*>(yb + pbase + ch) = v;
-#endif
                         if (!DGRAD)
                             gout |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u))
                                     << (16 * (nb & 1) + 4 * rg);
                     }
+#endif
                 }
             if (!DGRAD && a.gate_out && pix_in) {
 #pragma unroll
