@@ -826,8 +826,10 @@ def main():
                                "f32": ("pmc_hbm_traffic.json", "conv_mfma_kernel<3, false>")}[eng.conv_mode]
                     rdir = next(r for r in ("r05", "r04", "r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", r, fn)))
                     pm = json.load(open(os.path.join(ROOT, "profiles", rdir, fn)))
-                    if key not in pm["kernels"]:  # (round 3 added a template argument to the kernels' names)
-                        key = key.replace("<3, false>", "<3, false, false>")
+                    for extra in ("", ", false", ", false, false"):  # (rounds 3 and 5 added template arguments to the kernels' names)
+                        if key.replace("<3, false>", f"<3, false{extra}>") in pm["kernels"]:
+                            key = key.replace("<3, false>", f"<3, false{extra}>")
+                            break
                     traffic = round(pm["kernels"][key]["hbm_bytes_per_launch"])
                     import hashlib
                     hh = hashlib.sha256()

@@ -42,12 +42,12 @@ for r in rows:
         if n_adam == 25:
             break
     d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    if "conv3x3_x6b_kernel<3, false, false>" in k or "conv3x3_x6b_kernel<3, false>" in k:
+    if "conv3x3_x6b_kernel<3, false, false, false>" in k or "conv3x3_x6b_kernel<3, false, false>" in k or "conv3x3_x6b_kernel<3, false>" in k:
         tot += d
         n += 1
     key = short(k)
     per[key] = per.get(key, 0) + d
-json.dump({"kernel": "conv3x3_x6b_kernel<3, false, false> (NP = 3 planes, forward, bf16 planes)",
+json.dump({"kernel": "conv3x3_x6b_kernel<3, false, false, false> (NP = 3 planes, forward, bf16 planes, tiles per image)",
            "population": "the default command's dispatches up to the 25th Adam step (= the headline workload: 1 sizing + 3 warm-up + "
                          "10 graph-replayed + 1 + 10 eagerly launched steps), from the default command's kernel_trace.csv",
            "launches": n, "avg_us": tot / n / 1e3,
