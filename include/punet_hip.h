@@ -75,7 +75,8 @@ int punet_conv_dgrad_t(const float* dz, int cout, const float* wt, int cin_total
 #define PUNET_X6_SPLITK(n) ((int)(n) << 16)
 /* OR-ed into opts: lay the tiles of THIS launch over each image separately even where the library would fold the batch into one
  * virtual image row (round 5: widths that are not whole 32-pixel tiles while B * W is - 88, 176, 48 ... at batch 4; results are
- * bit-identical either way, tests/test_gpu_fold.py) */
+ * bit-identical either way, tests/test_gpu_fold.py).  punet_conv_wgrad_x6 honours the bit too: its 32-pixel column strips then run
+ * per image (folded and unfolded weight gradients sum the same pixels in another order: equal to rounding). */
 #define PUNET_X6_NOFOLD (1 << 24)
 /* compute units of the current device (grids are sized from it: persistent kernels launch one residency round) */
 int punet_compute_units(void);

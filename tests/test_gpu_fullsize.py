@@ -141,18 +141,22 @@ def test_training_step_fullsize_against_oracle(dev, B, channels, size):
     assert len(go) == 100 and not bad, bad
 
 
-def test_mean_teacher_step_batch4_512_is_bit_reproducible(dev):
+@pytest.mark.parametrize("channels,size", [(1, 512), (3, 704)], ids=["512x512x1", "704x704x3"])
+def test_mean_teacher_step_batch4_512_is_bit_reproducible(dev, channels, size):
     """The whole fused step (teacher MC pass, consensus, ELBO forward/backward, L2, Adam, EMA) at the bench shape, twice
-    from the same state: identical bits (no atomics, fixed reduction orders, fixed split-K order)."""
+    from the same state: identical bits (no atomics, fixed reduction orders, fixed split-K order).  Round 5: also at batch 4 of
+    704 x 704 x 3 (BASELINE configs[3]'s patches), where the 3x3 launches of the 88- and 176-pixel levels run FOLDED over the
+    virtual row of the four images and finish through the stream-K tail (parts combined in worker order by whichever workgroup
+    arrives last), the weight gradient's strips run folded, and the three-channel first layer runs on the matrix cores."""
     import copy
     from probabilistic_domain_adaptation_amd.my_trainer import FusedAdam
     from probabilistic_domain_adaptation_amd.my_trainer import fused as FU
-    x, x1, x2, y = [t.to(dev) for t in O.synth_batch(4, 1, 512, 512, 0)]
+    x, x1, x2, y = [t.to(dev) for t in O.synth_batch(4, channels, size, size, 0)]
     g = torch.Generator().manual_seed(3)
     eps_t, eps_s = torch.randn(8, 4, 6, generator=g).to(dev), torch.randn(4, 6, generator=g).to(dev)
     outs = []
     for _ in range(2):
-        m = _model(dev)
+        m = _model(dev, channels=channels)
         t = copy.deepcopy(m)
         opt = FusedAdam(m, lr=1e-4)
         loss, ys, zs, _ = FU.fused_self_training_step(m, t, opt, x1, x2, 8, True, eps_pl=eps_t, eps_s=eps_s)
