@@ -277,6 +277,37 @@ class SynthRawLoader:
             yield self.raw[i % len(self.raw)], self.y[i % len(self.y)]
 
 
+def traffic_from_profiles(conv_mode):
+    """roofline.traffic: HBM bytes per launch of the forward 3x3 instantiation from the newest committed PMC passes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.py -> profiles/rNN/pmc_hbm_traffic*.json).  Returns (bytes or None, note); a file
+    that cannot be read or has no entry for the kernel says so in the note instead of passing as "not collected"."""
+    fn, stem = {"x6": ("pmc_hbm_traffic_x6.json", "conv3x3_x6b_kernel<3, false"),
+                "f32": ("pmc_hbm_traffic.json", "conv_mfma_kernel<3, false")}[conv_mode]
+    try:
+        rdir = next(r for r in ("r05", "r04", "r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", r, fn)))
+        pm = json.load(open(os.path.join(ROOT, "profiles", rdir, fn)))
+        # the forward, bf16-plane, per-image instantiation: every template argument after the plane count is `false` (rounds 3 and 5
+        # added arguments to the kernels' names: "<3, false>", "<3, false, false>", "<3, false, false, false>")
+        key = next(k for k in pm["kernels"] if k.startswith(stem) and set(k[len(stem):].strip(">").replace(" ", "").split(",")) <= {"", "false"})
+        traffic = round(pm["kernels"][key]["hbm_bytes_per_launch"])
+        import hashlib
+        hh = hashlib.sha256()
+        for f_ in ("conv_x6.hip", "wgrad_x6.hip", "common.h"):
+            hh.update(open(os.path.join(ROOT, "probabilistic_domain_adaptation_amd", "csrc", f_), "rb").read())
+        same = pm.get("kernel_sources_sha16") == hh.hexdigest()[:16]
+        note = (f"NOT measured in this run: read from profiles/{rdir}/{fn} ({key}), collected at commit {pm.get('git_head', 'unknown (pre-r03 file)')}; "
+                f"kernel sources unchanged since that collection: {same if 'kernel_sources_sha16' in pm else 'unknown (pre-r03 file)'}; "
+                "= rocprofv3 --pmc FETCH_SIZE (x2, gfx950 "
+                "correction) + WRITE_SIZE in separate passes of this same command, bytes per launch, mean over the "
+                "launches of the forward instantiation (algorithmic mean over the 73 forward launches of a step: "
+                + ("250 MB with the up-blocks' entry convolutions in their low-resolution form, K5x" if rdir >= "r04"
+                   else "265 MB = 144 MB activations in + weight planes, 121 MB out")
+                + "); FETCH_SIZE includes the 1.33x halo re-reads of the 8x32-pixel tiles")
+        return traffic, note
+    except Exception as ex:
+        return None, f"the committed PMC file for this kernel could not be used ({type(ex).__name__}: {ex})"
+
+
 def fit_workload(a, dev, iterations, bare_ms_per_step=None, conv_mode=None):
     """What a user of the reference calls (LIVECell/livecell_mt.py:94-113): MeanTeacherTrainer.fit() with FusedAdam, graph=True and a
     DualViewLoader over raw patches (both views built by K13 on the GPU), two epochs of `iterations / 2` iterations, each followed
@@ -820,32 +851,8 @@ def main():
                            "share_of_step": round(v[1] / dt_eager, 3)} for k, v in agg.items()}
             k3 = agg.get("conv3x3_fwd")
             traffic, traffic_note = None, "not collected for this workload / shape"
-            try:  # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pmc_traffic.py)
-                if a.workload == "mean_teacher" and (B, H, W, N) == (4, 512, 512, 8) and eng.conv_mode in ("x6", "f32"):
-                    fn, key = {"x6": ("pmc_hbm_traffic_x6.json", "conv3x3_x6b_kernel<3, false>"),
-                               "f32": ("pmc_hbm_traffic.json", "conv_mfma_kernel<3, false>")}[eng.conv_mode]
-                    rdir = next(r for r in ("r05", "r04", "r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", r, fn)))
-                    pm = json.load(open(os.path.join(ROOT, "profiles", rdir, fn)))
-                    for extra in ("", ", false", ", false, false"):  # (rounds 3 and 5 added template arguments to the kernels' names)
-                        if key.replace("<3, false>", f"<3, false{extra}>") in pm["kernels"]:
-                            key = key.replace("<3, false>", f"<3, false{extra}>")
-                            break
-                    traffic = round(pm["kernels"][key]["hbm_bytes_per_launch"])
-                    import hashlib
-                    hh = hashlib.sha256()
-                    for f_ in ("conv_x6.hip", "wgrad_x6.hip", "common.h"):
-                        hh.update(open(os.path.join(ROOT, "probabilistic_domain_adaptation_amd", "csrc", f_), "rb").read())
-                    same = pm.get("kernel_sources_sha16") == hh.hexdigest()[:16]
-                    traffic_note = (f"NOT measured in this run: read from profiles/{rdir}/{fn}, collected at commit {pm.get('git_head', 'unknown (pre-r03 file)')}; "
-                                    f"kernel sources unchanged since that collection: {same if 'kernel_sources_sha16' in pm else 'unknown (pre-r03 file)'}; "
-                                    "= rocprofv3 --pmc FETCH_SIZE (x2, gfx950 "
-                                    "correction) + WRITE_SIZE in separate passes of this same command, bytes per launch, mean over the "
-                                    "launches of the forward instantiation (algorithmic mean over the 73 forward launches of a step: "
-                                    + ("250 MB with the up-blocks' entry convolutions in their low-resolution form, K5x" if rdir >= "r04"
-                                       else "265 MB = 144 MB activations in + weight planes, 121 MB out")
-                                    + "); FETCH_SIZE includes the 1.33x halo re-reads of the 8x32-pixel tiles")
-            except Exception:
-                pass
+            if a.workload == "mean_teacher" and (B, H, W, N) == (4, 512, 512, 8) and eng.conv_mode in ("x6", "f32"):
+                traffic, traffic_note = traffic_from_profiles(eng.conv_mode)
             if k3:
                 ach = k3[0] / k3[1] / 1e12
                 if eng.x6:

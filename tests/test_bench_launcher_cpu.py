@@ -48,3 +48,19 @@ def test_single_process_default_is_untouched_by_the_launcher():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip())
     assert out["n_gpus"] == 1 and out["launched_by"] == "external launcher"
+
+
+def test_roofline_traffic_is_found_in_the_committed_counter_files():
+    """bench.py's roofline.traffic is read from the newest committed PMC passes (profiles/rNN/pmc_hbm_traffic*.json).  The kernels' names
+    carry their template arguments and gained one in rounds 3 and 5: a lookup that no longer matches must not pass as a silent
+    `traffic: null` in the driver's line (it did for a few commits in round 5).  The x6 file must hold the forward, per-image,
+    bf16-plane instantiation, with a plausible byte count, the commit it was collected at and the digest of the kernel sources."""
+    sys.path.insert(0, ROOT)
+    import bench
+    traffic, note = bench.traffic_from_profiles("x6")
+    assert traffic is not None, note
+    assert 1e8 < traffic < 1e9, traffic                      # algorithmic 250 MB per launch; halo re-reads on top
+    assert "conv3x3_x6b_kernel<3, false" in note and "true" not in note.split(")")[0], note
+    assert "collected at commit" in note and "kernel sources unchanged since that collection: " in note
+    t32, n32 = bench.traffic_from_profiles("f32")
+    assert t32 is not None, n32
