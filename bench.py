@@ -459,8 +459,8 @@ def inference_hbm_report(H, W, ms_per_step):
                         "counted_note": f"NOT measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes over "
                                         f"this workload, summed over every kernel of a step, profiles/{rdir}/pmc_hbm_traffic_inference_1024.json "
                                         f"(collected at commit {pm.get('git_head', 'unknown')})"})
-    except Exception:
-        pass
+    except Exception as ex:
+        out["counted_note"] = f"the committed counter file could not be used ({type(ex).__name__}: {ex})"
     return out
 
 

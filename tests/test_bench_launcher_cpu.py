@@ -64,3 +64,13 @@ def test_roofline_traffic_is_found_in_the_committed_counter_files():
     assert "collected at commit" in note and "kernel sources unchanged since that collection: " in note
     t32, n32 = bench.traffic_from_profiles("f32")
     assert t32 is not None, n32
+
+
+def test_inference_hbm_report_reads_the_committed_counter_file():
+    """configs[4]'s hbm_report: the counted bytes per tile come from profiles/rNN/pmc_hbm_traffic_inference_1024.json."""
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.inference_hbm_report(1024, 1024, 10.5)
+    assert r["bound_in_this_design"] == "mfma" and r["algorithmic_min_bytes"] == int(78.1e6 + 9 * 1024 * 1024)
+    assert 1e10 < r["counted_hbm_bytes_per_step"] < 3e10, r.get("counted_note")
+    assert 0.1 < r["counted_frac_of_hbm_peak"] < 0.5
