@@ -31,6 +31,11 @@
 
 namespace {
 
+#ifndef PUNET_FT_PITCH  // A/B: 0 = the tile pitch before round 5 (CH + 32 / CH)
+#define PUNET_FT_PITCH 1
+#endif
+__host__ __device__ constexpr int ft_tile_pitch(int ch) { return PUNET_FT_PITCH ? ch + 4 : (ch % 64 == 0 ? ch + 32 : ch); }
+
 struct TrainArgs {
     const float* feat;    // [P][CH]
     const float* w1;      // [CH + L][CH], rows 0..CH-1 used
@@ -95,7 +100,12 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
     };
     constexpr int CH = 32 * NBLK;
     constexpr int WP = CH + 1;                       // weight pitch: row-wise AND column-wise b32 reads are conflict-free
-    constexpr int TP = (CH % 64 == 0) ? CH + 32 : CH;  // tile pitch: rows 2s and 2s+1 fall into different bank halves
+    // tile pitch CH + 4: the tiles are WRITTEN as one float4 per lane with a lane stride of one row, and every ds_write maps
+    // addresses onto 32 banks (cdna_hip_programming.md, LDS): with the former pitches (96 / 32 dwords = 0 mod 32) the 16 lanes of a
+    // write group fell onto the same four banks - SQ_LDS_BANK_CONFLICT was 60 % of this kernel's LDS cycles
+    // (profiles/r05/pmc_lds_conflicts_adamatch_704x704x3.json).  17 (9) slots of 16 bytes per row: consecutive lanes take
+    // consecutive slots mod 8.  The row-wise b32 reads (32 consecutive dwords per half-wave) are conflict-free at any pitch.
+    constexpr int TP = ft_tile_pitch(CH);
     constexpr int TILE = 32 * TP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sW1 = smem;                               // [CH][WP]
@@ -445,7 +455,7 @@ __global__ __launch_bounds__(256, 1) void fcomb_train_kernel(TrainArgs a) {
 
 template <int NBLK, int NMID>
 constexpr size_t train_smem_bytes() {
-    constexpr int CH = 32 * NBLK, WP = CH + 1, TP = (CH % 64 == 0) ? CH + 32 : CH;
+    constexpr int CH = 32 * NBLK, WP = CH + 1, TP = ft_tile_pitch(CH);
     return ((size_t)CH * WP * (1 + NMID) + (size_t)NMID * CH + CH + 4 + (size_t)4 * 2 * 32 * TP) * sizeof(float);
 }
 
