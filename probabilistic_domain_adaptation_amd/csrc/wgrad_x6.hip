@@ -354,8 +354,16 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6_kernel(WgradX6Args a) {
 // of tiles in strip-major order; where a run starts (slice start, top of a strip) its first tile is staged in full by a
 // prologue.  Fragment reads take the ring slot of their row from four (X) + two (dZ) per-tile base offsets.
 constexpr int XSLOTS = 6, DSLOTS = 4;
-constexpr int XIMGR = XSLOTS * HTW * ROWB;  // one (plane, ci block) ring image: 13,056 B
-constexpr int DIMGR = DSLOTS * WTW * ROWB;  // one (plane, co block) ring image: 8,192 B
+// The staging writes are 8 bytes per lane and the 16 lanes of a ds_write_b64 group are one pixel's 16 channel quads: quads 0-7 go
+// to the image of channel block 0, quads 8-15 to block 1's.  Every ds_write maps onto 32 banks (128 bytes): with images a multiple
+// of 128 bytes apart the two halves of a group shared 16 banks (2 LDS cycles per group instead of 1; SQ_LDS_BANK_CONFLICT was 13 %
+// of this kernel's LDS cycles, profiles/r05/pmc_lds_conflicts_adamatch_704x704x3.json).  64 bytes of padding per image put block
+// 1's quads on the other 16 banks.  (The fragment reads of a wave stay inside one image: unaffected.)
+#ifndef PUNET_WGRAD_IMGPAD
+#define PUNET_WGRAD_IMGPAD 64
+#endif
+constexpr int XIMGR = XSLOTS * HTW * ROWB + PUNET_WGRAD_IMGPAD;  // one (plane, ci block) ring image: 13,056 B + padding
+constexpr int DIMGR = DSLOTS * WTW * ROWB + PUNET_WGRAD_IMGPAD;  // one (plane, co block) ring image: 8,192 B + padding
 
 // xa / db: per-lane byte offsets of the tile's four X rows / two dZ rows, INCLUDING the wave's channel-block image (the
 // remaining compile-time part - plane, column, tap - then fits the 16-bit offset field of the LDS instruction)
@@ -474,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_x6r_kernel(WgradX6Args a) {
     static_assert(!X16 || NP == 1, "16-bit activation storage exists for the one-plane arithmetic only");
     static_assert(!F16 || NP <= 2, "fp16 operands: one or two planes");
     constexpr int HTW = ::HTW_BASE + (FOLD ? 2 : 0);            // (shadow the namespace constants: rows of the X ring are 36 pixels)
-    constexpr int XIMGR = XSLOTS * HTW * ROWB;
+    constexpr int XIMGR = XSLOTS * HTW * ROWB + PUNET_WGRAD_IMGPAD;
     float sxs = 1.f, sds = 1.f;  // F16: operand scales (block-uniform)
     if constexpr (F16) {
         if (!X16) sxs = punet_f16_scale_from(a.amax_x);
