@@ -333,6 +333,8 @@ def fit_workload(a, dev, iterations, bare_ms_per_step=None, conv_mode=None):
         times = {"train": 0.0, "val": 0.0, "ckpt": 0.0}
         inner_train, inner_val, inner_ckpt = tr._train_epoch_impl, tr._validate_impl, tr.save_checkpoint
 
+        each = {"train": [], "val": [], "ckpt": []}
+
         def timed(key, fn):
             def w(*args, **kw):
                 torch.cuda.synchronize()
@@ -340,6 +342,7 @@ def fit_workload(a, dev, iterations, bare_ms_per_step=None, conv_mode=None):
                 r = fn(*args, **kw)
                 torch.cuda.synchronize()
                 times[key] += time.perf_counter() - t0
+                each[key].append(round(time.perf_counter() - t0, 4))
                 return r
             return w
 
@@ -370,7 +373,7 @@ def fit_workload(a, dev, iterations, bare_ms_per_step=None, conv_mode=None):
                "train_loop_patches_per_s": round(1e3 * B / ms_iter, 3),
                "host_ms_per_iteration": round(1e3 * t_enq / n_enq, 3),
                "validation_s_per_epoch": round(times["val"] / 2, 3), "checkpoints_s_per_epoch": round(times["ckpt"] / 2, 3),
-               "fit_wall_s": round(wall, 3), "whole_fit_patches_per_s": round(B * done / wall, 3),
+               "train_epoch_s": each["train"], "fit_wall_s": round(wall, 3), "whole_fit_patches_per_s": round(B * done / wall, 3),
                "final_loss": float(tr.last_loss) if tr.last_loss is not None else None}
         if bare_ms_per_step:
             out["bare_step_ms"] = round(bare_ms_per_step, 3)
@@ -670,7 +673,7 @@ def main():
             torch.cuda.synchronize()
 
     B, H, W, N = a.batch, a.size, a.size, a.samples
-    fit_iterations = a.fit_iterations if a.workload == "fit" else (60 if not a.no_other_configs else 0)
+    fit_iterations = a.fit_iterations if a.workload == "fit" else (120 if not a.no_other_configs else 0)
     if a.workload == "fit":
         a.workload = "mean_teacher"
     use_graph = not a.no_graph
