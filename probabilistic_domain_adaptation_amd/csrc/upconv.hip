@@ -442,7 +442,13 @@ __global__ __launch_bounds__(512, 2) void upconv_wgrad_x6_kernel(UpWgradArgs a) 
 // 16 KB of x + 24 KB of dzt for the same 36 MFMAs per wave (0.625 x the bytes per MFMA), the nine maps are read by HALF as many
 // ci tiles, and with 2 x 60 KB of images the next tile is written while the current one is still being read: ONE barrier per
 // tile.  48 channel groups x 5 slices = 240 workgroups at the deepest block (12 x 21, 3 x 85 at the other two).
-constexpr int U2CI = 128, U2PD = 32, U2IMG = U2PD * UROWB;  // 2 KB images: 32 pixels x 32 channels
+// (images 2 KB + 64 bytes apart: the 16 lanes of a staging ds_write_b64 group are one pixel's channel quads of TWO neighbouring
+// channel-block images, and every ds_write maps onto 32 banks = 128 bytes - a multiple of 128 bytes apart the two images shared 16
+// banks: SQ_LDS_BANK_CONFLICT was 33 % of this kernel's LDS cycles; wgrad_x6.hip has the same padding)
+#ifndef PUNET_UPWGRAD_IMGPAD
+#define PUNET_UPWGRAD_IMGPAD 64
+#endif
+constexpr int U2CI = 128, U2PD = 32, U2IMG = U2PD * UROWB + PUNET_UPWGRAD_IMGPAD;  // 2 KB images: 32 pixels x 32 channels
 constexpr int U2X = 3 * 4 * U2IMG, U2D = UTAPS * 3 * 2 * U2IMG, U2SET = U2X + U2D;  // 24 KB + 36 KB per set
 
 __global__ __launch_bounds__(512, 2) void upconv_wgrad_x6w_kernel(UpWgradArgs a) {
@@ -686,7 +692,7 @@ extern "C" int punet_upconv_wgrad_x6(const float* x, int cup, const float* dzt, 
     a.x = x; a.dzt = dzt; a.partial = workspace; a.cs = cup; a.cout = cout; a.nslices = nslices; a.M = (long)B * h * w;
     int nslabs;
     if (punet_upconv_wgrad_wide()) {
-        constexpr int SMEM = 2 * U2SET;  // 122,880 B
+        constexpr int SMEM = 2 * U2SET;  // 122,880 B + the images' padding
         if (hipFuncSetAttribute((const void*)upconv_wgrad_x6w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
             punet_set_error("punet_upconv_wgrad_x6: cannot reserve %d bytes of LDS", SMEM);
             return PUNET_ERR_HIP;
